@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF on CPU.
+
+The reference (EdoardoBotta/RQ-VAE-Recommender, mounted read-only at /root/reference) has no tests,
+golden vectors or checkpoints for this path, so the oracle is pinned against
+outputs of the reference's own modules, imported in place -- nothing is copied from it.  The
+reference cannot travel to the GPU box, so the (small) vectors are committed together with this
+script.  Re-run:  python oracle/gen_golden.py   (needs /root/reference; CPU only; ~1 min)
+
+`gin-config` is not installable here; a 3-function stand-in is registered in sys.modules before the
+import (decorators become identities).  `data.processed` (torch_geometric/polars) is stubbed for
+modules/tokenizer/semids.py, which only uses the name `ItemData` as a type annotation.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("RQ_REFERENCE_ROOT", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _install_stubs() -> None:
+    gin = types.ModuleType("gin")
+    gin.constants_from_enum = lambda cls=None, **kw: cls
+    gin.configurable = lambda f=None, **kw: f if callable(f) else (lambda g: g)
+    gin.parse_config_file = lambda *a, **k: None
+    sys.modules.setdefault("gin", gin)
+    dp = types.ModuleType("data.processed")
+    dp.ItemData = object
+    sys.modules.setdefault("data.processed", dp)
+
+
+def import_reference():
+    _install_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from modules import quantize as q  # noqa
+    from modules import rqvae as r  # noqa
+    from init import kmeans as km  # noqa
+    from modules.tokenizer import semids as sem  # noqa
+    from data import schemas as sch  # noqa
+    return q, r, km, sem, sch
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32, copy=True)
+
+
+def gen_quantize(q):
+    """Quantize.forward (quantize.py:104-163), one level, eval / STE / rotation + autograd grads."""
+    cases = [
+        ("a", 96, 32, 256, 11),
+        ("b", 50, 64, 256, 12),   # ml32m width, B not a multiple of anything
+        ("c", 33, 16, 32, 13),    # class defaults of train(): D=16, K=32
+        ("d", 7, 8, 5, 14),       # K not a multiple of 32, tiny
+    ]
+    for tag, B, D, K, seed in cases:
+        for mode_name, fm, training in (("eval", q.QuantizeForwardMode.STE, False),
+                                        ("ste", q.QuantizeForwardMode.STE, True),
+                                        ("rotation", q.QuantizeForwardMode.ROTATION_TRICK, True)):
+            g = torch.Generator().manual_seed(seed)
+            x = torch.randn(B, D, generator=g) * 0.7
+            cb = torch.randn(K, D, generator=g) * 0.6
+            layer = q.Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=fm,
+                               commitment_weight=0.25)
+            with torch.no_grad():
+                layer.embedding.weight.copy_(cb)
+            layer.train(training)
+            xr = x.clone().requires_grad_(True)
+            out = layer(xr, temperature=0.2)
+            g_emb = torch.randn(B, D, generator=g)
+            g_loss = torch.rand(B, generator=g)
+            (out.embeddings * g_emb).sum().add((out.loss * g_loss).sum()).backward()
+            np.savez_compressed(
+                os.path.join(OUT, f"quantize_{mode_name}_{tag}.npz"),
+                x=np32(x), codebook=np32(cb), beta=np.float32(0.25),
+                ids=out.ids.numpy().astype(np.int64), embeddings=np32(out.embeddings), loss=np32(out.loss),
+                g_emb=np32(g_emb), g_loss=np32(g_loss), grad_x=np32(xr.grad),
+                grad_codebook=np32(layer.embedding.weight.grad))
+
+
+def gen_gumbel(q):
+    """Training-mode GUMBEL_SOFTMAX level (quantize.py:131-136; gumbel.py:8-20).  The uniform noise the
+    reference drew is recovered by re-seeding and calling torch.rand with the same shape."""
+    for tag, B, D, K, seed, T in (("a", 40, 32, 256, 21, 0.2), ("b", 17, 16, 32, 22, 0.5)):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, D, generator=g) * 0.5
+        cb = torch.randn(K, D, generator=g) * 0.5
+        layer = q.Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False,
+                           forward_mode=q.QuantizeForwardMode.GUMBEL_SOFTMAX, commitment_weight=0.25)
+        with torch.no_grad():
+            layer.embedding.weight.copy_(cb)
+        layer.train()
+        xr = x.clone().requires_grad_(True)
+        torch.manual_seed(1000 + seed)
+        out = layer(xr, temperature=T)
+        torch.manual_seed(1000 + seed)
+        U = torch.rand(B, K)
+        g_emb = torch.randn(B, D, generator=g)
+        g_loss = torch.rand(B, generator=g)
+        (out.embeddings * g_emb).sum().add((out.loss * g_loss).sum()).backward()
+        np.savez_compressed(
+            os.path.join(OUT, f"gumbel_{tag}.npz"),
+            x=np32(x), codebook=np32(cb), U=np32(U), temperature=np.float32(T), beta=np.float32(0.25),
+            ids=out.ids.numpy().astype(np.int64), embeddings=np32(out.embeddings), loss=np32(out.loss),
+            g_emb=np32(g_emb), g_loss=np32(g_loss), grad_x=np32(xr.grad),
+            grad_codebook=np32(layer.embedding.weight.grad))
+
+
+def gen_rqvae(q, r, sch):
+    """RqVae.get_semantic_ids / RqVae.forward (rqvae.py:118-175) on a small model, all weights stored.
+    forward is taken un-compiled (RqVae.forward._torchdynamo_orig_callable) to skip inductor."""
+    fwd = getattr(r.RqVae.forward, "_torchdynamo_orig_callable", None)
+    assert fwd is not None, "expected torch.compile-wrapped RqVae.forward"
+    cfgs = [
+        ("small_ste", dict(input_dim=48, embed_dim=16, hidden_dims=[32, 24], codebook_size=32, n_layers=3,
+                           n_cat_features=0), q.QuantizeForwardMode.STE, 80, 31),
+        ("small_rot", dict(input_dim=48, embed_dim=16, hidden_dims=[32, 24], codebook_size=32, n_layers=3,
+                           n_cat_features=0), q.QuantizeForwardMode.ROTATION_TRICK, 80, 32),
+        ("wide_ste", dict(input_dim=64, embed_dim=32, hidden_dims=[48], codebook_size=256, n_layers=4,
+                          n_cat_features=0), q.QuantizeForwardMode.STE, 200, 33),
+        ("cat_ste", dict(input_dim=40, embed_dim=8, hidden_dims=[24], codebook_size=16, n_layers=2,
+                         n_cat_features=6), q.QuantizeForwardMode.STE, 64, 34),
+    ]
+    for tag, kw, mode, B, seed in cfgs:
+        torch.manual_seed(seed)
+        model = r.RqVae(codebook_kmeans_init=False, codebook_mode=mode, commitment_weight=0.25, **kw)
+        g = torch.Generator().manual_seed(seed)
+        # spread the codebooks like trained ones (uniform(0,1) init collapses every row onto few codes)
+        with torch.no_grad():
+            for l, layer in enumerate(model.layers):
+                layer.embedding.weight.copy_(torch.randn(kw["codebook_size"], kw["embed_dim"], generator=g)
+                                             * (0.35 / (l + 1)))
+        x = torch.nn.functional.normalize(torch.randn(B, kw["input_dim"], generator=g), dim=-1)
+        if kw["n_cat_features"]:
+            x[:, -kw["n_cat_features"]:] = (torch.rand(B, kw["n_cat_features"], generator=g) > 0.7).float()
+        x[B // 2] = x[B // 4]  # a guaranteed duplicate row -> p_unique_ids < 1
+        batch = sch.SeqBatch(user_ids=None, ids=None, ids_fut=None, x=x, x_fut=None, seq_mask=None)
+        save = {f"param::{k}": np32(v) for k, v in model.state_dict().items()}
+        save["x"] = np32(x)
+        save["beta"] = np.float32(0.25)
+        for training in (True, False):
+            model.train(training)
+            model.zero_grad()
+            sem = model.get_semantic_ids(x, 0.2)
+            out = fwd(model, batch, 0.2)
+            out.loss.backward()
+            p = "train_" if training else "eval_"
+            save[p + "res0"] = np32(model.encode(x))
+            save[p + "embeddings"] = np32(sem.embeddings)        # [B,D,L]
+            save[p + "residuals"] = np32(sem.residuals)          # [B,D,L]
+            save[p + "sem_ids"] = sem.sem_ids.numpy().astype(np.int64)  # [B,L]
+            save[p + "quantize_loss"] = np32(sem.quantize_loss)
+            save[p + "loss"] = np32(out.loss)
+            save[p + "reconstruction_loss"] = np32(out.reconstruction_loss)
+            save[p + "rqvae_loss"] = np32(out.rqvae_loss)
+            save[p + "embs_norm"] = np32(out.embs_norm)
+            save[p + "p_unique_ids"] = np32(out.p_unique_ids)
+            for k, v in model.named_parameters():
+                save[p + "grad::" + k] = np32(v.grad)
+        np.savez_compressed(os.path.join(OUT, f"rqvae_{tag}.npz"), **save)
+
+
+def gen_kmeans(km):
+    """Kmeans.run (kmeans.py:61-72).  Records np.random.choice's rows and every torch.randint draw."""
+    cases = [("a", 300, 16, 8, 41, None), ("b", 500, 32, 64, 42, 3), ("dup", 64, 8, 6, 43, None)]
+    for tag, B, D, K, seed, max_iters in cases:
+        g = torch.Generator().manual_seed(seed)
+        centers = torch.randn(K, D, generator=g) * 2.0
+        x = centers[torch.randint(0, K, (B,), generator=g)] + 0.3 * torch.randn(B, D, generator=g)
+        np.random.seed(seed)
+        init_idx = np.random.choice(B, K, replace=False)
+        if tag == "dup":
+            # two identical seed rows -> the later one can never win the argmin -> empty cluster -> reseed
+            x[init_idx[3]] = x[init_idx[1]]
+        draws = []
+        real_randint = torch.randint
+
+        def logging_randint(*a, **k):
+            out = real_randint(*a, **k)
+            draws.append(int(out.reshape(-1)[0]))
+            return out
+
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        torch.randint = logging_randint
+        try:
+            algo = km.Kmeans(k=K, max_iters=max_iters)
+            out = algo.run(x.clone())
+        finally:
+            torch.randint = real_randint
+        np.savez_compressed(
+            os.path.join(OUT, f"kmeans_{tag}.npz"),
+            x=np32(x), k=np.int64(K), seed=np.int64(seed), max_iters=np.int64(-1 if max_iters is None else max_iters),
+            init_idx=init_idx.astype(np.int64), reseed_draws=np.asarray(draws, dtype=np.int64),
+            centroids=np32(out.centroids), assignment=out.assignment.numpy().astype(np.int64))
+
+
+def gen_dedup(q, r, sem, sch):
+    """SemanticIdTokenizer.precompute_corpus_ids (semids.py:76-110): [N, L+1], last column = number of
+    earlier rows with the same tuple.  N > 512 so that the cross-batch branch (:100-104) runs."""
+    torch.manual_seed(51)
+    tok = sem.SemanticIdTokenizer(input_dim=24, output_dim=8, hidden_dims=[16], codebook_size=4, n_layers=3,
+                                  n_cat_feats=0)
+    g = torch.Generator().manual_seed(51)
+    with torch.no_grad():
+        for l, layer in enumerate(tok.rq_vae.layers):
+            layer.embedding.weight.copy_(torch.randn(4, 8, generator=g) * (0.4 / (l + 1)))
+    N = 700
+    X = torch.randn(N, 24, generator=g)
+
+    class DS:
+        def __len__(self):
+            return N
+
+        def __getitem__(self, idx):
+            # like ItemData.__getitem__ (data/processed.py:74-86) for a list index: ids is [1, len(idx)]
+            ids = torch.tensor(idx).unsqueeze(0)
+            return sch.SeqBatch(user_ids=-torch.ones_like(ids.squeeze(0)), ids=ids,
+                                ids_fut=-torch.ones_like(ids.squeeze(0)), x=X[idx],
+                                x_fut=-torch.ones_like(ids.squeeze(0)), seq_mask=torch.ones_like(ids, dtype=bool))
+
+    ids = tok.precompute_corpus_ids(DS())
+    save = {f"param::{k}": np32(v) for k, v in tok.rq_vae.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "dedup_a.npz"), x=np32(X), corpus_ids=ids.numpy().astype(np.int64), **save)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    q, r, km, sem, sch = import_reference()
+    gen_quantize(q)
+    gen_gumbel(q)
+    gen_rqvae(q, r, sch)
+    gen_kmeans(km)
+    gen_dedup(q, r, sem, sch)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"wrote {len(os.listdir(OUT))} fixtures, {total / 1024:.0f} KiB -> {os.path.abspath(OUT)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""ctypes/numpy binding of the CPU oracle (oracle/rq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of rq_oracle.c.  Importable from tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg; the product package
+(``rq-vae-recommender_amd/``) never imports it.
+
+Every function takes/returns numpy arrays (fp32 / int64, C-contiguous) and mirrors one entry point
+of the C file; the reference lines each restates are cited there.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librq_oracle.so")
+
+MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> str:
+    """Compile librq_oracle.so with the committed Makefile (gcc only, no third-party deps)."""
+    src = os.path.join(_HERE, "rq_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.rqo_kmeans_shift.restype = C.c_float
+        _lib.rqo_sumsq2.restype = C.c_float
+        _lib.rqo_count_rows_without_later_duplicate.restype = C.c_int64
+    return _lib
+
+
+def _f(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def rq_forward(res0, codebooks, mode: int, beta: float = 0.25):
+    """L chained quantisation levels.  Returns dict(ids [L,B], embs [L,B,D], residuals [L,B,D],
+    emb_sum [B,D], loss [B], embs_norm [B,L])."""
+    res0, codebooks = _f(res0), _f(codebooks)
+    B, D = res0.shape
+    L, K, D2 = codebooks.shape
+    assert D == D2
+    out = dict(ids=np.empty((L, B), np.int64), embs=np.empty((L, B, D), np.float32),
+               residuals=np.empty((L, B, D), np.float32), emb_sum=np.empty((B, D), np.float32),
+               loss=np.empty((B,), np.float32), embs_norm=np.empty((B, L), np.float32))
+    rc = lib().rqo_rq_forward(_p(res0), C.c_int64(B), C.c_int(D), _p(codebooks), C.c_int(L), C.c_int(K),
+                              C.c_int(mode), C.c_float(beta), _p(out["ids"]), _p(out["embs"]),
+                              _p(out["residuals"]), _p(out["emb_sum"]), _p(out["loss"]),
+                              _p(out["embs_norm"]))
+    _chk(rc, "rq_forward")
+    return out
+
+
+def rq_backward(res0, codebooks, mode: int, beta: float, ids, g_embs=None, g_embsum=None,
+                g_resid=None, g_loss=None):
+    """Closed-form backward of rq_forward.  Returns (g_res0 [B,D], g_codebooks [L,K,D])."""
+    res0, codebooks = _f(res0), _f(codebooks)
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    B, D = res0.shape
+    L, K, _ = codebooks.shape
+    ge = None if g_embs is None else _f(g_embs)
+    gs = None if g_embsum is None else _f(g_embsum)
+    gr = None if g_resid is None else _f(g_resid)
+    gl = None if g_loss is None else _f(g_loss)
+    g_res0 = np.empty((B, D), np.float32)
+    g_cb = np.empty((L, K, D), np.float32)
+    rc = lib().rqo_rq_backward(_p(res0), C.c_int64(B), C.c_int(D), _p(codebooks), C.c_int(L), C.c_int(K),
+                               C.c_int(mode), C.c_float(beta), _p(ids), _p(ge), _p(gs), _p(gr), _p(gl),
+                               _p(g_res0), _p(g_cb))
+    _chk(rc, "rq_backward")
+    return g_res0, g_cb
+
+
+def gumbel_forward(x, cb, U, temperature: float, beta: float = 0.25):
+    x, cb, U = _f(x), _f(cb), _f(U)
+    B, D = x.shape
+    K = cb.shape[0]
+    out = dict(ids=np.empty((B,), np.int64), emb=np.empty((B, D), np.float32),
+               loss=np.empty((B,), np.float32), weights=np.empty((B, K), np.float32))
+    rc = lib().rqo_gumbel_forward(_p(x), C.c_int64(B), C.c_int(D), _p(cb), C.c_int(K), _p(U),
+                                  C.c_float(temperature), C.c_float(beta), _p(out["ids"]), _p(out["emb"]),
+                                  _p(out["loss"]), _p(out["weights"]))
+    _chk(rc, "gumbel_forward")
+    return out
+
+
+def gumbel_backward(x, cb, U, temperature: float, beta: float, g_emb=None, g_loss=None):
+    x, cb, U = _f(x), _f(cb), _f(U)
+    B, D = x.shape
+    K = cb.shape[0]
+    ge = None if g_emb is None else _f(g_emb)
+    gl = None if g_loss is None else _f(g_loss)
+    g_x = np.empty((B, D), np.float32)
+    g_cb = np.empty((K, D), np.float32)
+    rc = lib().rqo_gumbel_backward(_p(x), C.c_int64(B), C.c_int(D), _p(cb), C.c_int(K), _p(U),
+                                   C.c_float(temperature), C.c_float(beta), _p(ge), _p(gl), _p(g_x), _p(g_cb))
+    _chk(rc, "gumbel_backward")
+    return g_x, g_cb
+
+
+def kmeans_assign(x, cent) -> np.ndarray:
+    x, cent = _f(x), _f(cent)
+    B, D = x.shape
+    K = cent.shape[0]
+    a = np.empty((B,), np.int64)
+    _chk(lib().rqo_kmeans_assign(_p(x), C.c_int64(B), C.c_int(D), _p(cent), C.c_int(K), _p(a)), "kmeans_assign")
+    return a
+
+
+def kmeans_update(x, assign, cent):
+    """In-place centroid update; returns counts [K] (0 => cluster empty, centroid untouched)."""
+    x = _f(x)
+    assert cent.dtype == np.float32 and cent.flags.c_contiguous
+    assign = np.ascontiguousarray(assign, dtype=np.int64)
+    B, D = x.shape
+    K = cent.shape[0]
+    counts = np.empty((K,), np.int64)
+    _chk(lib().rqo_kmeans_update(_p(x), C.c_int64(B), C.c_int(D), _p(assign), C.c_int(K), _p(cent), _p(counts)),
+         "kmeans_update")
+    return counts
+
+
+def kmeans_shift(cent, old) -> float:
+    cent, old = _f(cent), _f(old)
+    K, D = cent.shape
+    return float(lib().rqo_kmeans_shift(_p(cent), _p(old), C.c_int(K), C.c_int(D)))
+
+
+def kmeans_run(x, init_idx, reseed_draws=None, max_iters=None, stop_threshold: float = 1e-10):
+    """Lloyd loop of init/kmeans.py:61-72 given the rows np.random.choice picked (init_idx) and a
+    callable ``reseed_draws() -> int`` standing in for torch.randint(0, B, (1,)) (kmeans.py:53).
+    Returns (centroids [K,D], assignment [B], n_update_calls)."""
+    x = _f(x)
+    cent = x[np.asarray(init_idx)].copy()
+    K = cent.shape[0]
+    assign = None
+    i = 0
+    calls = 0
+    while max_iters is None or i < max_iters:
+        old = cent.copy()
+        assign = kmeans_assign(x, cent)
+        counts = kmeans_update(x, assign, cent)
+        calls += 1
+        for k in range(K):
+            if counts[k] == 0:
+                if x.shape[0] == 0:
+                    raise ValueError("Can not choose random element from x, x is empty")
+                cent[k] = x[int(reseed_draws())]
+        if kmeans_shift(cent, old) < stop_threshold:
+            break
+        i += 1
+    return cent, assign, calls
+
+
+def dedup_rank(ids) -> np.ndarray:
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    L, B = ids.shape
+    r = np.empty((B,), np.int64)
+    _chk(lib().rqo_dedup_rank(_p(ids), C.c_int64(B), C.c_int(L), _p(r)), "dedup_rank")
+    return r
+
+
+def count_rows_without_later_duplicate(ids) -> int:
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    L, B = ids.shape
+    return int(lib().rqo_count_rows_without_later_duplicate(_p(ids), C.c_int64(B), C.c_int(L)))
