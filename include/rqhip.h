@@ -1,0 +1,147 @@
+/*
+ * rqhip.h -- C ABI of librqhip.so: the MI355X (gfx950) residual-quantisation hot path.
+ *
+ * The reference (EdoardoBotta/RQ-VAE-Recommender) is pure Python: it has no FFI, plugin or operator
+ * registry for this path, so the drop-in boundary is its Python module API (modules.quantize.Quantize,
+ * modules.rqvae.RqVae, init.kmeans.kmeans_init_, ...; mirrored under rq-vae-recommender_amd/).  This
+ * header is the C boundary UNDER that mirror: plain pointers and sizes, no torch types.  Each entry
+ * point names the reference code it replaces (paths relative to the reference root); INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add to call it from modules/quantize.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch CUDA tensor data_ptr), fp32 row-major
+ *     contiguous, ids int64; optional outputs/inputs may be NULL where stated.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns
+ *     without synchronising.  The library never allocates, frees or retains device memory: scratch
+ *     comes from the caller (`workspace`, size from the matching *_workspace_bytes()).
+ *   - return value: 0 = success; negative = RQHIP_E* argument/shape error; positive = hipError_t.
+ *     rqhip_last_error() returns a thread-local message for the last failure.
+ *   - results are bit-exact with oracle/rq_oracle.c (which fixes every floating-point reduction
+ *     order) for everything except transcendental functions in the Gumbel path.
+ */
+#ifndef RQHIP_H
+#define RQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RQHIP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#define RQHIP_OK 0
+#define RQHIP_EARG (-1)         /* bad pointer / size / mode */
+#define RQHIP_EUNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. D > 128) */
+#define RQHIP_EWORKSPACE (-3)   /* workspace missing or too small */
+
+/* forward modes == the reference's QuantizeForwardMode (modules/quantize.py:16-20) plus eval */
+#define RQHIP_MODE_EVAL 0     /* module.eval(): quantize.py:159-161 */
+#define RQHIP_MODE_STE 1      /* QuantizeForwardMode.STE, training: quantize.py:137-139 */
+#define RQHIP_MODE_ROTATION 2 /* QuantizeForwardMode.ROTATION_TRICK, training: quantize.py:140-153 */
+#define RQHIP_MODE_GUMBEL 3   /* QuantizeForwardMode.GUMBEL_SOFTMAX, training: quantize.py:131-136 */
+
+typedef void *rqhip_stream_t;
+
+int rqhip_version(void);
+const char *rqhip_last_error(void);
+/* number of compute units of the current device (grid sizing, reported by bench.py) */
+int rqhip_device_cu_count(int *cu_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * Residual quantisation, forward.  Replaces the level loop of RqVae.get_semantic_ids
+ * (modules/rqvae.py:118-139) together with every Quantize.forward it calls (modules/quantize.py:
+ * 104-163: L2 distance :112-117, argmin :128, STE :137-139 / rotation trick :140-153 / eval :159-161,
+ * QuantizeLoss modules/loss.py:33-41) and the embs.sum / embs.norm consumers (rqvae.py:146,158).
+ * L = 1 is a single Quantize.forward.
+ *
+ *   res0      [B,D]    level-0 input (encoder output)
+ *   codebooks [L,K,D]  out_proj(embedding.weight) of each level
+ *   mode      RQHIP_MODE_EVAL | _STE | _ROTATION
+ *   beta      commitment weight
+ *   ids       [L,B] int64 (required)   -- sem_ids[b,l] = ids[l*B + b]
+ *   embs      [L,B,D] or NULL          -- quantized.embeddings per level
+ *   residuals [L,B,D] or NULL          -- input of each level
+ *   emb_sum   [B,D]   or NULL          -- sum over levels of embs, ((e0+e1)+e2)+...
+ *   loss      [B]     or NULL          -- sum over levels of the quantize loss
+ *   embs_norm [B,L]   or NULL          -- L2 norm of embs per level
+ *   workspace rqhip_rq_forward_workspace_bytes(L,K) bytes of scratch (codebook norms)
+ * Limits: 1 <= D <= 128, 1 <= K <= 65536, 1 <= L <= 16.
+ */
+size_t rqhip_rq_forward_workspace_bytes(int L, int K);
+int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                     int mode, float beta, int64_t *ids, float *embs, float *residuals,
+                     float *emb_sum, float *loss, float *embs_norm, void *workspace,
+                     size_t workspace_bytes, rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Residual quantisation, backward: what torch.autograd computes through the code above
+ * (embedding backward + STE / rotation / eval branches + QuantizeLoss), in closed form.
+ *
+ *   upstream gradients (each may be NULL = zeros):
+ *     g_embs [L,B,D] wrt embs, g_embsum [B,D] wrt emb_sum, g_resid [L,B,D] wrt residuals,
+ *     g_loss [B] wrt loss
+ *   outputs: g_res0 [B,D] (may be NULL), g_codebooks [L,K,D] (may be NULL; OVERWRITTEN, each entry
+ *     is the sum over its rows in ascending row order -- deterministic)
+ *   workspace: rqhip_rq_backward_workspace_bytes(B,D,L) bytes
+ */
+size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L);
+int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                      int mode, float beta, const int64_t *ids, const float *g_embs,
+                      const float *g_embsum, const float *g_resid, const float *g_loss,
+                      float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
+                      rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One Gumbel-softmax level, training mode.  Replaces quantize.py:112-117,128,131-136,157 and
+ * distributions/gumbel.py:8-20.  The uniform noise U [B,K] is supplied by the caller (torch.rand on
+ * the device), exactly where the reference draws it.
+ *   outputs: ids [B] (argmin of the noise-free distance), emb [B,D] (= embeddings), loss [B]
+ */
+int rqhip_gumbel_forward(const float *x, int64_t B, int D, const float *codebook, int K,
+                         const float *U, float temperature, float beta, int64_t *ids, float *emb,
+                         float *loss, rqhip_stream_t stream);
+/*   g_emb [B,D] / g_loss [B] upstream (may be NULL); outputs g_x [B,D], g_codebook [K,D] (overwritten).
+ *   workspace: rqhip_gumbel_backward_workspace_bytes(B,D,K) */
+size_t rqhip_gumbel_backward_workspace_bytes(int64_t B, int D, int K);
+int rqhip_gumbel_backward(const float *x, int64_t B, int D, const float *codebook, int K,
+                          const float *U, float temperature, float beta, const float *g_emb,
+                          const float *g_loss, float *g_x, float *g_codebook, void *workspace,
+                          size_t workspace_bytes, rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * k-means codebook initialisation (init/kmeans.py).  The Lloyd loop, the np.random.choice seeding
+ * and the torch.randint reseed of empty clusters stay on the host (they consume host RNG streams
+ * the reference's results depend on); these are the two data-parallel steps of one iteration.
+ *
+ * rqhip_kmeans_assign : kmeans.py:40-43  assign[i] = argmin_k sum_d (x[i,d]-c[k,d])^2
+ * rqhip_kmeans_update : kmeans.py:44-59  c[k] <- mean of its rows (ascending-row sum / count);
+ *                       empty clusters are left untouched, counts[k] == 0 reports them;
+ *                       shift_sq_max (device scalar, may be NULL) <- max_k sum_d (c_new-c_old)^2,
+ *                       i.e. the square of kmeans.py:68's torch.norm(...).max(), computed BEFORE any
+ *                       host reseed (the host adds the reseeded rows' shift itself).
+ */
+int rqhip_kmeans_assign(const float *x, int64_t B, int D, const float *centroids, int K,
+                        int64_t *assign, rqhip_stream_t stream);
+int rqhip_kmeans_update(const float *x, int64_t B, int D, const int64_t *assign, int K,
+                        float *centroids, int64_t *counts, float *shift_sq_max,
+                        rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Semantic-id statistics.
+ * rqhip_dedup_rank: rank[i] = number of rows j < i whose L-tuple equals row i's -- the dedup column
+ *   of SemanticIdTokenizer.precompute_corpus_ids (modules/tokenizer/semids.py:92-108).  Also yields
+ *   n_distinct = number of rows with no LATER duplicate, i.e. B * p_unique_ids of rqvae.py:159-167.
+ *   ids [L,B] int64 with 0 <= id < K; rank [B] int64 or NULL; n_distinct device int64 scalar or NULL.
+ *   workspace: rqhip_dedup_workspace_bytes(B)
+ */
+size_t rqhip_dedup_workspace_bytes(int64_t B);
+int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int64_t *rank,
+                     int64_t *n_distinct, void *workspace, size_t workspace_bytes,
+                     rqhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RQHIP_H */

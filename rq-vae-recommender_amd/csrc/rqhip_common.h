@@ -1,0 +1,50 @@
+// rqhip_common.h -- shared device/host helpers for librqhip (gfx950 only).
+//
+// Numerics contract (see include/rqhip.h and oracle/rq_oracle.c): the library is compiled with
+// -ffp-contract=off, so the ONLY fused multiply-adds are the explicit __builtin_fmaf calls and the MFMA
+// instructions (which are fp32 FMA chains in k order).  Reductions over the feature dimension use two
+// accumulators split by the parity of d -- the split the 32x32x2 MFMA operand layout induces (lanes 0-31
+// hold even d, lanes 32-63 odd d) -- combined as a0 + a1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rqhip.h"
+
+#define RQ_WAVE 64
+
+namespace rqhip {
+
+void set_error(const char *fmt, ...);
+
+inline int check_hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define RQ_RETURN_IF_HIP(expr)                                                      \
+    do {                                                                            \
+        int _rc = ::rqhip::check_hip((expr), #expr);                                \
+        if (_rc) return _rc;                                                        \
+    } while (0)
+
+#define RQ_CHECK_LAUNCH(name)                                                       \
+    do {                                                                            \
+        int _rc = ::rqhip::check_hip(hipGetLastError(), name);                      \
+        if (_rc) return _rc;                                                        \
+    } while (0)
+
+int cu_count();
+
+// torch.min(dim) update rule (ATen compare kernel): take v when !(v >= best); a NaN, once taken, stays.
+__device__ __forceinline__ bool torch_min_takes(float v, float best) { return !(v >= best); }
+
+__device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ int shfl_xor32(int v) { return __shfl_xor(v, 32, 64); }
+
+}  // namespace rqhip

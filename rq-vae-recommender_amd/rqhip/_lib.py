@@ -1,0 +1,80 @@
+"""ctypes loader of csrc/librqhip.so -- the only bridge between the Python mirror of the reference
+API and the HIP kernels.  There is NO fallback: if the library is missing (or, at call time, the
+tensors are not on a ROCm device) the call raises.
+
+Load order matters: torch bundles its own libamdhip64 with the same SONAME as /opt/rocm's, so torch is
+imported first and librqhip.so then binds to the HIP runtime already in the process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+SO_PATH = os.path.join(_CSRC, "librqhip.so")
+
+MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
+
+# every symbol include/rqhip.h declares: (restype, argtypes)
+_i64, _int, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+SIGNATURES = {
+    "rqhip_version": (_int, []),
+    "rqhip_last_error": (C.c_char_p, []),
+    "rqhip_device_cu_count": (_int, [C.POINTER(_int)]),
+    "rqhip_rq_forward_workspace_bytes": (_sz, [_int, _int]),
+    "rqhip_rq_forward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp]),
+    "rqhip_rq_backward_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "rqhip_rq_backward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _sz, _vp]),
+    "rqhip_gumbel_forward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "rqhip_gumbel_backward_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "rqhip_gumbel_backward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _sz,
+                                     _vp]),
+    "rqhip_kmeans_assign": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp]),
+    "rqhip_kmeans_update": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "rqhip_dedup_workspace_bytes": (_sz, [_i64]),
+    "rqhip_dedup_rank": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class RqHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 with the committed Makefile (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, "-j8"] + (["-B"] if force else [])
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RqHipError("building librqhip.so failed:\n" + proc.stdout[-4000:])
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RqHipError(
+                f"{SO_PATH} not found: build it with `python __graft_entry__.py` or `make -C {_CSRC}`. "
+                "The HIP extension is the product path; there is no CPU fallback.")
+        handle = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().rqhip_last_error().decode("utf-8", "replace")
+        kind = "HIP error" if rc > 0 else "argument error"
+        raise RqHipError(f"{what}: {kind} {rc}: {msg}")

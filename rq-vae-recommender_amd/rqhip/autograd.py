@@ -1,0 +1,75 @@
+"""torch.autograd bridges: forward and backward both run in HIP through the C ABI.
+
+These Functions are the seam between the reference-shaped Python modules (modules/quantize.py,
+modules/rqvae.py) and librqhip.so.  They hold no arithmetic of their own.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+def _dense(g: Optional[Tensor]) -> Optional[Tensor]:
+    """Upstream gradients may arrive as None, expanded views or non-contiguous tensors."""
+    if g is None:
+        return None
+    return g.contiguous()
+
+
+class RqStackFunction(torch.autograd.Function):
+    """L chained quantisation levels (EVAL / STE / ROTATION) as one differentiable op.
+
+    forward(res0 [B,D], codebooks [L,K,D], mode, beta, want_levels) ->
+        embs [L,B,D], residuals [L,B,D], ids [L,B], loss [B], emb_sum [B,D], embs_norm [B,L]
+    (embs / residuals are empty tensors when want_levels is False: the fused training step only consumes
+    emb_sum, loss and embs_norm, see modules/rqvae.py.)
+    """
+
+    @staticmethod
+    def forward(ctx, res0: Tensor, codebooks: Tensor, mode: int, beta: float, want_levels: bool):
+        out = ops.rq_forward(res0, codebooks, mode, beta, want_embs=want_levels, want_residuals=want_levels)
+        ctx.save_for_backward(res0, codebooks, out.ids)
+        ctx.mode, ctx.beta, ctx.want_levels = mode, beta, want_levels
+        ctx.mark_non_differentiable(out.ids, out.embs_norm)
+        empty = res0.new_empty((0,))
+        embs = out.embs if want_levels else empty
+        residuals = out.residuals if want_levels else empty
+        if not want_levels:
+            ctx.mark_non_differentiable(embs, residuals)
+        return embs, residuals, out.ids, out.loss, out.emb_sum, out.embs_norm
+
+    @staticmethod
+    def backward(ctx, g_embs, g_resid, _g_ids, g_loss, g_embsum, _g_norm):
+        res0, codebooks, ids = ctx.saved_tensors
+        need_res0, need_cb = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_res0 or need_cb):
+            return None, None, None, None, None
+        if not ctx.want_levels:
+            g_embs = g_resid = None
+        g_res0, g_cb = ops.rq_backward(res0, codebooks, ctx.mode, ctx.beta, ids, g_embs=_dense(g_embs),
+                                       g_embsum=_dense(g_embsum), g_resid=_dense(g_resid), g_loss=_dense(g_loss),
+                                       need_res0=need_res0, need_codebooks=need_cb)
+        return g_res0, g_cb, None, None, None
+
+
+class GumbelLevelFunction(torch.autograd.Function):
+    """One GUMBEL_SOFTMAX level (training): forward(x [B,D], codebook [K,D], U [B,K], T, beta) -> emb, ids, loss."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, codebook: Tensor, U: Tensor, temperature: float, beta: float):
+        ids, emb, loss = ops.gumbel_forward(x, codebook, U, temperature, beta)
+        ctx.save_for_backward(x, codebook, U)
+        ctx.temperature, ctx.beta = temperature, beta
+        ctx.mark_non_differentiable(ids)
+        return emb, ids, loss
+
+    @staticmethod
+    def backward(ctx, g_emb, _g_ids, g_loss):
+        x, codebook, U = ctx.saved_tensors
+        g_x, g_cb = ops.gumbel_backward(x, codebook, U, ctx.temperature, ctx.beta, g_emb=_dense(g_emb),
+                                        g_loss=_dense(g_loss))
+        return g_x, g_cb, None, None, None

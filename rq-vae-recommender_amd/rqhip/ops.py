@@ -1,0 +1,148 @@
+"""Tensor-level wrappers over the C ABI (include/rqhip.h).
+
+Every function takes CUDA(ROCm) fp32 tensors, allocates outputs/scratch with torch (the library never
+owns memory), enqueues on torch's current stream and returns without synchronising.  CPU tensors are
+rejected loudly: the HIP kernels are the product path, there is no host fallback.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import MODE_EVAL, MODE_GUMBEL, MODE_ROTATION, MODE_STE, RqHipError, check  # noqa: F401
+
+
+def _need_gpu(*tensors: Optional[Tensor]) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RqHipError(
+                "rqhip ops need ROCm device tensors (got a %s tensor); the HIP kernels are the only "
+                "implementation of this path -- there is no CPU fallback." % t.device.type)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RqHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _f32c(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise RqHipError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class RqForwardOut(NamedTuple):
+    ids: Tensor                  # [L,B] int64
+    embs: Optional[Tensor]       # [L,B,D]
+    residuals: Optional[Tensor]  # [L,B,D]
+    emb_sum: Optional[Tensor]    # [B,D]
+    loss: Optional[Tensor]       # [B]
+    embs_norm: Optional[Tensor]  # [B,L]
+
+
+def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_embs: bool = True,
+               want_residuals: bool = True, want_emb_sum: bool = True, want_loss: bool = True,
+               want_norm: bool = True) -> RqForwardOut:
+    """L fused quantisation levels (rqhip_rq_forward).  res0 [B,D], codebooks [L,K,D]."""
+    _need_gpu(res0, codebooks)
+    res0, codebooks = _f32c(res0, "res0"), _f32c(codebooks, "codebooks")
+    if res0.dim() != 2 or codebooks.dim() != 3 or codebooks.shape[2] != res0.shape[1]:
+        raise RqHipError(f"shape mismatch: res0 {tuple(res0.shape)}, codebooks {tuple(codebooks.shape)}")
+    B, D = res0.shape
+    L, K, _ = codebooks.shape
+    dev = res0.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        ids = torch.empty((L, B), dtype=torch.int64, device=dev)
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        embs = f(L, B, D) if want_embs else None
+        residuals = f(L, B, D) if want_residuals else None
+        emb_sum = f(B, D) if want_emb_sum else None
+        loss = f(B) if want_loss else None
+        norm = f(B, L) if want_norm else None
+        wsb = l.rqhip_rq_forward_workspace_bytes(L, K)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        rc = l.rqhip_rq_forward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(embs),
+                                _ptr(residuals), _ptr(emb_sum), _ptr(loss), _ptr(norm), _ptr(ws), wsb, _stream())
+        check(rc, "rqhip_rq_forward")
+    return RqForwardOut(ids, embs, residuals, emb_sum, loss, norm)
+
+
+def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Tensor, *,
+                g_embs: Optional[Tensor] = None, g_embsum: Optional[Tensor] = None,
+                g_resid: Optional[Tensor] = None, g_loss: Optional[Tensor] = None,
+                need_res0: bool = True, need_codebooks: bool = True):
+    """Closed-form backward of rq_forward (rqhip_rq_backward) -> (g_res0 [B,D] | None, g_codebooks [L,K,D] | None)."""
+    _need_gpu(res0, codebooks, ids, g_embs, g_embsum, g_resid, g_loss)
+    res0, codebooks = _f32c(res0, "res0"), _f32c(codebooks, "codebooks")
+    g_embs, g_embsum = _f32c(g_embs, "g_embs"), _f32c(g_embsum, "g_embsum")
+    g_resid, g_loss = _f32c(g_resid, "g_resid"), _f32c(g_loss, "g_loss")
+    if ids.dtype != torch.int64:
+        raise RqHipError("ids must be int64")
+    ids = ids.contiguous()
+    B, D = res0.shape
+    L, K, _ = codebooks.shape
+    if tuple(ids.shape) != (L, B):
+        raise RqHipError(f"ids must be [L,B]=({L},{B}), got {tuple(ids.shape)}")
+    dev = res0.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        g_res0 = torch.empty((B, D), dtype=torch.float32, device=dev) if need_res0 else None
+        g_cb = torch.empty((L, K, D), dtype=torch.float32, device=dev) if need_codebooks else None
+        wsb = l.rqhip_rq_backward_workspace_bytes(B, D, L)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        rc = l.rqhip_rq_backward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(g_embs),
+                                 _ptr(g_embsum), _ptr(g_resid), _ptr(g_loss), _ptr(g_res0), _ptr(g_cb), _ptr(ws),
+                                 wsb, _stream())
+        check(rc, "rqhip_rq_backward")
+    return g_res0, g_cb
+
+
+def kmeans_assign(x: Tensor, centroids: Tensor) -> Tensor:
+    """assign[i] = argmin_k |x_i - c_k|^2 (rqhip_kmeans_assign; reference init/kmeans.py:40-43)."""
+    _need_gpu(x, centroids)
+    x, centroids = _f32c(x, "x"), _f32c(centroids, "centroids")
+    B, D = x.shape
+    K = centroids.shape[0]
+    with torch.cuda.device(x.device):
+        assign = torch.empty((B,), dtype=torch.int64, device=x.device)
+        rc = _lib.lib().rqhip_kmeans_assign(_ptr(x), B, D, _ptr(centroids), K, _ptr(assign), _stream())
+        check(rc, "rqhip_kmeans_assign")
+    return assign
+
+
+def kmeans_update(x: Tensor, assign: Tensor, centroids: Tensor):
+    """In-place centroid update (rqhip_kmeans_update; init/kmeans.py:44-59).  `centroids` must be a contiguous
+    fp32 device tensor.  Returns (counts [K] int64, shift_sq_max [] fp32), both on the device."""
+    _need_gpu(x, assign, centroids)
+    x = _f32c(x, "x")
+    if centroids.dtype != torch.float32 or not centroids.is_contiguous():
+        raise RqHipError("centroids must be contiguous float32 (updated in place)")
+    if assign.dtype != torch.int64:
+        raise RqHipError("assign must be int64")
+    assign = assign.contiguous()
+    B, D = x.shape
+    K = centroids.shape[0]
+    with torch.cuda.device(x.device):
+        counts = torch.empty((K,), dtype=torch.int64, device=x.device)
+        shift = torch.empty((), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().rqhip_kmeans_update(_ptr(x), B, D, _ptr(assign), K, _ptr(centroids), _ptr(counts),
+                                            _ptr(shift), _stream())
+        check(rc, "rqhip_kmeans_update")
+    return counts, shift

@@ -1,0 +1,212 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for semantic ids AND for every fp32 output of the non-transcendental paths (the oracle
+fixes the reduction orders the kernels use); committed golden fixtures produced by the reference itself
+are checked too (ids exact, losses within 1e-5).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import rq_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"eval": 0, "ste": 1, "rotation": 2}
+
+
+def _gpu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _run_forward(x, cbs, mode, beta=0.25):
+    from rqhip import ops
+    out = ops.rq_forward(_gpu(x), _gpu(cbs), mode, beta)
+    torch.cuda.synchronize()
+    return {k: (None if v is None else v.cpu().numpy()) for k, v in out._asdict().items()}
+
+
+def _assert_bitexact(got, ref, what):
+    assert got.shape == ref.shape, what
+    if got.dtype.kind == "f":
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    else:
+        same = got == ref
+    assert same.all(), f"{what}: {(~same).sum()} of {same.size} elements differ; first at {np.argwhere(~same)[:3].tolist()}"
+
+
+def _check_forward(x, cbs, mode, beta=0.25):
+    ref = o.rq_forward(x, cbs, mode, beta)
+    got = _run_forward(x, cbs, mode, beta)
+    for k in ("ids", "embs", "residuals", "emb_sum", "loss", "embs_norm"):
+        _assert_bitexact(got[k], ref[k], f"{k} (mode {mode}, B={x.shape[0]}, cb={cbs.shape})")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,D,K,L", [(1, 32, 256, 3), (33, 32, 256, 3), (640, 32, 256, 3), (4099, 32, 256, 3),
+                                     (64, 64, 256, 3), (100, 16, 32, 3), (50, 8, 5, 2), (77, 24, 100, 4),
+                                     (65, 30, 70, 2), (40, 128, 64, 2), (300, 32, 1024, 4), (96, 64, 2048, 2)])
+def test_forward_bitexact_vs_oracle(mode, B, D, K, L):
+    rng = np.random.default_rng(B * 131 + D * 7 + K + L + mode)
+    x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, D)) * np.array([0.6 / (l + 1) for l in range(L)])[:, None, None]).astype(np.float32)
+    _check_forward(x, cbs, mode)
+
+
+def test_forward_ties_duplicates_nan_inf():
+    """quantize.py:128: first index on ties; NaN distance wins; Inf handled like torch.min."""
+    rng = np.random.default_rng(5)
+    B, D, K, L = 70, 32, 96, 2
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    cbs = rng.standard_normal((L, K, D)).astype(np.float32)
+    cbs[0, 40] = cbs[0, 7]          # duplicated codes -> lowest index
+    cbs[0, 90] = cbs[0, 7]
+    x[3] = cbs[0, 7]                 # exact hit on the duplicated code
+    x[10] = 0.0
+    x[11] = np.nan
+    x[12, 5] = np.inf
+    x[13, 0] = 3e19                  # |x|^2 overflows to +Inf
+    x[14] = 1e-30                    # subnormal squares
+    _check_forward(x, cbs, 0)
+    _check_forward(x, cbs, 1)
+    cbs2 = cbs.copy()
+    cbs2[0, 50, 3] = np.nan          # a NaN code: every row's level-0 id is 50
+    _check_forward(x[:40], cbs2, 0)
+    cbs3 = cbs.copy()
+    cbs3[1, 20, 1] = np.inf
+    _check_forward(x[:40], cbs3, 1)
+
+
+def test_forward_all_equal_rows_and_zero_codebook():
+    x = np.ones((130, 32), np.float32)
+    cbs = np.zeros((3, 256, 32), np.float32)
+    _check_forward(x, cbs, 1)
+    got = _run_forward(x, cbs, 0)
+    assert (got["ids"] == 0).all()
+
+
+def test_forward_empty_batch():
+    got = _run_forward(np.zeros((0, 32), np.float32), np.ones((3, 256, 32), np.float32), 1)
+    assert got["ids"].shape == (3, 0) and got["loss"].shape == (0,)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "quantize_*.npz"))))
+def test_forward_vs_reference_golden(name):
+    g = load_golden(name)
+    mode = MODES[name.split("_")[1]]
+    got = _run_forward(g["x"], g["codebook"][None], mode, float(g["beta"]))
+    assert np.array_equal(got["ids"][0], g["ids"])
+    np.testing.assert_allclose(got["loss"], g["loss"], rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(got["embs"][0], g["embeddings"], rtol=1e-5, atol=2e-6)
+
+
+def test_forward_full_size_properties():
+    """BASELINE config 2 size (100k x 32-d latents, 3 x 256): properties that do not need the oracle at
+    full size -- decode(ids) reproduces embs, residual chain closes, loss == (1+beta)*|res-emb|^2 -- plus
+    an oracle check on a random 2k-row subsample."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(1234)
+    B, D, K, L = 100_000, 32, 256, 3
+    x = torch.randn(B, D, generator=g) * 0.5
+    cbs = torch.randn(L, K, D, generator=g) * torch.tensor([0.5, 0.25, 0.12])[:, None, None]
+    out = ops.rq_forward(x.cuda(), cbs.cuda(), 0, 0.25)
+    ids = out.ids.cpu()
+    assert ids.min() >= 0 and ids.max() < K
+    dec = torch.stack([cbs[l][ids[l]] for l in range(L)])
+    assert torch.equal(dec, out.embs.cpu())
+    res = out.residuals.cpu()
+    assert torch.equal(res[0], x)
+    for l in range(L - 1):
+        assert torch.equal(res[l + 1], res[l] - dec[l])
+    sel = torch.randperm(B, generator=g)[:2000]
+    ref = o.rq_forward(x[sel].numpy(), cbs.numpy(), 0, 0.25)
+    assert np.array_equal(ref["ids"], ids[:, sel].numpy())
+    _assert_bitexact(out.loss.cpu().numpy()[sel.numpy()], ref["loss"], "loss subsample")
+
+
+# ---------------------------------------------------------------- backward ---------------------------
+
+def _run_backward(x, cbs, mode, beta, ids, **g):
+    from rqhip import ops
+    gg = {k: (None if v is None else _gpu(v)) for k, v in g.items()}
+    g_res0, g_cb = ops.rq_backward(_gpu(x), _gpu(cbs), mode, beta, _gpu(ids), **gg)
+    torch.cuda.synchronize()
+    return g_res0.cpu().numpy(), g_cb.cpu().numpy()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,D,K,L", [(1, 32, 256, 3), (333, 32, 256, 3), (64, 64, 256, 3), (100, 16, 32, 1),
+                                     (77, 24, 100, 4), (40, 128, 64, 2), (2000, 32, 1024, 4)])
+@pytest.mark.parametrize("which", ["all", "train_like"])
+def test_backward_vs_oracle(mode, B, D, K, L, which):
+    rng = np.random.default_rng(B + D + K + L + mode)
+    x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, D)) * np.array([0.6 / (l + 1) for l in range(L)])[:, None, None]).astype(np.float32)
+    ref = o.rq_forward(x, cbs, mode, 0.25)
+    if which == "all":
+        g = dict(g_embs=rng.standard_normal((L, B, D)).astype(np.float32),
+                 g_embsum=rng.standard_normal((B, D)).astype(np.float32),
+                 g_resid=rng.standard_normal((L, B, D)).astype(np.float32),
+                 g_loss=rng.random(B).astype(np.float32))
+    else:  # what RqVae.forward's loss produces: decoder gradient through emb_sum, 1/B through the loss
+        g = dict(g_embs=None, g_embsum=(rng.standard_normal((B, D)) / B).astype(np.float32), g_resid=None,
+                 g_loss=np.full((B,), 1.0 / B, np.float32))
+    r_res0, r_cb = o.rq_backward(x, cbs, mode, 0.25, ref["ids"], **g)
+    g_res0, g_cb = _run_backward(x, cbs, mode, 0.25, ref["ids"], **g)
+    _assert_bitexact(g_res0, r_res0, "g_res0")          # per-row arithmetic: exact
+    # codeword gradients are accumulated across rows with float atomics: order differs, value does not
+    scale = max(1e-6, float(np.abs(r_cb).max()))
+    np.testing.assert_allclose(g_cb, r_cb, rtol=1e-4, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "quantize_*.npz"))))
+def test_backward_vs_reference_autograd_golden(name):
+    g = load_golden(name)
+    mode = MODES[name.split("_")[1]]
+    g_x, g_cb = _run_backward(g["x"], g["codebook"][None], mode, float(g["beta"]), g["ids"][None],
+                              g_embs=g["g_emb"][None], g_loss=g["g_loss"])
+    np.testing.assert_allclose(g_x, g["grad_x"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(g_cb[0], g["grad_codebook"], rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------- k-means -----------------------------
+
+@pytest.mark.parametrize("B,D,K", [(300, 16, 8), (20000, 32, 256), (5000, 64, 256), (3000, 32, 1024), (257, 7, 5),
+                                   (64, 128, 33)])
+def test_kmeans_assign_and_update_bitexact(B, D, K):
+    from rqhip import ops
+    rng = np.random.default_rng(B + D + K)
+    centers = rng.standard_normal((K, D)).astype(np.float32) * 2
+    x = (centers[rng.integers(0, K, B)] + 0.3 * rng.standard_normal((B, D))).astype(np.float32)
+    cent = x[rng.choice(B, K, replace=False)].copy()
+    if K > 4:
+        cent[3] = cent[1]           # duplicate centroid -> index 3 can never win -> empty cluster
+    a_ref = o.kmeans_assign(x, cent)
+    a_gpu = ops.kmeans_assign(_gpu(x), _gpu(cent))
+    _assert_bitexact(a_gpu.cpu().numpy(), a_ref, "assignment")
+    c_ref = cent.copy()
+    counts_ref = o.kmeans_update(x, a_ref, c_ref)
+    c_gpu = _gpu(cent)
+    counts, shift = ops.kmeans_update(_gpu(x), a_gpu, c_gpu)
+    _assert_bitexact(counts.cpu().numpy(), counts_ref, "counts")
+    _assert_bitexact(c_gpu.cpu().numpy(), c_ref, "centroids")
+    if K > 4:
+        assert counts_ref[3] == 0
+    ref_shift = o.kmeans_shift(c_ref, cent)
+    assert np.float32(np.sqrt(np.float32(shift.item()))) == np.float32(ref_shift)
+
+
+@pytest.mark.parametrize("name", ["kmeans_a.npz", "kmeans_b.npz", "kmeans_dup.npz"])
+def test_kmeans_golden_one_iteration_matches_reference_start(name):
+    """First Lloyd iteration from the reference's own seed rows: assignments exact (init/kmeans.py:40-43)."""
+    from rqhip import ops
+    g = load_golden(name)
+    x = g["x"]
+    cent = x[g["init_idx"]].copy()
+    a_ref = o.kmeans_assign(x, cent)
+    a_gpu = ops.kmeans_assign(_gpu(x), _gpu(cent)).cpu().numpy()
+    assert np.array_equal(a_gpu, a_ref)
