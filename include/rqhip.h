@@ -141,6 +141,15 @@ int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int64_t *rank,
                      int64_t *n_distinct, void *workspace, size_t workspace_bytes,
                      rqhip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every
+ * rqhip_rq_forward call brackets its MAIN kernel (not the codebook-norm prologue) with a hipEvent pair
+ * recorded on the call's stream.  rqhip_profile_read synchronises the recorded events and returns the
+ * per-launch durations in milliseconds (at most `cap`), then clears the log.
+ */
+int rqhip_profile_enable(int max_records); /* 0 disables and frees the events */
+int rqhip_profile_read(float *ms_out, int cap, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,23 @@ int cu_count() {
     return n;
 }
 
+
+static hipEvent_t *g_ev = nullptr;   // 2 * g_cap events
+static int g_cap = 0, g_n = 0;
+static bool g_open = false;
+
+void profile_begin(hipStream_t s) {
+    g_open = false;
+    if (g_cap == 0 || g_n >= g_cap) return;
+    if (hipEventRecord(g_ev[2 * g_n], s) == hipSuccess) g_open = true;
+}
+
+void profile_end(hipStream_t s) {
+    if (!g_open) return;
+    g_open = false;
+    if (hipEventRecord(g_ev[2 * g_n + 1], s) == hipSuccess) ++g_n;
+}
+
 }  // namespace rqhip
 
 extern "C" int rqhip_version(void) { return RQHIP_VERSION; }
@@ -39,5 +56,36 @@ extern "C" int rqhip_device_cu_count(int *out) {
     RQ_RETURN_IF_HIP(hipGetDevice(&dev));
     RQ_RETURN_IF_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
     *out = n;
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_profile_enable(int max_records) {
+    using namespace rqhip;
+    for (int i = 0; i < 2 * g_cap; ++i) (void)hipEventDestroy(g_ev[i]);
+    delete[] g_ev;
+    g_ev = nullptr;
+    g_cap = g_n = 0;
+    if (max_records <= 0) return RQHIP_OK;
+    g_ev = new hipEvent_t[2 * (size_t)max_records];
+    for (int i = 0; i < 2 * max_records; ++i) RQ_RETURN_IF_HIP(hipEventCreate(&g_ev[i]));
+    g_cap = max_records;
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_profile_read(float *ms_out, int cap, int *n_out) {
+    using namespace rqhip;
+    if (!n_out || (cap > 0 && !ms_out)) {
+        set_error("rqhip_profile_read: null output pointer");
+        return RQHIP_EARG;
+    }
+    int n = 0;
+    for (int i = 0; i < g_n && n < cap; ++i) {
+        RQ_RETURN_IF_HIP(hipEventSynchronize(g_ev[2 * i + 1]));
+        float ms = 0.f;
+        RQ_RETURN_IF_HIP(hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]));
+        ms_out[n++] = ms;
+    }
+    *n_out = n;
+    g_n = 0;
     return RQHIP_OK;
 }

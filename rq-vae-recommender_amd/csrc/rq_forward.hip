@@ -351,7 +351,9 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
     auto go = [&](auto kern) -> int {
         RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        profile_begin(s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kWgThreads), lds, s, p);
+        profile_end(s);
         RQ_CHECK_LAUNCH("rq_forward_kernel");
         return 0;
     };

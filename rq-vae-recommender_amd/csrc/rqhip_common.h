@@ -41,6 +41,10 @@ inline int check_hip(hipError_t e, const char *what) {
 
 int cu_count();
 
+// bench-only kernel timing (capi.hip); no-ops unless rqhip_profile_enable(n > 0) was called
+void profile_begin(hipStream_t s);
+void profile_end(hipStream_t s);
+
 // torch.min(dim) update rule (ATen compare kernel): take v when !(v >= best); a NaN, once taken, stays.
 __device__ __forceinline__ bool torch_min_takes(float v, float best) { return !(v >= best); }
 

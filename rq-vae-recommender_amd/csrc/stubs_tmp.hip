@@ -13,9 +13,3 @@ extern "C" int rqhip_gumbel_backward(const float *, int64_t, int, const float *,
     set_error("rqhip_gumbel_backward: not implemented yet");
     return RQHIP_EUNSUPPORTED;
 }
-extern "C" size_t rqhip_dedup_workspace_bytes(int64_t) { return 16; }
-extern "C" int rqhip_dedup_rank(const int64_t *, int64_t, int, int, int64_t *, int64_t *, void *, size_t,
-                                rqhip_stream_t) {
-    set_error("rqhip_dedup_rank: not implemented yet");
-    return RQHIP_EUNSUPPORTED;
-}

@@ -1,0 +1,45 @@
+"""Loss modules with the reference's names and semantics (reference modules/loss.py:5-41).
+
+`QuantizeLoss` exists for API compatibility: inside Quantize/RqVae the same quantity is produced by the
+fused HIP kernel (csrc/rq_forward.hip) and its gradient by csrc/rq_backward.hip.  The reconstruction losses
+act on the decoder output and stay PyTorch-ROCm elementwise ops."""
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+
+class ReconstructionLoss(nn.Module):
+    """Row-wise squared error, summed over features."""
+
+    def forward(self, x_hat: Tensor, x: Tensor) -> Tensor:
+        err = x_hat - x
+        return (err * err).sum(dim=-1)
+
+
+class CategoricalReconstuctionLoss(nn.Module):  # (sic) the reference's spelling is part of its API
+    """Squared error on the dense columns + BCE-with-logits on the trailing `n_cat_feats` columns."""
+
+    def __init__(self, n_cat_feats: int) -> None:
+        super().__init__()
+        self.reconstruction_loss = ReconstructionLoss()
+        self.n_cat_feats = n_cat_feats
+
+    def forward(self, x_hat: Tensor, x: Tensor) -> Tensor:
+        n = self.n_cat_feats
+        total = self.reconstruction_loss(x_hat[:, :-n], x[:, :-n])
+        if n > 0:
+            bce = F.binary_cross_entropy_with_logits(x_hat[:, -n:], x[:, -n:], reduction="none")
+            total = total + bce.sum(dim=-1)
+        return total
+
+
+class QuantizeLoss(nn.Module):
+    """||sg(query) - value||^2 + commitment_weight * ||query - sg(value)||^2 per row."""
+
+    def __init__(self, commitment_weight: float = 1.0) -> None:
+        super().__init__()
+        self.commitment_weight = commitment_weight
+
+    def forward(self, query: Tensor, value: Tensor) -> Tensor:
+        codebook_term = (query.detach() - value).pow(2).sum(dim=-1)
+        commit_term = (query - value.detach()).pow(2).sum(dim=-1)
+        return codebook_term + self.commitment_weight * commit_term

@@ -1,0 +1,182 @@
+"""RQ-VAE on the MI355X behind the reference's `RqVae` API (reference modules/rqvae.py).
+
+Same constructor, attributes, state_dict keys (`layers.{l}.embedding.weight`, `encoder.mlp.*`,
+`decoder.mlp.*`), `get_semantic_ids` / `forward` signatures and return types.  What differs is where the
+arithmetic runs: the whole residual-quantisation stack -- every level's distance, argmin, codeword gather,
+STE / rotation-trick output, quantize loss and residual update, plus the emb-sum / emb-norm the loss
+consumes -- is ONE fused HIP kernel (csrc/rq_forward.hip) with a closed-form HIP backward
+(csrc/rq_backward.hip); the O(B^2) duplicate statistic of rqvae.py:159-167 is a hash pass (csrc/ids.hip).
+Encoder/decoder GEMMs and the reconstruction loss stay PyTorch-ROCm.
+
+Differences a caller can observe, all deliberate:
+  * no `@torch.compile(mode="reduce-overhead")` on forward (rqvae.py:141): the hot path is already a
+    handful of launches and a ctypes call cannot be traced by dynamo;
+  * tensors must be on a ROCm device; a CPU call raises (no fallback path exists).
+"""
+from functools import cached_property
+from typing import List, NamedTuple
+
+import torch
+from huggingface_hub import PyTorchModelHubMixin
+from torch import Tensor, nn
+
+from data.schemas import SeqBatch
+from modules.encoder import MLP
+from modules.loss import CategoricalReconstuctionLoss, ReconstructionLoss
+from modules.normalize import l2norm
+from modules.quantize import Quantize, QuantizeForwardMode
+from rqhip import ops
+from rqhip.autograd import RqStackFunction
+
+torch.set_float32_matmul_precision("high")  # as the reference does at import (rqvae.py:19)
+
+
+class RqVaeOutput(NamedTuple):
+    embeddings: Tensor     # [B, D, L]
+    residuals: Tensor      # [B, D, L]
+    sem_ids: Tensor        # [B, L] int64
+    quantize_loss: Tensor  # [B]
+
+
+class RqVaeComputedLosses(NamedTuple):
+    loss: Tensor
+    reconstruction_loss: Tensor
+    rqvae_loss: Tensor
+    embs_norm: Tensor      # [B, L]
+    p_unique_ids: Tensor
+
+
+class _StackResult(NamedTuple):
+    embs: Tensor       # [L,B,D] (empty when levels were not requested)
+    residuals: Tensor  # [L,B,D] (")
+    ids: Tensor        # [L,B]
+    loss: Tensor       # [B]
+    emb_sum: Tensor    # [B,D]
+    embs_norm: Tensor  # [B,L]
+
+
+class RqVae(nn.Module, PyTorchModelHubMixin):
+    def __init__(
+        self,
+        input_dim: int,
+        embed_dim: int,
+        hidden_dims: List[int],
+        codebook_size: int,
+        codebook_kmeans_init: bool = True,
+        codebook_normalize: bool = False,
+        codebook_sim_vq: bool = False,
+        codebook_mode: QuantizeForwardMode = QuantizeForwardMode.GUMBEL_SOFTMAX,
+        n_layers: int = 3,
+        commitment_weight: float = 0.25,
+        n_cat_features: int = 18,
+    ) -> None:
+        self._config = locals()
+        super().__init__()
+        self.input_dim = input_dim
+        self.embed_dim = embed_dim
+        self.hidden_dims = hidden_dims
+        self.n_layers = n_layers
+        self.codebook_size = codebook_size
+        self.commitment_weight = commitment_weight
+        self.n_cat_feats = n_cat_features
+
+        # construction order (levels, encoder, decoder) == the reference's, so a seeded init matches it
+        self.layers = nn.ModuleList(
+            Quantize(embed_dim=embed_dim, n_embed=codebook_size, forward_mode=codebook_mode,
+                     do_kmeans_init=codebook_kmeans_init, codebook_normalize=(level == 0 and codebook_normalize),
+                     sim_vq=codebook_sim_vq, commitment_weight=commitment_weight)
+            for level in range(n_layers))
+        self.encoder = MLP(input_dim=input_dim, hidden_dims=hidden_dims, out_dim=embed_dim,
+                           normalize=codebook_normalize)
+        self.decoder = MLP(input_dim=embed_dim, hidden_dims=hidden_dims[::-1], out_dim=input_dim, normalize=False)
+        self.reconstruction_loss = (CategoricalReconstuctionLoss(n_cat_features) if n_cat_features != 0
+                                    else ReconstructionLoss())
+
+    @cached_property
+    def config(self) -> dict:
+        return self._config
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.encoder.parameters()).device
+
+    def load_pretrained(self, path: str) -> None:
+        state = torch.load(path, map_location=self.device, weights_only=False)
+        self.load_state_dict(state["model"])
+        print(f"---Loaded RQVAE Iter {state['iter']}---")
+
+    def encode(self, x: Tensor) -> Tensor:
+        return self.encoder(x)
+
+    def decode(self, x: Tensor) -> Tensor:
+        return self.decoder(x)
+
+    # ---- the hot path --------------------------------------------------------------------------------
+    def _can_fuse(self) -> bool:
+        """All levels in one launch: needs every level past its lazy k-means init and a mode the stack
+        kernel implements (eval, STE, rotation trick)."""
+        for layer in self.layers:
+            if layer.do_kmeans_init and not layer.kmeans_initted:
+                return False
+            if layer.training and layer.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
+                return False
+            if layer.training != self.layers[0].training or layer.forward_mode != self.layers[0].forward_mode:
+                return False
+        return True
+
+    def _quantize_stack(self, res: Tensor, gumbel_t: float, want_levels: bool) -> _StackResult:
+        if self._can_fuse():
+            codebooks = torch.stack([layer.codebook() for layer in self.layers])  # [L,K,D], autograd splits it back
+            out = RqStackFunction.apply(res, codebooks, self.layers[0].hip_mode(), float(self.commitment_weight),
+                                        want_levels)
+            return _StackResult(*out)
+        # level-by-level (first call with lazy k-means init, or Gumbel-softmax training): the reference's loop
+        # (rqvae.py:125-132), each level being one L=1 launch of the same kernels
+        embs, residuals, ids = [], [], []
+        loss = 0
+        for layer in self.layers:
+            residuals.append(res)
+            q = layer(res, temperature=gumbel_t)
+            loss = loss + q.loss
+            res = res - q.embeddings
+            ids.append(q.ids)
+            embs.append(q.embeddings)
+        embs_t = torch.stack(embs)
+        emb_sum = embs[0]
+        for e in embs[1:]:
+            emb_sum = emb_sum + e
+        norms = torch.linalg.vector_norm(embs_t.detach(), dim=2).t()
+        return _StackResult(embs_t, torch.stack(residuals), torch.stack(ids), loss, emb_sum, norms)
+
+    def get_semantic_ids(self, x: Tensor, gumbel_t: float = 0.001) -> RqVaeOutput:
+        x = x.to(next(self.encoder.parameters()).dtype)
+        res = self.encode(x)
+        st = self._quantize_stack(res, gumbel_t, want_levels=True)
+        return RqVaeOutput(
+            embeddings=st.embs.permute(1, 2, 0),     # [B,D,L], same strides as the reference's rearrange
+            residuals=st.residuals.permute(1, 2, 0),
+            sem_ids=st.ids.t(),                      # [B,L] view of [L,B] (strides (1,B) like the reference)
+            quantize_loss=st.loss,
+        )
+
+    def forward(self, batch: SeqBatch, gumbel_t: float) -> RqVaeComputedLosses:
+        x = batch.x
+        xin = x.to(next(self.encoder.parameters()).dtype)
+        st = self._quantize_stack(self.encode(xin), gumbel_t, want_levels=False)
+        x_hat = self.decode(st.emb_sum)                                   # embs.sum(axis=-1), rqvae.py:146
+        n = self.n_cat_feats
+        # rqvae.py:147-150: with n == 0 the `[..., :-0]` slice is EMPTY, so nothing is normalised
+        x_hat = torch.cat([l2norm(x_hat[..., :-n]), x_hat[..., -n:]], dim=-1) if n != 0 else x_hat
+        reconstruction = self.reconstruction_loss(x_hat, x)
+        rqvae_loss = st.loss
+        loss = (reconstruction + rqvae_loss).mean()
+        with torch.no_grad():
+            _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
+            p_unique_ids = n_distinct / st.ids.shape[1]                   # rqvae.py:159-167
+        return RqVaeComputedLosses(
+            loss=loss,
+            reconstruction_loss=reconstruction.mean(),
+            rqvae_loss=rqvae_loss.mean(),
+            embs_norm=st.embs_norm,
+            p_unique_ids=p_unique_ids,
+        )

@@ -1,0 +1,128 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL/xGMI ("nccl" backend on ROCm).
+
+The path shards by rows (items are independent through encoder, every RQ level, decoder and losses,
+SURVEY.md section 8e).  The only data-path exchange of a training step is the gradient reduction that HF
+accelerate's DDP wrap performs implicitly in the reference (train_rqvae.py:153,195).  Here it is explicit
+and MI355X-shaped: every parameter's .grad is a view into ONE flat fp32 buffer (4.6 MB for the Amazon
+config), so a step issues exactly one in-place all-reduce -- the payload is far below the xGMI
+bandwidth regime, what matters is one collective instead of a bucket per layer -- followed by a 1/W scale
+(DDP's mean).  k-means init runs on the first <= 20 000 rows, which every rank holds: rank 0 computes it and
+broadcasts the parameters (this also removes the reference's latent per-rank-divergent init).
+
+On CPU (tests) the same code runs over the gloo backend.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+
+def env_world() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_from_env(device_type: str = "cuda") -> tuple[int, int, int]:
+    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, local, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def barrier() -> None:
+    if world_size() > 1:
+        dist.barrier()
+
+
+def shard_bounds(n_rows: int, rank: Optional[int] = None, world: Optional[int] = None) -> tuple[int, int]:
+    """Contiguous row shard [lo, hi) of rank r: sizes differ by at most one row."""
+    rank = get_rank() if rank is None else rank
+    world = world_size() if world is None else world
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+@torch.no_grad()
+def broadcast_module(module: nn.Module, src: int = 0) -> None:
+    """Make every rank's parameters and buffers identical to rank `src`'s (after k-means init / at start)."""
+    if world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+class FlatGradReducer:
+    """Gradients of `params` live in one flat buffer; `allreduce_mean()` is a single collective."""
+
+    def __init__(self, params: Iterable[nn.Parameter]) -> None:
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dtype = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=dtype)
+        offset = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[offset:offset + n].view_as(p)
+            offset += n
+
+    def zero_(self) -> None:
+        """Use instead of optimizer.zero_grad(): keeps the .grad views attached to the flat buffer."""
+        self.flat.zero_()
+
+    def check_attached(self) -> None:
+        for p in self.params:
+            if p.grad is None or p.grad.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
+                raise RuntimeError("a parameter's .grad was detached from the flat buffer "
+                                   "(call reducer.zero_() instead of optimizer.zero_grad(set_to_none=True))")
+
+    @torch.no_grad()
+    def allreduce_mean(self) -> Tensor:
+        w = world_size()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / w)
+        return self.flat
+
+
+@torch.no_grad()
+def allgather_rows(local: Tensor) -> Tensor:
+    """Concatenate per-rank row blocks (possibly of unequal length) along dim 0 -- used to assemble the
+    corpus-wide semantic-id table from row shards."""
+    w = world_size()
+    if w == 1:
+        return local
+    n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s) for s in sizes]
+    m = max(sizes)
+    pad = local.new_zeros((m,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)

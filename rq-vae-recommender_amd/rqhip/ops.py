@@ -146,3 +146,78 @@ def kmeans_update(x: Tensor, assign: Tensor, centroids: Tensor):
                                             _ptr(shift), _stream())
         check(rc, "rqhip_kmeans_update")
     return counts, shift
+
+
+def dedup_rank(ids: Tensor, codebook_size: int = 0, *, want_rank: bool = True):
+    """Duplicate statistics of semantic-id tuples (rqhip_dedup_rank).  ids [L,B] int64 ->
+    (rank [B] int64 | None, n_distinct [] int64): rank[i] = number of earlier rows with row i's tuple
+    (reference modules/tokenizer/semids.py:92-108); n_distinct / B = p_unique_ids (modules/rqvae.py:159-167)."""
+    _need_gpu(ids)
+    if ids.dtype != torch.int64 or ids.dim() != 2:
+        raise RqHipError("ids must be an int64 [L,B] tensor")
+    ids = ids.contiguous()
+    L, B = ids.shape
+    dev = ids.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        rank = torch.empty((B,), dtype=torch.int64, device=dev) if want_rank else None
+        n = torch.empty((), dtype=torch.int64, device=dev)
+        wsb = l.rqhip_dedup_workspace_bytes(B)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        rc = l.rqhip_dedup_rank(_ptr(ids), B, L, int(codebook_size), _ptr(rank), _ptr(n), _ptr(ws), wsb, _stream())
+        check(rc, "rqhip_dedup_rank")
+    return rank, n
+
+
+def gumbel_forward(x: Tensor, codebook: Tensor, U: Tensor, temperature: float, beta: float):
+    """One GUMBEL_SOFTMAX level, training (rqhip_gumbel_forward) -> (ids [B], emb [B,D], loss [B])."""
+    _need_gpu(x, codebook, U)
+    x, codebook, U = _f32c(x, "x"), _f32c(codebook, "codebook"), _f32c(U, "U")
+    B, D = x.shape
+    K = codebook.shape[0]
+    if tuple(U.shape) != (B, K):
+        raise RqHipError(f"U must be [B,K]=({B},{K}), got {tuple(U.shape)}")
+    dev = x.device
+    with torch.cuda.device(dev):
+        ids = torch.empty((B,), dtype=torch.int64, device=dev)
+        emb = torch.empty((B, D), dtype=torch.float32, device=dev)
+        loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        rc = _lib.lib().rqhip_gumbel_forward(_ptr(x), B, D, _ptr(codebook), K, _ptr(U), temperature, beta, _ptr(ids),
+                                             _ptr(emb), _ptr(loss), _stream())
+        check(rc, "rqhip_gumbel_forward")
+    return ids, emb, loss
+
+
+def gumbel_backward(x: Tensor, codebook: Tensor, U: Tensor, temperature: float, beta: float, *,
+                    g_emb: Optional[Tensor] = None, g_loss: Optional[Tensor] = None):
+    """Backward of gumbel_forward (rqhip_gumbel_backward) -> (g_x [B,D], g_codebook [K,D])."""
+    _need_gpu(x, codebook, U, g_emb, g_loss)
+    x, codebook, U = _f32c(x, "x"), _f32c(codebook, "codebook"), _f32c(U, "U")
+    g_emb, g_loss = _f32c(g_emb, "g_emb"), _f32c(g_loss, "g_loss")
+    B, D = x.shape
+    K = codebook.shape[0]
+    dev = x.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        g_x = torch.empty((B, D), dtype=torch.float32, device=dev)
+        g_cb = torch.empty((K, D), dtype=torch.float32, device=dev)
+        wsb = l.rqhip_gumbel_backward_workspace_bytes(B, D, K)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        rc = l.rqhip_gumbel_backward(_ptr(x), B, D, _ptr(codebook), K, _ptr(U), temperature, beta, _ptr(g_emb),
+                                     _ptr(g_loss), _ptr(g_x), _ptr(g_cb), _ptr(ws), wsb, _stream())
+        check(rc, "rqhip_gumbel_backward")
+    return g_x, g_cb
+
+
+def profile_enable(max_records: int) -> None:
+    """Bench-only: time the main rq_forward kernel of every following call with HIP events on its stream."""
+    check(_lib.lib().rqhip_profile_enable(int(max_records)), "rqhip_profile_enable")
+
+
+def profile_read(cap: int = 4096):
+    """Durations (ms) of the rq_forward kernels recorded since the last read (synchronises them)."""
+    import ctypes as C
+    buf = (C.c_float * cap)()
+    n = C.c_int(0)
+    check(_lib.lib().rqhip_profile_read(buf, cap, C.byref(n)), "rqhip_profile_read")
+    return [buf[i] for i in range(n.value)]

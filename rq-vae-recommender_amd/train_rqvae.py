@@ -1,0 +1,260 @@
+"""`python train_rqvae.py <config.gin>` -- RQ-VAE tokenizer training on MI355X.
+
+Drop-in for the reference's entry point (train_rqvae.py:24-305): the same gin-configurable `train(...)` with
+the same 29 keyword arguments and defaults, the same schedule (k-means warm-up forward at iteration 0,
+`iterations + 1` optimiser steps, gradient accumulation, eval / checkpoint / id-diversity cadence) and the
+same checkpoint dictionary (`iter`, `model`, `model_config`, `optimizer`; state_dict keys unchanged).
+
+What is MI355X-native about it:
+  * the model's quantisation stack, k-means init and id statistics are HIP kernels (modules/, init/);
+  * one process per GPU (`torchrun --nproc-per-node N train_rqvae.py cfg.gin`): no accelerate/DDP wrapper --
+    gradients live in one flat buffer and a step issues exactly one RCCL all-reduce (rqhip/dist.py); every
+    rank draws its own batches from the full dataset, as the un-`prepare`d dataloader of the reference does
+    (train_rqvae.py:119-120); rank 0 alone runs the k-means warm-up and broadcasts the result;
+  * the item-feature matrix is resident in HBM and batches are gathered on the device (data/processed.py),
+    there is no host->device copy in the loop;
+  * the progress-bar losses are read back every `log_every` steps instead of three `.cpu().item()` syncs
+    per step (train_rqvae.py:197-199).
+wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
+"""
+import os
+import time
+from typing import List
+
+import numpy as np
+import torch
+from torch.optim import AdamW
+
+from data.processed import ItemData, RecDataset
+from modules.quantize import QuantizeForwardMode
+from modules.rqvae import RqVae
+from modules.tokenizer.semids import SemanticIdTokenizer
+from modules.utils import parse_config
+from rqhip import dist as rqdist
+
+try:
+    import gin
+except ImportError:  # pragma: no cover
+    from rqhip import ginlite as gin
+
+try:
+    import wandb  # noqa: F401
+    _HAVE_WANDB = True
+except ImportError:  # pragma: no cover
+    wandb = None
+    _HAVE_WANDB = False
+
+
+class _DeviceBatcher:
+    """Endless stream of random batches gathered on the device: a shuffled epoch at a time, without
+    replacement, short final batch kept (what BatchSampler(RandomSampler(ds), bs, drop_last=False) wrapped in
+    `cycle` yields in the reference, train_rqvae.py:82-89)."""
+
+    def __init__(self, dataset: ItemData, batch_size: int, generator: torch.Generator | None = None) -> None:
+        self.dataset, self.batch_size, self.generator = dataset, batch_size, generator
+        self._perm, self._pos = None, 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        n = len(self.dataset)
+        if self._perm is None or self._pos >= n:
+            self._perm = torch.randperm(n, generator=self.generator)
+            self._pos = 0
+        idx = self._perm[self._pos:self._pos + self.batch_size]
+        self._pos += self.batch_size
+        return self.dataset[idx]
+
+    def epoch(self):
+        """One pass in random order (the eval loop of train_rqvae.py:236-256)."""
+        perm = torch.randperm(len(self.dataset), generator=self.generator)
+        for start in range(0, len(perm), self.batch_size):
+            yield self.dataset[perm[start:start + self.batch_size]]
+
+
+def _id_diversity(tokenizer: SemanticIdTokenizer, index_dataset: ItemData, n_layers: int, codebook_size: int) -> dict:
+    """Entropy / codebook usage / duplicate statistics of train_rqvae.py:272-292."""
+    tokenizer.reset()
+    corpus_ids = tokenizer.precompute_corpus_ids(index_dataset)
+    n = corpus_ids.shape[0]
+    log = {"max_id_duplicates": (corpus_ids[:, -1].max() / n).item()}
+    _, counts = torch.unique(corpus_ids[:, :-1], dim=0, return_counts=True)
+    p = counts / n
+    log["rqvae_entropy"] = (-(p * torch.log(p)).sum()).item()
+    for cid in range(n_layers):
+        _, counts = torch.unique(corpus_ids[:, cid], return_counts=True)
+        log[f"codebook_usage_{cid}"] = len(counts) / codebook_size
+    return log
+
+
+@gin.configurable
+def train(
+    iterations=50000,
+    batch_size=64,
+    learning_rate=0.0001,
+    weight_decay=0.01,
+    dataset_folder="dataset/ml-1m",
+    dataset=RecDataset.ML_1M,
+    pretrained_rqvae_path=None,
+    save_dir_root="out/",
+    use_kmeans_init=True,
+    split_batches=True,
+    amp=False,
+    wandb_logging=False,
+    do_eval=True,
+    force_dataset_process=False,
+    mixed_precision_type="fp16",
+    gradient_accumulate_every=1,
+    save_model_every=1000000,
+    eval_every=50000,
+    commitment_weight=0.25,
+    vae_n_cat_feats=18,
+    vae_input_dim=18,
+    vae_embed_dim=16,
+    vae_hidden_dims=[18, 18],
+    vae_codebook_size=32,
+    vae_codebook_normalize=False,
+    vae_codebook_mode=QuantizeForwardMode.GUMBEL_SOFTMAX,
+    vae_sim_vq=False,
+    vae_n_layers=3,
+    dataset_split="beauty",
+    log_every=100,
+):
+    params = dict(locals())
+    del split_batches  # every rank always draws its own full batch (reference behaviour with a bare dataloader)
+    if amp:
+        raise NotImplementedError(
+            f"amp=True ({mixed_precision_type}): the HIP quantisation kernels are fp32 only, as the parity "
+            "contract (bit-exact ids vs the fp32 reference) requires")
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_rqvae needs a ROCm GPU: the quantisation path has no CPU implementation")
+
+    rank, local_rank, world = rqdist.init_from_env("cuda")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    is_main = rank == 0
+    print(f"Device: {device} (rank {rank}/{world})")
+
+    def make(split):
+        return ItemData(root=dataset_folder, dataset=dataset, force_process=force_dataset_process and split != "eval",
+                        train_test_split=split, split=dataset_split).to_device(device)
+
+    train_dataset = make("train" if do_eval else "all")
+    train_batches = _DeviceBatcher(train_dataset, batch_size)
+    eval_batches = _DeviceBatcher(make("eval"), batch_size) if do_eval else None
+    index_dataset = make("all") if do_eval else train_dataset
+
+    model = RqVae(
+        input_dim=vae_input_dim, embed_dim=vae_embed_dim, hidden_dims=vae_hidden_dims,
+        codebook_size=vae_codebook_size, codebook_kmeans_init=use_kmeans_init and pretrained_rqvae_path is None,
+        codebook_normalize=vae_codebook_normalize, codebook_sim_vq=vae_sim_vq, codebook_mode=vae_codebook_mode,
+        n_layers=vae_n_layers, n_cat_features=vae_n_cat_feats, commitment_weight=commitment_weight,
+    ).to(device)
+    optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay)
+
+    use_wandb = wandb_logging and is_main and _HAVE_WANDB
+    if wandb_logging and is_main and not _HAVE_WANDB:
+        print("wandb is not installed: metrics go to stdout")
+    if use_wandb:
+        wandb.login()
+        wandb.init(project="rq-vae-training", config=params)
+
+    start_iter = 0
+    if pretrained_rqvae_path is not None:
+        model.load_pretrained(pretrained_rqvae_path)
+        state = torch.load(pretrained_rqvae_path, map_location=device, weights_only=False)
+        optimizer.load_state_dict(state["optimizer"])
+        start_iter = state["iter"] + 1
+
+    rqdist.broadcast_module(model)
+    reducer = rqdist.FlatGradReducer(model.parameters())
+
+    tokenizer = SemanticIdTokenizer(
+        input_dim=vae_input_dim, hidden_dims=vae_hidden_dims, output_dim=vae_embed_dim,
+        codebook_size=vae_codebook_size, n_layers=vae_n_layers, n_cat_feats=vae_n_cat_feats,
+        rqvae_weights_path=pretrained_rqvae_path, rqvae_codebook_normalize=vae_codebook_normalize,
+        rqvae_sim_vq=vae_sim_vq)
+    tokenizer.rq_vae = model
+
+    t = 0.2  # the reference's constant gumbel temperature (train_rqvae.py:177)
+    window: List[torch.Tensor] = []
+    shown = (float("nan"),) * 3
+    t0 = time.time()
+    for it in range(start_iter, start_iter + 1 + iterations):
+        model.train()
+        if it == 0 and use_kmeans_init:
+            # lazy k-means init of every level on its own residuals of the first <= 20 000 items
+            # (train_rqvae.py:178-183); rank 0 computes, everyone receives
+            if is_main:
+                warm = train_dataset[torch.arange(min(20000, len(train_dataset)))]
+                model(warm, t)
+            for layer in model.layers:
+                layer.kmeans_initted = True
+            rqdist.broadcast_module(model)
+
+        reducer.zero_()
+        total_loss = 0
+        for _ in range(gradient_accumulate_every):
+            data = next(train_batches)
+            model_output = model(data, gumbel_t=t)
+            loss = model_output.loss / gradient_accumulate_every
+            loss.backward()
+            total_loss = total_loss + loss.detach()
+        reducer.allreduce_mean()
+        optimizer.step()
+
+        window.append(torch.stack([total_loss, model_output.reconstruction_loss.detach(),
+                                   model_output.rqvae_loss.detach()]))
+        window = window[-1000:]
+        if it % log_every == 0:
+            shown = tuple(torch.stack(window).mean(dim=0).tolist())  # the only host sync of a normal step
+            if is_main:
+                rate = (it - start_iter + 1) / max(time.time() - t0, 1e-9)
+                print(f"iter {it}: loss: {shown[0]:.4f}, rl: {shown[1]:.4f}, vl: {shown[2]:.4f} ({rate:.1f} it/s)")
+
+        log = {}
+        last = it + 1 == iterations
+        if use_wandb or (wandb_logging and is_main and it % log_every == 0):
+            norms = model_output.embs_norm.mean(dim=0)
+            log.update({f"emb_avg_norm_{i}": norms[i].item() for i in range(vae_n_layers)})
+            log.update({"learning_rate": optimizer.param_groups[0]["lr"], "total_loss": float(total_loss),
+                        "reconstruction_loss": model_output.reconstruction_loss.item(),
+                        "rqvae_loss": model_output.rqvae_loss.item(), "temperature": t,
+                        "p_unique_ids": model_output.p_unique_ids.item()})
+
+        if do_eval and ((it + 1) % eval_every == 0 or last):
+            model.eval()
+            rows = []
+            with torch.no_grad():
+                for batch in eval_batches.epoch():
+                    out = model(batch, gumbel_t=t)
+                    rows.append(torch.stack([out.loss, out.reconstruction_loss, out.rqvae_loss]))
+            if rows:
+                ev = torch.stack(rows).mean(dim=0).tolist()
+                log.update({"eval_total_loss": ev[0], "eval_reconstruction_loss": ev[1], "eval_rqvae_loss": ev[2]})
+
+        if (it + 1) % eval_every == 0 or last:
+            model.eval()
+            log.update(_id_diversity(tokenizer, index_dataset, vae_n_layers, vae_codebook_size))  # collective
+
+        if is_main and ((it + 1) % save_model_every == 0 or last):
+            os.makedirs(save_dir_root, exist_ok=True)
+            torch.save({"iter": it, "model": model.state_dict(), "model_config": model.config,
+                        "optimizer": optimizer.state_dict()}, save_dir_root + f"checkpoint_{it}.pt")
+
+        if is_main and log:
+            if use_wandb:
+                wandb.log(log)
+            elif wandb_logging:
+                print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in log.items()})
+
+    if use_wandb:
+        wandb.finish()
+    rqdist.barrier()
+    return {"loss": shown[0], "reconstruction_loss": shown[1], "rqvae_loss": shown[2]}
+
+
+if __name__ == "__main__":
+    parse_config()
+    train()

@@ -1,0 +1,170 @@
+"""GPU tests of the reference-shaped Python API (modules.quantize / modules.rqvae / init.kmeans /
+tokenizer) against golden outputs of the reference itself (tests/golden, see oracle/gen_golden.py):
+semantic ids exact, losses within 1e-5, gradients of every parameter within fp32 tolerance."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RQVAE_CFG = {
+    "small_ste": dict(input_dim=48, embed_dim=16, hidden_dims=[32, 24], codebook_size=32, n_layers=3, n_cat_features=0),
+    "small_rot": dict(input_dim=48, embed_dim=16, hidden_dims=[32, 24], codebook_size=32, n_layers=3, n_cat_features=0),
+    "wide_ste": dict(input_dim=64, embed_dim=32, hidden_dims=[48], codebook_size=256, n_layers=4, n_cat_features=0),
+    "cat_ste": dict(input_dim=40, embed_dim=8, hidden_dims=[24], codebook_size=16, n_layers=2, n_cat_features=6),
+}
+
+
+def _build(tag, g):
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    mode = QuantizeForwardMode.ROTATION_TRICK if "rot" in tag else QuantizeForwardMode.STE
+    m = RqVae(codebook_kmeans_init=False, codebook_mode=mode, commitment_weight=0.25, **RQVAE_CFG[tag])
+    m.load_state_dict({k[len("param::"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param::")})
+    return m.cuda()
+
+
+@pytest.mark.parametrize("tag", sorted(RQVAE_CFG))
+@pytest.mark.parametrize("phase", ["train", "eval"])
+def test_rqvae_matches_reference(tag, phase):
+    from data.schemas import SeqBatch
+    g = load_golden(f"rqvae_{tag}.npz")
+    m = _build(tag, g)
+    m.train(phase == "train")
+    x = torch.from_numpy(g["x"]).cuda()
+    p = phase + "_"
+    sem = m.get_semantic_ids(x, 0.2)
+    assert sem.sem_ids.shape == g[p + "sem_ids"].shape and sem.sem_ids.dtype == torch.int64
+    assert sem.sem_ids.stride() == (1, x.shape[0])                       # the reference's [B,L] view layout
+    assert np.array_equal(sem.sem_ids.cpu().numpy(), g[p + "sem_ids"]), "semantic ids must be bit-exact"
+    np.testing.assert_allclose(sem.quantize_loss.detach().cpu().numpy(), g[p + "quantize_loss"], rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(sem.embeddings.detach().cpu().numpy(), g[p + "embeddings"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sem.residuals.detach().cpu().numpy(), g[p + "residuals"], rtol=1e-5, atol=1e-6)
+
+    batch = SeqBatch(user_ids=None, ids=None, ids_fut=None, x=x, x_fut=None, seq_mask=None)
+    out = m(batch, 0.2)
+    for k in ("loss", "reconstruction_loss", "rqvae_loss", "p_unique_ids"):
+        np.testing.assert_allclose(getattr(out, k).detach().cpu().numpy(), g[p + k], rtol=2e-6, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(out.embs_norm.cpu().numpy(), g[p + "embs_norm"], rtol=1e-5, atol=1e-6)
+    out.loss.backward()
+    for name, prm in m.named_parameters():
+        ref = g[p + "grad::" + name]
+        got = prm.grad.cpu().numpy()
+        scale = max(1e-6, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * scale, err_msg=f"{phase} grad {name}")
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "quantize_*.npz"))))
+def test_quantize_module_matches_reference(name):
+    from modules.quantize import Quantize, QuantizeForwardMode
+    g = load_golden(name)
+    kind = name.split("_")[1]
+    fm = QuantizeForwardMode.ROTATION_TRICK if kind == "rotation" else QuantizeForwardMode.STE
+    K, D = g["codebook"].shape
+    q = Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=fm, commitment_weight=0.25).cuda()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(g["codebook"]))
+    q.train(kind != "eval")
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    out = q(x, temperature=0.2)
+    assert np.array_equal(out.ids.cpu().numpy(), g["ids"])
+    np.testing.assert_allclose(out.loss.detach().cpu().numpy(), g["loss"], rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(out.embeddings.detach().cpu().numpy(), g["embeddings"], rtol=1e-5, atol=2e-6)
+    ge, gl = torch.from_numpy(g["g_emb"]).cuda(), torch.from_numpy(g["g_loss"]).cuda()
+    ((out.embeddings * ge).sum() + (out.loss * gl).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(q.embedding.weight.grad.cpu().numpy(), g["grad_codebook"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["kmeans_a.npz", "kmeans_b.npz", "kmeans_dup.npz"])
+def test_kmeans_run_matches_reference(name):
+    """Same numpy / torch seeds as the reference run -> same seed rows, same reseed draws, same result."""
+    from init.kmeans import Kmeans, kmeans_init_
+    g = load_golden(name)
+    seed = int(g["seed"])
+    max_iters = None if int(g["max_iters"]) < 0 else int(g["max_iters"])
+    x = torch.from_numpy(g["x"]).cuda()
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    out = Kmeans(k=int(g["k"]), max_iters=max_iters).run(x)
+    assert np.array_equal(out.assignment.cpu().numpy(), g["assignment"])
+    np.testing.assert_allclose(out.centroids.cpu().numpy(), g["centroids"], rtol=1e-5, atol=1e-6)
+    w = torch.zeros(int(g["k"]), x.shape[1], device="cuda")
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if max_iters is None:
+        kmeans_init_(w, x)
+        np.testing.assert_allclose(w.cpu().numpy(), g["centroids"], rtol=1e-5, atol=1e-6)
+
+
+def test_lazy_kmeans_init_inside_rqvae_forward():
+    """quantize.py:107-108 via train_rqvae.py:178-183: the first training forward k-means-initialises every
+    level on its own residuals; afterwards the fused path takes over and agrees with the level-by-level one."""
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = RqVae(input_dim=64, embed_dim=16, hidden_dims=[32], codebook_size=16, n_layers=3, n_cat_features=0,
+              codebook_kmeans_init=True, codebook_mode=QuantizeForwardMode.STE).cuda()
+    before = [l.weight.detach().clone() for l in m.layers]
+    x = torch.nn.functional.normalize(torch.randn(500, 64), dim=-1).cuda()
+    batch = SeqBatch(None, None, None, x, None, None)
+    assert not m._can_fuse()
+    out1 = m(batch, 0.2)
+    assert all(l.kmeans_initted for l in m.layers) and m._can_fuse()
+    assert all(not torch.equal(b, l.weight) for b, l in zip(before, m.layers))
+    out2 = m(batch, 0.2)       # fused kernel, same weights
+    assert torch.allclose(out1.loss, out2.loss, rtol=1e-6, atol=1e-6)
+    assert torch.equal(out1.p_unique_ids, out2.p_unique_ids)
+
+
+def test_tokenizer_dedup_column_matches_reference():
+    from data.processed import ItemData
+    from modules.tokenizer.semids import SemanticIdTokenizer
+    g = load_golden("dedup_a.npz")
+    tok = SemanticIdTokenizer(input_dim=24, output_dim=8, hidden_dims=[16], codebook_size=4, n_layers=3, n_cat_feats=0)
+    tok.rq_vae.load_state_dict({k[len("param::"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param::")})
+    tok = tok.cuda()
+    X = torch.from_numpy(g["x"])
+    ds = ItemData(root="/nonexistent", item_matrix=torch.cat([X, torch.zeros(X.shape[0], 768 - 24)], dim=1),
+                  train_test_split="all")
+    ds.item_data = ds.item_data[:, :24].contiguous()   # ItemData slices [:768]; the fixture model is 24-d
+    ids = tok.precompute_corpus_ids(ds.to_device("cuda"))
+    assert ids.shape == g["corpus_ids"].shape
+    assert np.array_equal(ids.cpu().numpy(), g["corpus_ids"])
+    assert tok.cached_ids is ids
+
+
+@pytest.mark.parametrize("B,L,K", [(1, 3, 4), (700, 3, 4), (5000, 2, 3), (100_000, 3, 256), (300_000, 4, 6)])
+def test_dedup_rank_vs_definition(B, L, K):
+    from rqhip import ops
+    g = torch.Generator().manual_seed(B + L + K)
+    ids = torch.randint(0, K, (L, B), generator=g)
+    rank, n = ops.dedup_rank(ids.cuda(), K)
+    # definition via a stable sort on the packed key (host)
+    key = torch.zeros(B, dtype=torch.int64)
+    for l in range(L):
+        key = key * K + ids[l]
+    order = torch.sort(key, stable=True).indices
+    sk = key[order]
+    start = torch.ones(B, dtype=torch.bool)
+    start[1:] = sk[1:] != sk[:-1]
+    pos = torch.arange(B)
+    run_start = torch.cummax(torch.where(start, pos, torch.zeros_like(pos)), 0).values
+    want = torch.empty(B, dtype=torch.int64)
+    want[order] = pos - run_start
+    assert torch.equal(rank.cpu(), want)
+    assert int(n) == int(start.sum())
+
+
+def test_dedup_all_rows_identical():
+    from rqhip import ops
+    ids = torch.zeros((3, 70_000), dtype=torch.int64).cuda()
+    rank, n = ops.dedup_rank(ids, 256)
+    assert int(n) == 1 and torch.equal(rank.cpu(), torch.arange(70_000))
