@@ -169,7 +169,7 @@ def main():
             "breakdown_ms": {"encoder_fwd": round(enc_ms, 3), "rq_forward_call": round(rq_ms, 3),
                              "model_fwd_total": round(fwd_ms, 3), "backward_total": round(bwd_ms, 3),
                              "adamw": round(opt_ms, 3), "kmeans_init_warmup_s": round(kmeans_s, 3)},
-            "final_loss": round(float(out.loss), 6), "p_unique_ids": round(float(out.p_unique_ids), 6),
+            "final_loss": round(float(out.loss.detach()), 6), "p_unique_ids": round(float(out.p_unique_ids), 6),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_rows)

@@ -20,7 +20,7 @@
  * the same order the HIP kernels use -- so that GPU output can be compared to it bit for bit:
  *
  *   dot(x,c)    : one fp32 FMA chain over d = 0..D-1 starting from 0 (what v_mfma_f32_32x32x2_f32
- *                 computes), with x pre-scaled by 2 as the reference's `2 * x @ codebook.T` does.
+ *                 computes); the reference's factor 2 (`2 * x @ codebook.T`) multiplies the finished dot.
  *   sumsq(v)    : two accumulators by the parity of d, separately rounded multiply and add
  *                 (the reference's `(v**2).sum()` squares then sums), combined as a0 + a1.
  *   dotp(a,b)   : two FMA accumulators by the parity of d, combined as a0 + a1 (rotation trick).
@@ -62,10 +62,12 @@ static float dotp2(const float *a, const float *b, int D) {
     return a0 + a1;
 }
 
-/* 2x . c as one FMA chain (quantize.py:116: `2 * x @ codebook.T` == (2x) @ C^T) */
-static float dot2x_chain(const float *x, const float *c, int D) {
+/* x . c as one FMA chain over d.  quantize.py:116 computes `2 * x @ codebook.T` == (2x) @ C^T; scaling by 2
+ * is exact in binary floating point, so 2 * chain(x, c) is the same number (bar overflow / subnormal partial
+ * sums, where the reference's BLAS result is unspecified anyway) -- and lets the matrix pipe consume x as is. */
+static float dot_chain(const float *x, const float *c, int D) {
     float acc = 0.0f;
-    for (int d = 0; d < D; ++d) acc = fmaf(2.0f * x[d], c[d], acc);
+    for (int d = 0; d < D; ++d) acc = fmaf(x[d], c[d], acc);
     return acc;
 }
 
@@ -92,7 +94,7 @@ static void l2_dist_row(const float *x, const float *cb, const float *csq, int K
     float xsq = sumsq2(x, D);
     for (int k = 0; k < K; ++k) {
         float t = xsq + csq[k];
-        dist[k] = t - dot2x_chain(x, cb + (size_t)k * D, D);
+        dist[k] = t - 2.0f * dot_chain(x, cb + (size_t)k * D, D);
     }
 }
 

@@ -6,10 +6,16 @@
 // in oracle/rq_oracle.c:rqo_rq_backward.  HBM-bound: per row it reads res0, the L ids and the upstream
 // gradients once and writes g_res0 once; the codeword rows come from L2.
 //
-// One wave owns 32 rows in the pair layout of rq_rowmath.h.  Pass 1 replays the residual chain
-// (bit-identical to the forward) and parks res_l, l >= 1, in the caller's workspace; pass 2 walks the
-// levels backwards carrying G = dL/d res_l in registers and scatters each row's codeword gradient with
-// global_atomic_add_f32 (order of accumulation across rows is therefore not fixed; g_res0 is exact).
+// Kernel 1 (rows): one wave owns 32 rows in the pair layout of rq_rowmath.h.  Pass 1 replays the residual
+//   chain (bit-identical to the forward) and parks res_l, l >= 1, in the workspace; pass 2 walks the levels
+//   backwards carrying G = dL/d res_l in registers, writes g_res0 (exact) and leaves each row's codeword-
+//   gradient vector V_l (what the embedding backward would index_add) in the workspace slot of level l.
+// Kernel 2 (scatter): the embedding backward proper.  Each workgroup owns a contiguous range of rows and
+//   accumulates V_l into an LDS-private [L,K,D+1] table with ds_add_f32 (row stride D+1 spreads codes over
+//   the banks), then stores the table as one partial; a direct global atomicAdd version of this (9.6 M
+//   atomics on 24 576 addresses at B = 100 k) measured 6.1 ms on MI355X, 60x the whole forward.
+// Kernel 3 (reduce): g_codebooks[j] = sum over workgroups of partial[g][j], fixed order.
+// When one level's table exceeds LDS (K (D+1) 4 B > 150 KiB) kernel 1 falls back to global atomics.
 #include "rq_rowmath.h"
 
 namespace rqhip {
@@ -19,7 +25,8 @@ struct RqBwdParams {
     const int64_t *ids;
     const float *g_embs, *g_embsum, *g_resid, *g_loss;
     float *g_res0, *g_cb;
-    float *ws;  // [(L-1), B, D] replayed residuals
+    float *ws;  // [L, B, D]: slot l holds res_l (l >= 1) during pass 1, then V_l
+    int atomic_scatter;  // 1: scatter codeword gradients with global atomics (tables do not fit LDS)
     long long B, n_tiles;
     int D, L, K;
     float beta;
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
             load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + id) * D, D, h, e);
             const float xsq = (MODE == RQHIP_MODE_ROTATION) ? pair_sumsq<KSTEPS>(r) : 0.0f;
             level_output<KSTEPS, MODE>(r, e, xsq, o);
-            float *dst = p.ws + ((size_t)l * p.B + rc) * D;
+            float *dst = p.ws + ((size_t)(l + 1) * p.B + rc) * D;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 r[kk] = r[kk] - o[kk];
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
 
         for (int l = L - 1; l >= 0; --l) {
             if (l != L - 1) {
-                const float *src = (l == 0) ? p.res0 + (size_t)rc * D : p.ws + ((size_t)(l - 1) * p.B + rc) * D;
+                const float *src = (l == 0) ? p.res0 + (size_t)rc * D : p.ws + ((size_t)l * p.B + rc) * D;
                 load_pair_row<KSTEPS>(src, D, h, r);
             }
             const long long id = p.ids[(size_t)l * p.B + rc];
@@ -78,7 +85,8 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
                 A[kk] = a - G[kk];
                 gr[kk] = (p.g_resid && d < D) ? p.g_resid[lrow + d] : 0.0f;
             }
-            float *dE = p.g_cb ? p.g_cb + ((size_t)l * K + id) * D : nullptr;
+            float *dE = (p.g_cb && p.atomic_scatter) ? p.g_cb + ((size_t)l * K + id) * D : nullptr;
+            float *V = (p.g_cb && !p.atomic_scatter) ? p.ws + lrow : nullptr;
             if (MODE == RQHIP_MODE_ROTATION) {
                 float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
                 const float xsq = pair_sumsq<KSTEPS>(r);
@@ -91,7 +99,10 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
                     const float embg = (2.0f * (e[kk] - r[kk])) * gl;
                     G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
                     const int d = 2 * kk + h;
-                    if (dE && ok && d < D) atomicAdd(dE + d, embg);
+                    if (ok && d < D) {
+                        if (dE) atomicAdd(dE + d, embg);
+                        if (V) V[d] = embg;
+                    }
                 }
             } else {
 #pragma unroll
@@ -102,10 +113,16 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
                     if (MODE == RQHIP_MODE_EVAL) {
                         const float contrib = A[kk] + embg;
                         G[kk] = (gr[kk] + G[kk]) + commit;
-                        if (dE && ok && d < D) atomicAdd(dE + d, contrib);
+                        if (ok && d < D) {
+                            if (dE) atomicAdd(dE + d, contrib);
+                            if (V) V[d] = contrib;
+                        }
                     } else {
                         G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
-                        if (dE && ok && d < D) atomicAdd(dE + d, embg);
+                        if (ok && d < D) {
+                            if (dE) atomicAdd(dE + d, embg);
+                            if (V) V[d] = embg;
+                        }
                     }
                 }
             }
@@ -119,6 +136,59 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
         }
     }
 }
+
+
+// ---- kernel 2: LDS-private scatter of V into per-workgroup codebook-gradient tables -----------------------
+// thread (rs, d): rs = row slot inside the workgroup's step, d = feature.  DR = D rounded up to a power of 2.
+__global__ __launch_bounds__(256) void rq_cbgrad_scatter_kernel(const float *__restrict__ V,
+                                                                const int64_t *__restrict__ ids, long long B, int D,
+                                                                int DR, int K, int l0, int nl, long long rows_per_wg,
+                                                                float *__restrict__ partial, int LKD_total) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int stride = D + 1;
+    const int tbl = nl * K * stride;
+    for (int e = threadIdx.x; e < tbl; e += 256) acc[e] = 0.0f;
+    __syncthreads();
+    const int d = threadIdx.x % DR, rs = threadIdx.x / DR, rstep = 256 / DR;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < B) ? r0 + rows_per_wg : B;
+    if (d < D) {
+        for (long long row = r0 + rs; row < r1; row += rstep) {
+            for (int l = 0; l < nl; ++l) {
+                const int id = (int)ids[(size_t)(l0 + l) * B + row];
+                const float v = V[((size_t)(l0 + l) * B + row) * D + d];
+                atomicAdd(&acc[(l * K + id) * stride + d], v);  // ds_add_f32
+            }
+        }
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * LKD_total + (size_t)l0 * K * D;
+    for (int e = threadIdx.x; e < nl * K * D; e += 256) {
+        const int kd = e / D, dd = e - kd * D;
+        out[e] = acc[kd * stride + dd];
+    }
+}
+
+// ---- kernel 3: fixed-order sum of the per-workgroup partials ------------------------------------------------
+__global__ void rq_cbgrad_reduce_kernel(const float *__restrict__ partial, int G, int n, float *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.0f;
+    for (int g = 0; g < G; ++g) s = s + partial[(size_t)g * n + j];
+    out[j] = s;
+}
+
+constexpr size_t kScatterLdsBudget = 150 * 1024;
+constexpr int kMaxScatterWgs = 128;
+
+static int scatter_wgs(long long B) {
+    long long g = (B + 255) / 256;
+    if (g > kMaxScatterWgs) g = kMaxScatterWgs;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static bool scatter_fits_lds(int D, int K) { return (size_t)K * (D + 1) * sizeof(float) <= kScatterLdsBudget; }
 
 template <int KSTEPS>
 static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
@@ -144,9 +214,12 @@ static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
 
 using namespace rqhip;
 
-extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L) {
-    if (B <= 0 || D <= 0 || L <= 1) return 16;
-    return (size_t)(L - 1) * (size_t)B * (size_t)D * sizeof(float);
+// layout: [L,B,D] row scratch | [G, L*K*D] per-workgroup partial tables (LDS scatter path only)
+extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K) {
+    if (B <= 0 || D <= 0 || L <= 0 || K <= 0) return 16;
+    const size_t rows = (size_t)L * (size_t)B * (size_t)D * sizeof(float);
+    const size_t partial = scatter_fits_lds(D, K) ? (size_t)scatter_wgs(B) * (size_t)L * K * D * sizeof(float) : 0;
+    return rows + partial;
 }
 
 extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
@@ -166,26 +239,57 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
         set_error("rq_backward: mode %d is not EVAL/STE/ROTATION", mode);
         return RQHIP_EARG;
     }
-    if (L > 1 && B > 0 && (!workspace || workspace_bytes < rqhip_rq_backward_workspace_bytes(B, D, L))) {
+    if (B > 0 && (!workspace || workspace_bytes < rqhip_rq_backward_workspace_bytes(B, D, L, K))) {
         set_error("rq_backward: workspace too small");
         return RQHIP_EWORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (g_codebooks) RQ_RETURN_IF_HIP(hipMemsetAsync(g_codebooks, 0, sizeof(float) * (size_t)L * K * D, s));
+    const bool lds_path = scatter_fits_lds(D, K);
+    if (g_codebooks && (B == 0 || !lds_path))
+        RQ_RETURN_IF_HIP(hipMemsetAsync(g_codebooks, 0, sizeof(float) * (size_t)L * K * D, s));
     if (B == 0) return RQHIP_OK;
     RqBwdParams p;
     p.res0 = res0; p.cb = codebooks; p.ids = ids; p.g_embs = g_embs; p.g_embsum = g_embsum;
     p.g_resid = g_resid; p.g_loss = g_loss; p.g_res0 = g_res0; p.g_cb = g_codebooks;
     p.ws = reinterpret_cast<float *>(workspace);
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.beta = beta;
+    p.atomic_scatter = lds_path ? 0 : 1;
     long long want = (p.n_tiles + 3) / 4;
     long long cap = (long long)cu_count() * 8;
     const int grid = (int)(want < cap ? want : cap);
+    int rc;
     switch (ksteps_for(D)) {
-        case 4: return launch_bwd<4>(p, mode, grid, s);
-        case 8: return launch_bwd<8>(p, mode, grid, s);
-        case 16: return launch_bwd<16>(p, mode, grid, s);
-        case 32: return launch_bwd<32>(p, mode, grid, s);
-        default: return launch_bwd<64>(p, mode, grid, s);
+        case 4: rc = launch_bwd<4>(p, mode, grid, s); break;
+        case 8: rc = launch_bwd<8>(p, mode, grid, s); break;
+        case 16: rc = launch_bwd<16>(p, mode, grid, s); break;
+        case 32: rc = launch_bwd<32>(p, mode, grid, s); break;
+        default: rc = launch_bwd<64>(p, mode, grid, s); break;
     }
+    if (rc || !g_codebooks || !lds_path) return rc;
+
+    // embedding backward: LDS-private scatter in groups of whole levels, then a fixed-order reduce
+    const int G = scatter_wgs(B);
+    const long long rows_per_wg = (B + G - 1) / G;
+    const int LKD = L * K * D;
+    float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
+    int DR = 1;
+    while (DR < D) DR <<= 1;
+    const size_t level_bytes = (size_t)K * (D + 1) * sizeof(float);
+    int per_pass = (int)(kScatterLdsBudget / level_bytes);
+    if (per_pass < 1) per_pass = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rq_cbgrad_scatter_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScatterLdsBudget));
+        attr_set = true;
+    }
+    for (int l0 = 0; l0 < L; l0 += per_pass) {
+        const int nl = (L - l0 < per_pass) ? L - l0 : per_pass;
+        hipLaunchKernelGGL(rq_cbgrad_scatter_kernel, dim3(G), dim3(256), nl * level_bytes, s, p.ws, ids, (long long)B,
+                           D, DR, K, l0, nl, rows_per_wg, partial, LKD);
+        RQ_CHECK_LAUNCH("rq_cbgrad_scatter_kernel");
+    }
+    hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 255) / 256), dim3(256), 0, s, partial, G, LKD, g_codebooks);
+    RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+    return RQHIP_OK;
 }

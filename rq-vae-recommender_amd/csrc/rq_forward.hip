@@ -8,7 +8,8 @@
 // Mapping to the hardware
 //   * distance: dist[i,k] = (|x_i|^2 + |c_k|^2) - (2 x_i).c_k with the dot product on the fp32 matrix
 //     pipe: v_mfma_f32_32x32x2_f32 computes a 32(codes) x 32(items) tile, k = 2 feature dims per
-//     instruction, as an exact fp32 FMA chain in d order (== oracle's dot2x_chain).  Codes are the A
+//     instruction, as an exact fp32 FMA chain in d order (== oracle's dot_chain; the factor 2 is applied to
+//     the finished dot product, which is exact).  Codes are the A
 //     operand so that after the MFMA every lane owns ONE item (column) and 16 codes (rows): the argmin
 //     over codes is a per-lane running minimum, no cross-lane traffic until one final lane/lane+32
 //     exchange per level.
@@ -26,12 +27,23 @@
 
 namespace rqhip {
 
+#ifdef RQ_TIMING
+// developer-only phase timestamps of wave 0 / workgroup 0 (build with EXTRA=-DRQ_TIMING; tools/phase_timing.py)
+__device__ unsigned long long rq_dbg[256];
+#define RQ_STAMP(i)                                                                         \
+    do {                                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 256) rq_dbg[(i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RQ_STAMP(i) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kWgThreads = 512;
-constexpr int kWavesPerWg = kWgThreads / RQ_WAVE;
+// workgroup size is a template parameter of the kernel (NT): more waves per SIMD hide the VALU epilogue and the
+// per-level tail of one wave behind the MFMAs of the others, as far as the register budget of KSTEPS allows
 constexpr int kLdsBudget = 160 * 1024;
 
 struct RqFwdParams {
@@ -91,38 +103,71 @@ __global__ void rq_csq_kernel(const float *__restrict__ cb, int L, int K, int Kp
 // ---- LDS staging ------------------------------------------------------------------------------------
 // buffer = [image: KSTEPS*2*Kc floats as float4[(q*2+h)*Kc + c]][csq: Kc floats]
 // image float4 (q,h,c), element j  =  C[kbase+c][d = 2*(4q+j)+h]   (0 beyond K or D)
-template <int KSTEPS>
-__device__ __forceinline__ void stage_codes(float *buf, const float *__restrict__ cb_l,
-                                            const float *__restrict__ csq_l, int kbase, int Kc, int K,
+// `nbuf` consecutive buffers are filled from `nbuf` consecutive codebooks (resident mode: all levels at once,
+// so that a thread has up to kStageBatch independent 16-byte loads in flight before its first LDS write).
+constexpr int kStageBatch = 4;
+
+template <int KSTEPS, int NT>
+__device__ __forceinline__ void stage_codes(float *buf0, int buf_floats, int nbuf, const float *__restrict__ cb0,
+                                            const float *__restrict__ csq0, int csq_stride, int kbase, int Kc, int K,
                                             int D) {
     const int tid = threadIdx.x;
     if ((D & 3) == 0) {
-        constexpr int d4n = KSTEPS / 2;  // float4 groups per padded row
-        const int total = Kc * d4n;
-        for (int e = tid; e < total; e += kWgThreads) {
-            const int c = e / d4n, d4 = e - c * d4n;
-            const int k = kbase + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < K && 4 * d4 < D) v = *reinterpret_cast<const f32x4 *>(cb_l + (size_t)k * D + 4 * d4);
-            const int q = d4 >> 1, j = (d4 & 1) * 2;
-            f32x2 ev = {v.x, v.z}, od = {v.y, v.w};
-            *reinterpret_cast<f32x2 *>(buf + ((size_t)(q * 2 + 0) * Kc + c) * 4 + j) = ev;
-            *reinterpret_cast<f32x2 *>(buf + ((size_t)(q * 2 + 1) * Kc + c) * 4 + j) = od;
+        // thread -> (code c, float4 group d4) with d4 fixed for the thread's whole walk; c advances by a constant
+        // step, wrapping into the next buffer (no divisions, 32-bit offsets: L*K*D <= 2^27)
+        constexpr int d4n = KSTEPS / 2;            // float4 groups per padded row (power of two)
+        constexpr int cstep = NT / d4n;            // codes covered per sweep of the workgroup
+        const int d4 = tid & (d4n - 1);
+        const bool dok = 4 * d4 < D;
+        const int q = d4 >> 1, j = (d4 & 1) * 2;
+        const int lds_even = ((q * 2 + 0) * Kc) * 4 + j, lds_odd = ((q * 2 + 1) * Kc) * 4 + j;
+        int c = tid / d4n, bi = 0;
+        while (c >= Kc) { c -= Kc; ++bi; }
+        while (bi < nbuf) {
+            f32x4 v[kStageBatch];
+            int cc[kStageBatch], bb[kStageBatch];
+#pragma unroll
+            for (int u = 0; u < kStageBatch; ++u) {
+                cc[u] = c; bb[u] = bi;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int k = kbase + c;
+                if (bi < nbuf && k < K && dok)
+                    v[u] = *reinterpret_cast<const f32x4 *>(cb0 + (bi * K + k) * D + 4 * d4);
+                c += cstep;
+                while (c >= Kc && bi < nbuf) { c -= Kc; ++bi; }
+            }
+#pragma unroll
+            for (int u = 0; u < kStageBatch; ++u) {
+                if (bb[u] < nbuf) {
+                    float *buf = buf0 + bb[u] * buf_floats + cc[u] * 4;
+                    f32x2 ev = {v[u].x, v[u].z}, od = {v[u].y, v[u].w};
+                    *reinterpret_cast<f32x2 *>(buf + lds_even) = ev;
+                    *reinterpret_cast<f32x2 *>(buf + lds_odd) = od;
+                }
+            }
         }
     } else {
         constexpr int Dp = KSTEPS * 2;
-        const int total = Kc * Dp;
-        for (int e = tid; e < total; e += kWgThreads) {
-            const int c = e / Dp, d = e - c * Dp;
+        const int per_buf = Kc * Dp;
+        const int total = per_buf * nbuf;
+        for (int e = tid; e < total; e += NT) {
+            const int bi = e / per_buf, er = e - bi * per_buf;
+            const int c = er / Dp, d = er - c * Dp;
             const int k = kbase + c;
-            float v = (k < K && d < D) ? cb_l[(size_t)k * D + d] : 0.0f;
+            float v = (k < K && d < D) ? cb0[(bi * K + k) * D + d] : 0.0f;
             const int kk = d >> 1, h = d & 1;
-            buf[((size_t)((kk >> 2) * 2 + h) * Kc + c) * 4 + (kk & 3)] = v;
+            buf0[bi * buf_floats + (((kk >> 2) * 2 + h) * Kc + c) * 4 + (kk & 3)] = v;
         }
     }
-    float *csq_s = buf + (size_t)KSTEPS * 2 * Kc;
-    for (int c = tid; c < Kc; c += kWgThreads)
-        csq_s[c] = (kbase + c < K) ? csq_l[kbase + c] : __builtin_inff();
+    {
+        int c = tid, bi = 0;
+        while (c >= Kc) { c -= Kc; ++bi; }
+        while (bi < nbuf) {
+            buf0[bi * buf_floats + KSTEPS * 2 * Kc + c] = (kbase + c < K) ? csq0[bi * csq_stride + kbase + c] : __builtin_inff();
+            c += NT;
+            while (c >= Kc && bi < nbuf) { c -= Kc; ++bi; }
+        }
+    }
 }
 
 // ---- exact torch.min semantics for rows whose distances may be non-finite (rare) ----------------------
@@ -130,8 +175,8 @@ __device__ __forceinline__ void stage_codes(float *buf, const float *__restrict_
 // distance if any, else the first index of the minimum (quantize.py:128 / ATen min kernel).
 template <int KSTEPS>
 __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, float xsq_j,
-                                            const float *__restrict__ cb_l,
-                                            const float *__restrict__ csq_l, int K, int D) {
+                                               const float *__restrict__ cb_l, const float *__restrict__ csq_l, int K,
+                                               int D) {
     const int lane = threadIdx.x & 63;
     float x0[KSTEPS], x1[KSTEPS];
 #pragma unroll
@@ -146,11 +191,11 @@ __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, 
         float acc = 0.0f;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            if (2 * kk < D) acc = __builtin_fmaf(2.0f * x0[kk], c[2 * kk], acc);
-            if (2 * kk + 1 < D) acc = __builtin_fmaf(2.0f * x1[kk], c[2 * kk + 1], acc);
+            if (2 * kk < D) acc = __builtin_fmaf(x0[kk], c[2 * kk], acc);
+            if (2 * kk + 1 < D) acc = __builtin_fmaf(x1[kk], c[2 * kk + 1], acc);
         }
         const float t = xsq_j + csq_l[k];
-        const float dist = t - acc;
+        const float dist = t - 2.0f * acc;
         if (dist != dist) {
             nanidx = min(nanidx, k);
         } else if (dist < lbest || (dist == lbest && k < lidx)) {
@@ -172,99 +217,155 @@ __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, 
     return nanidx != 0x7fffffff ? nanidx : lidx;
 }
 
-template <int KSTEPS, int MODE>
-__global__ __launch_bounds__(kWgThreads) void rq_forward_kernel(const RqFwdParams p) {
+// ---- the hot loop: distances of 32 items against Kc staged codes, running argmin -------------------------
+// Per 32-code tile: KSTEPS dependent MFMAs (exact fp32 FMA chain over d), then 16 distances per lane:
+// distance = (|x|^2 + |c|^2) - (2x).c, strict '<' in ascending code order == first-index ties.  The MFMAs of
+// one wave overlap the VALU epilogue of the other wave on the same SIMD; interleaving them inside one wave
+// measured slower (an instruction between two MFMAs on one accumulator costs ~40 cycles, tools/mfma_probe.hip).
+template <int KSTEPS>
+__device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
+                                           int kbase, int il, int h, const float (&x)[KSTEPS], float xsq,
+                                           float &best, int &bidx) {
+    constexpr int KQ = KSTEPS / 4;
+    const int ntiles = Kc / 32;
+    // code offset of accumulator element j inside a tile, held in registers the optimiser cannot see through:
+    // as compile-time constants LLVM turns the index tournament below into a ~400-instruction decode of the
+    // comparison masks
+    int slotreg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(slotreg[j]) : "n"(8 * (j >> 2) + (j & 3)));
+    for (int t = 0; t < ntiles; ++t) {
+        f32x4 a[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[q] = img[(size_t)(q * 2 + h) * Kc + t * 32 + il];
+        const float *cq = csq_s + t * 32 + 4 * h;
+        f32x4 c4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c4[g] = *reinterpret_cast<const f32x4 *>(cq + 8 * g);
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < KSTEPS; ++sidx)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx >> 2][sidx & 3], x[sidx], acc, 0, 0, 0);
+        // acc[j]: code = 32 t + 8 (j>>2) + 4 h + (j&3), item = il.   dist = (|x|^2 + |c|^2) - 2 (x.c): the
+        // doubling is exact, so one FMA gives the separately rounded  tt - (2 acc)  (quantize.py:113-117).
+        float dv[16];
+        int ds[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float tt = xsq + c4[j >> 2][j & 3];
+            dv[j] = __builtin_fmaf(-2.0f, acc[j], tt);
+            ds[j] = slotreg[j];
+        }
+        // tournament instead of a 16-long dependent chain; the right element wins only on strict '<', so the
+        // lower code index survives ties at every round (== a left-to-right scan)
+#define RQ_TOURNAMENT_ROUND(W)                                    \
+    _Pragma("unroll") for (int j = 0; j < 16; j += 2 * (W)) {    \
+        const bool take = dv[j + (W)] < dv[j];                   \
+        dv[j] = take ? dv[j + (W)] : dv[j];                      \
+        ds[j] = take ? ds[j + (W)] : ds[j];                      \
+    }
+        RQ_TOURNAMENT_ROUND(1)
+        RQ_TOURNAMENT_ROUND(2)
+        RQ_TOURNAMENT_ROUND(4)
+        RQ_TOURNAMENT_ROUND(8)
+#undef RQ_TOURNAMENT_ROUND
+        const float tmin = dv[0];
+        const int slot = ds[0];
+        // branch-free merge: with a branch the compiler sinks the whole slot tournament into it and rebuilds the
+        // slot from the comparison masks with a ~300-instruction select chain
+        const int cand = kbase + t * 32 + 4 * h + slot;
+        const bool better = tmin < best;
+        best = better ? tmin : best;
+        bidx = better ? cand : bidx;
+    }
+}
+
+// FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
+template <int KSTEPS, int MODE, bool FULLD, int NT>
+__global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *smem = reinterpret_cast<float *>(smem_raw);
+    constexpr int KQ = KSTEPS / 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int il = lane & 31;
     const int h = lane >> 5;
-    const int D = p.D, K = p.K, Kc = p.Kc, L = p.L;
-    const size_t buf_floats = (size_t)Kc * (KSTEPS * 2 + 1);
+    const int D = FULLD ? 2 * KSTEPS : p.D;
+    const int K = p.K, Kc = p.Kc, L = p.L;
+    const int buf_floats = Kc * (KSTEPS * 2 + 1);
+    constexpr int kWavesPerWg = NT / RQ_WAVE;
     const long long total_waves = (long long)gridDim.x * kWavesPerWg;
-    const long long gw = (long long)blockIdx.x * kWavesPerWg + wave;
+    // round `it`: waves are enumerated wave-major (wave w of every workgroup before wave w+1), so a partly
+    // filled last round spreads over all CUs instead of filling the first workgroups only
+    const long long wave_slot = (long long)wave * gridDim.x + blockIdx.x;
+    const size_t level_stride = (size_t)p.B * D;  // elements between levels of embs / residuals
 
-    if (p.resident) {
-        for (int l = 0; l < L; ++l)
-            stage_codes<KSTEPS>(smem + l * buf_floats, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, 0, Kc,
-                                K, D);
-        __syncthreads();
-    }
+    auto load_rows = [&](long long tile, float(&v)[KSTEPS]) {
+        const long long row = tile * 32 + il;
+        const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
+        const float *src = p.res0 + (size_t)rowc * D + h;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) v[kk] = (FULLD || 2 * kk + h < D) ? src[2 * kk] : 0.0f;
+    };
+
+    RQ_STAMP(0);
+    float rn[KSTEPS];  // rows of the NEXT tile, fetched one tile ahead
+    load_rows(wave_slot, rn);
+    // per-level max codebook norm (Inf/NaN guard) lives in LDS: no global load inside the level loop, so the
+    // in-order vmcnt counter never makes a level wait for the previous level's stores
+    float *csqmax_s = smem + (p.resident ? L : 1) * buf_floats;
+    if (tid < L) csqmax_s[tid] = p.csqmax[tid];
+    if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
+    __syncthreads();
 
     for (int it = 0; it < p.n_iter; ++it) {
-        const long long tile = (long long)it * total_waves + gw;
+        const long long tile = (long long)it * total_waves + wave_slot;
         const bool active = tile < p.n_tiles;
         if (p.resident && !active) break;
         const long long row = tile * 32 + il;
         const bool row_ok = active && row < p.B;
-        const long long rowc = row_ok ? row : (p.B - 1);
 
         float r[KSTEPS], es[KSTEPS];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int d = 2 * kk + h;
-            r[kk] = (d < D) ? p.res0[(size_t)rowc * D + d] : 0.0f;
+            r[kk] = rn[kk];
             es[kk] = 0.0f;
         }
+        if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
         float lsum = 0.0f;
+        // running output pointers of this lane (advanced per level: no 64-bit multiplies inside the level loop)
+        int64_t *ids_ptr = p.ids + row;
+        float *norm_ptr = p.embs_norm ? p.embs_norm + (size_t)row * L : nullptr;
+        float *embs_ptr = p.embs ? p.embs + (size_t)row * D + h : nullptr;
+        float *resid_ptr = p.residuals ? p.residuals + (size_t)row * D + h : nullptr;
+        RQ_STAMP(1);
 
         for (int l = 0; l < L; ++l) {
-            const float *cb_l = p.cb + (size_t)l * K * D;
-            const float *csq_l = p.csq + (size_t)l * p.Kp;
+            RQ_STAMP(2 + 8 * l);
+            const float csqmax_l = csqmax_s[l];
 
             // |x|^2 (quantize.py:114): parity accumulators, multiply and add separately rounded
             const float xsq = pair_sumsq<KSTEPS>(r);
-
             float best = __builtin_inff();
             int bidx = 0;
 
+            const float *buf = smem + (p.resident ? l * buf_floats : 0);
             for (int ch = 0; ch < p.nchunks; ++ch) {
                 const int kbase = ch * Kc;
-                const float *buf = smem + (p.resident ? l * buf_floats : 0);
                 if (!p.resident) {
                     __syncthreads();  // previous chunk fully consumed
-                    stage_codes<KSTEPS>(smem, cb_l, csq_l, kbase, Kc, K, D);
+                    stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
+                                        kbase, Kc, K, D);
                     __syncthreads();
                 }
-                if (active) {
-                    const f32x4 *img = reinterpret_cast<const f32x4 *>(buf);
-                    const float *csq_s = buf + (size_t)KSTEPS * 2 * Kc;
-                    const int ntiles = Kc / 32;
-
-                    for (int t = 0; t < ntiles; ++t) {
-                        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int q = 0; q < KSTEPS / 4; ++q) {
-                            const f32x4 a4 = img[(size_t)(q * 2 + h) * Kc + t * 32 + il];
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, r[4 * q + 0] + r[4 * q + 0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, r[4 * q + 1] + r[4 * q + 1], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, r[4 * q + 2] + r[4 * q + 2], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r[4 * q + 3] + r[4 * q + 3], acc, 0, 0, 0);
-                        }
-                        // acc[j] belongs to code  t*32 + 8*(j>>2) + 4*h + (j&3)  and item il
-                        const float *cq = csq_s + t * 32 + 4 * h;
-                        const int kt = kbase + t * 32 + 4 * h;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 c4 = *reinterpret_cast<const f32x4 *>(cq + 8 * g);
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                const float tt = xsq + c4[jj];            // (|x|^2 + |c|^2)
-                                const float dist = tt - acc[4 * g + jj];  //   - (2x).c
-                                const int k = kt + 8 * g + jj;
-                                if (dist < best) {
-                                    best = dist;
-                                    bidx = k;
-                                }
-                            }
-                        }
-                    }
-                }
+                if (active)
+                    scan_codes<KSTEPS>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r,
+                                       xsq, best, bidx);
             }
 
+            RQ_STAMP(3 + 8 * l);
             if (active) {
                 // lanes (il,0) and (il,1) scanned disjoint code subsets: keep the smaller, ties -> lower index
                 {
@@ -276,23 +377,37 @@ __global__ __launch_bounds__(kWgThreads) void rq_forward_kernel(const RqFwdParam
                     }
                 }
                 // rows whose distances can be Inf/NaN take torch's exact scan
-                const float guard = xsq + p.csqmax[l];
-                const bool bad = !(guard < __builtin_inff());
+                // fast path only when no distance term can overflow (then fma(-2,acc,tt) == tt - 2*acc exactly)
+                const float guard = xsq + csqmax_l;
+                const bool bad = !(guard < 1.0e38f);
                 unsigned long long badmask = __ballot(bad) & 0xffffffffull;
-                while (badmask) {
-                    const int j = __builtin_ctzll(badmask);
-                    badmask &= badmask - 1;
-                    const float xj = __shfl(xsq, j, 64);
-                    const int res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, D);
-                    if (il == j) bidx = res;
+                if (badmask) {
+                    const float *cb_l = p.cb + (size_t)l * K * D;
+                    const float *csq_l = p.csq + (size_t)l * p.Kp;
+                    while (badmask) {
+                        const int j = __builtin_ctzll(badmask);
+                        badmask &= badmask - 1;
+                        const float xj = __shfl(xsq, j, 64);
+                        const int res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
+                        if (il == j) bidx = res;
+                    }
                 }
 
-                // codeword gather (quantize.py:101-102) for this lane's feature parity
+                RQ_STAMP(4 + 8 * l);
+                // codeword gather (quantize.py:101-102) for this lane's feature parity: from the staged LDS image
+                // when the whole level is resident, else from global memory (L2)
                 float e[KSTEPS];
+                if (p.resident) {
+                    const f32x4 *img = reinterpret_cast<const f32x4 *>(buf) + h * Kc + bidx;
 #pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) {
-                    const int d = 2 * kk + h;
-                    e[kk] = (d < D) ? cb_l[(size_t)bidx * D + d] : 0.0f;
+                    for (int q = 0; q < KQ; ++q) {
+                        const f32x4 v = img[q * 2 * Kc];
+                        e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+                    }
+                } else {
+                    const float *src = p.cb + ((size_t)l * K + bidx) * D + h;
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) e[kk] = (FULLD || 2 * kk + h < D) ? src[2 * kk] : 0.0f;
                 }
                 // QuantizeLoss (loss.py:38-41): both terms equal sum((x-emb)^2)
                 float sa = 0.0f;
@@ -305,26 +420,31 @@ __global__ __launch_bounds__(kWgThreads) void rq_forward_kernel(const RqFwdParam
                 const float lv = s + p.beta * s;
                 lsum = (l == 0) ? lv : lsum + lv;
 
+                RQ_STAMP(5 + 8 * l);
                 float o[KSTEPS];
                 level_output<KSTEPS, MODE>(r, e, xsq, o);
 
-                const float onorm = __builtin_sqrtf(pair_sumsq<KSTEPS>(o));
-
+                RQ_STAMP(6 + 8 * l);
                 if (row_ok) {
-                    if (h == 0) {
-                        p.ids[(size_t)l * p.B + row] = (int64_t)bidx;
-                        if (p.embs_norm) p.embs_norm[(size_t)row * L + l] = onorm;
+                    if (h == 0) *ids_ptr = (int64_t)bidx;
+                    if (norm_ptr) {  // uniform branch: the sqrt sequence is skipped when norms are not requested
+                        const float onorm = __builtin_sqrtf(pair_sumsq<KSTEPS>(o));
+                        if (h == 0) norm_ptr[l] = onorm;
                     }
-                    const size_t base = ((size_t)l * p.B + row) * D;
+                    if (resid_ptr) {
 #pragma unroll
-                    for (int kk = 0; kk < KSTEPS; ++kk) {
-                        const int d = 2 * kk + h;
-                        if (d < D) {
-                            if (p.residuals) p.residuals[base + d] = r[kk];
-                            if (p.embs) p.embs[base + d] = o[kk];
-                        }
+                        for (int kk = 0; kk < KSTEPS; ++kk)
+                            if (FULLD || 2 * kk + h < D) resid_ptr[2 * kk] = r[kk];
+                    }
+                    if (embs_ptr) {
+#pragma unroll
+                        for (int kk = 0; kk < KSTEPS; ++kk)
+                            if (FULLD || 2 * kk + h < D) embs_ptr[2 * kk] = o[kk];
                     }
                 }
+                ids_ptr += p.B;
+                if (resid_ptr) resid_ptr += level_stride;
+                if (embs_ptr) embs_ptr += level_stride;
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
                     es[kk] = (l == 0) ? o[kk] : es[kk] + o[kk];
@@ -333,34 +453,53 @@ __global__ __launch_bounds__(kWgThreads) void rq_forward_kernel(const RqFwdParam
             }
         }
 
+        RQ_STAMP(100);
         if (row_ok) {
             if (h == 0 && p.loss) p.loss[row] = lsum;
             if (p.emb_sum) {
+                float *dst = p.emb_sum + (size_t)row * D + h;
 #pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) {
-                    const int d = 2 * kk + h;
-                    if (d < D) p.emb_sum[(size_t)row * D + d] = es[kk];
-                }
+                for (int kk = 0; kk < KSTEPS; ++kk)
+                    if (FULLD || 2 * kk + h < D) dst[2 * kk] = es[kk];
             }
         }
+        RQ_STAMP(101);
     }
 }
 
+#ifdef RQ_TIMING
+extern "C" int rqhip_debug_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rqhip::rq_dbg), sizeof(unsigned long long) * 256);
+}
+#endif
+
+// threads per workgroup by register appetite: <= 168 VGPRs at KSTEPS <= 16 (3 waves/SIMD), 256 at 32, 512 at 64
+template <int KSTEPS>
+struct WgThreads { static constexpr int value = KSTEPS <= 16 ? 768 : KSTEPS == 32 ? 512 : 256; };
+
 template <int KSTEPS>
 static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hipStream_t s) {
+    constexpr int NT = WgThreads<KSTEPS>::value;
     auto go = [&](auto kern) -> int {
         RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         profile_begin(s);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWgThreads), lds, s, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
         profile_end(s);
         RQ_CHECK_LAUNCH("rq_forward_kernel");
         return 0;
     };
+    const bool full = p.D == 2 * KSTEPS;
     switch (mode) {
-        case RQHIP_MODE_EVAL: return go(rq_forward_kernel<KSTEPS, RQHIP_MODE_EVAL>);
-        case RQHIP_MODE_STE: return go(rq_forward_kernel<KSTEPS, RQHIP_MODE_STE>);
-        case RQHIP_MODE_ROTATION: return go(rq_forward_kernel<KSTEPS, RQHIP_MODE_ROTATION>);
+        case RQHIP_MODE_EVAL:
+            return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_EVAL, true, NT>)
+                        : go(rq_forward_kernel<KSTEPS, RQHIP_MODE_EVAL, false, NT>);
+        case RQHIP_MODE_STE:
+            return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_STE, true, NT>)
+                        : go(rq_forward_kernel<KSTEPS, RQHIP_MODE_STE, false, NT>);
+        case RQHIP_MODE_ROTATION:
+            return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_ROTATION, true, NT>)
+                        : go(rq_forward_kernel<KSTEPS, RQHIP_MODE_ROTATION, false, NT>);
     }
     set_error("rq_forward: unsupported mode %d", mode);
     return RQHIP_EARG;
@@ -370,7 +509,7 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
 
 using namespace rqhip;
 
-static inline int pad32(int k) { return (k + 31) & ~31; }
+static inline int pad32(int k) { return (k + 63) & ~63; }  // code tiles are processed in pairs
 
 extern "C" size_t rqhip_rq_forward_workspace_bytes(int L, int K) {
     if (L <= 0 || K <= 0) return 0;
@@ -414,23 +553,24 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     p.embs_norm = embs_norm;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
     const size_t level_bytes = (size_t)Kp * (Dp + 1) * sizeof(float);
-    if (level_bytes * L <= (size_t)kLdsBudget) {
+    if (level_bytes * L + 64 <= (size_t)kLdsBudget) {
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
         p.resident = 0;
-        int kc = (int)(((size_t)kLdsBudget / 2) / ((size_t)(Dp + 1) * sizeof(float)));  // <= 80 KiB: 2 WG/CU
-        kc &= ~31;
+        int kc = (int)(((size_t)kLdsBudget / 2 - 64) / ((size_t)(Dp + 1) * sizeof(float)));  // <= 80 KiB: 2 WG/CU
+        kc &= ~63;
         if (kc > Kp) kc = Kp;
-        if (kc < 32) kc = 32;
+        if (kc < 64) kc = 64;
         p.Kc = kc; p.nchunks = (Kp + kc - 1) / kc;
     }
-    const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1);
+    const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1) + 16 * sizeof(float);
     const int cus = cu_count();
     const int wg_per_cu = (lds * 2 <= (size_t)kLdsBudget) ? 2 : 1;
-    long long want = (p.n_tiles + kWavesPerWg - 1) / kWavesPerWg;
+    const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
+    long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
     long long cap = (long long)cus * wg_per_cu;
     const int grid = (int)(want < cap ? want : cap);
-    const long long total_waves = (long long)grid * kWavesPerWg;
+    const long long total_waves = (long long)grid * waves_per_wg;
     p.n_iter = (int)((p.n_tiles + total_waves - 1) / total_waves);
 
     switch (ksteps) {

@@ -34,12 +34,12 @@ class RqStackFunction(torch.autograd.Function):
         out = ops.rq_forward(res0, codebooks, mode, beta, want_embs=want_levels, want_residuals=want_levels)
         ctx.save_for_backward(res0, codebooks, out.ids)
         ctx.mode, ctx.beta, ctx.want_levels = mode, beta, want_levels
-        ctx.mark_non_differentiable(out.ids, out.embs_norm)
-        empty = res0.new_empty((0,))
-        embs = out.embs if want_levels else empty
-        residuals = out.residuals if want_levels else empty
-        if not want_levels:
-            ctx.mark_non_differentiable(embs, residuals)
+        embs = out.embs if want_levels else res0.new_empty((0,))
+        residuals = out.residuals if want_levels else res0.new_empty((0,))
+        if want_levels:
+            ctx.mark_non_differentiable(out.ids, out.embs_norm)
+        else:  # one call: a second mark_non_differentiable would replace the first
+            ctx.mark_non_differentiable(out.ids, out.embs_norm, embs, residuals)
         return embs, residuals, out.ids, out.loss, out.emb_sum, out.embs_norm
 
     @staticmethod

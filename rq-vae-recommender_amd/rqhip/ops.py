@@ -105,7 +105,7 @@ def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Te
         l = _lib.lib()
         g_res0 = torch.empty((B, D), dtype=torch.float32, device=dev) if need_res0 else None
         g_cb = torch.empty((L, K, D), dtype=torch.float32, device=dev) if need_codebooks else None
-        wsb = l.rqhip_rq_backward_workspace_bytes(B, D, L)
+        wsb = l.rqhip_rq_backward_workspace_bytes(B, D, L, K)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         rc = l.rqhip_rq_backward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(g_embs),
                                  _ptr(g_embsum), _ptr(g_resid), _ptr(g_loss), _ptr(g_res0), _ptr(g_cb), _ptr(ws),

@@ -50,5 +50,5 @@ def test_workspace_queries():
     l = _lib.lib()
     assert l.rqhip_rq_forward_workspace_bytes(3, 256) == (3 * 256 + 3) * 4
     assert l.rqhip_rq_forward_workspace_bytes(2, 100) == (2 * 128 + 2) * 4
-    assert l.rqhip_rq_backward_workspace_bytes(1000, 32, 3) == 2 * 1000 * 32 * 4
+    assert l.rqhip_rq_backward_workspace_bytes(1000, 32, 3, 256) == 3 * 1000 * 32 * 4 + 4 * 3 * 256 * 32 * 4
     assert l.rqhip_dedup_workspace_bytes(1000) >= 2048 * 4 + 4 * 1000 * 4
