@@ -168,3 +168,47 @@ def test_dedup_all_rows_identical():
     ids = torch.zeros((3, 70_000), dtype=torch.int64).cuda()
     rank, n = ops.dedup_rank(ids, 256)
     assert int(n) == 1 and torch.equal(rank.cpu(), torch.arange(70_000))
+
+
+@pytest.mark.parametrize("name", ["gumbel_a.npz", "gumbel_b.npz"])
+def test_quantize_module_gumbel_mode(name, monkeypatch):
+    """Quantize(forward_mode=GUMBEL_SOFTMAX).train(): draws torch.rand(B, K) on its device like the reference
+    (distributions/gumbel.py:10); with that draw replaced by the reference's own noise the outputs match."""
+    from modules.quantize import Quantize, QuantizeForwardMode
+    g = load_golden(name)
+    K, D = g["codebook"].shape
+    q = Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=QuantizeForwardMode.GUMBEL_SOFTMAX).cuda()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(g["codebook"]))
+    q.train()
+    U = torch.from_numpy(g["U"]).cuda()
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: U if tuple(a[0]) == tuple(U.shape) else real_rand(*a, **k))
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    out = q(x, temperature=float(g["temperature"]))
+    assert np.array_equal(out.ids.cpu().numpy(), g["ids"])
+    np.testing.assert_allclose(out.embeddings.detach().cpu().numpy(), g["embeddings"], rtol=2e-4, atol=1e-5)
+    ((out.embeddings * torch.from_numpy(g["g_emb"]).cuda()).sum() + (out.loss * torch.from_numpy(g["g_loss"]).cuda()).sum()).backward()
+    sx = max(1.0, float(np.abs(g["grad_x"]).max()))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=2e-3, atol=5e-5 * sx)
+
+
+def test_rqvae_gumbel_training_step_runs_level_by_level():
+    """GUMBEL_SOFTMAX is the class default of RqVae (rqvae.py:47): one optimisation step must work end to end."""
+    from data.schemas import SeqBatch
+    from modules.rqvae import RqVae
+    torch.manual_seed(0)
+    m = RqVae(input_dim=64, embed_dim=16, hidden_dims=[32], codebook_size=32, n_layers=3, n_cat_features=0,
+              codebook_kmeans_init=False).cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    x = torch.nn.functional.normalize(torch.randn(200, 64), dim=-1).cuda()
+    m.train()
+    assert not m._can_fuse()
+    out = m(SeqBatch(None, None, None, x, None, None), 0.2)
+    out.loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    opt.step()
+    m.eval()
+    assert m._can_fuse()
+    sem = m.get_semantic_ids(x)
+    assert sem.sem_ids.shape == (200, 3)

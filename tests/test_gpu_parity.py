@@ -210,3 +210,57 @@ def test_kmeans_golden_one_iteration_matches_reference_start(name):
     a_ref = o.kmeans_assign(x, cent)
     a_gpu = ops.kmeans_assign(_gpu(x), _gpu(cent)).cpu().numpy()
     assert np.array_equal(a_gpu, a_ref)
+
+
+# ---------------------------------------------------------------- gumbel ------------------------------
+
+def _gumbel_inputs(B, D, K, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((B, D)) * 0.5).astype(np.float32)
+    cb = (rng.standard_normal((K, D)) * 0.5).astype(np.float32)
+    U = rng.random((B, K)).astype(np.float32)
+    return x, cb, U
+
+
+@pytest.mark.parametrize("B,D,K,T", [(40, 32, 256, 0.2), (17, 16, 32, 0.5), (300, 64, 256, 0.2), (5, 8, 5, 1.0),
+                                     (1000, 32, 100, 0.2), (64, 128, 96, 0.3)])
+def test_gumbel_forward_backward_vs_oracle(B, D, K, T):
+    from rqhip import ops
+    x, cb, U = _gumbel_inputs(B, D, K, B + D + K)
+    ref = o.gumbel_forward(x, cb, U, T, 0.25)
+    ids, emb, loss = ops.gumbel_forward(_gpu(x), _gpu(cb), _gpu(U), T, 0.25)
+    assert np.array_equal(ids.cpu().numpy(), ref["ids"])                      # noise-free argmin: exact
+    np.testing.assert_allclose(emb.cpu().numpy(), ref["emb"], rtol=2e-4, atol=1e-5)  # exp((.)/T) amplifies 1-ulp distance differences
+    np.testing.assert_allclose(loss.cpu().numpy(), ref["loss"], rtol=1e-4, atol=1e-5)
+    rng = np.random.default_rng(1)
+    g_emb = rng.standard_normal((B, D)).astype(np.float32)
+    g_loss = rng.random(B).astype(np.float32)
+    r_x, r_cb = o.gumbel_backward(x, cb, U, T, 0.25, g_emb=g_emb, g_loss=g_loss)
+    g_x, g_cb = ops.gumbel_backward(_gpu(x), _gpu(cb), _gpu(U), T, 0.25, g_emb=_gpu(g_emb), g_loss=_gpu(g_loss))
+    sx, sc = max(1.0, float(np.abs(r_x).max())), max(1.0, float(np.abs(r_cb).max()))
+    np.testing.assert_allclose(g_x.cpu().numpy(), r_x, rtol=2e-3, atol=5e-5 * sx)
+    np.testing.assert_allclose(g_cb.cpu().numpy(), r_cb, rtol=2e-3, atol=5e-5 * sc)
+
+
+@pytest.mark.parametrize("name", ["gumbel_a.npz", "gumbel_b.npz"])
+def test_gumbel_vs_reference_golden(name):
+    """Same U as the reference drew (recovered in oracle/gen_golden.py): ids exact, emb/loss/grads close."""
+    from rqhip import ops
+    g = load_golden(name)
+    T, beta = float(g["temperature"]), float(g["beta"])
+    ids, emb, loss = ops.gumbel_forward(_gpu(g["x"]), _gpu(g["codebook"]), _gpu(g["U"]), T, beta)
+    assert np.array_equal(ids.cpu().numpy(), g["ids"])
+    np.testing.assert_allclose(emb.cpu().numpy(), g["embeddings"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-4, atol=1e-5)
+    g_x, g_cb = ops.gumbel_backward(_gpu(g["x"]), _gpu(g["codebook"]), _gpu(g["U"]), T, beta, g_emb=_gpu(g["g_emb"]),
+                                    g_loss=_gpu(g["g_loss"]))
+    sx, sc = max(1.0, float(np.abs(g["grad_x"]).max())), max(1.0, float(np.abs(g["grad_codebook"]).max()))
+    np.testing.assert_allclose(g_x.cpu().numpy(), g["grad_x"], rtol=2e-3, atol=5e-5 * sx)
+    np.testing.assert_allclose(g_cb.cpu().numpy(), g["grad_codebook"], rtol=2e-3, atol=5e-5 * sc)
+
+
+def test_gumbel_unsupported_shape_fails_loudly():
+    from rqhip import RqHipError, ops
+    x, cb, U = _gumbel_inputs(8, 32, 4096, 0)
+    with pytest.raises(RqHipError, match="Gumbel"):
+        ops.gumbel_forward(_gpu(x), _gpu(cb), _gpu(U), 0.2, 0.25)
