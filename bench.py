@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 INPUT_DIM, HIDDEN, EMBED, LEVELS, CODES, BETA = 768, [512, 256, 128], 32, 3, 256, 0.25
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")  # separate rocprofv3 --pmc passes (see file)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA == fp32 vector peak
 PEAK_HBM_GBPS = 8000.0
 
@@ -150,6 +151,10 @@ def main():
         mean_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = flops_per_row * B / (mean_ms * 1e-3) / 1e12 if kernel_ms else float("nan")
         bytes_per_row = 8 * EMBED + 12 * LEVELS + 4                          # 296 B fwd
+        traffic = None
+        if os.path.exists(PMC_FILE) and B == 100_000:
+            with open(PMC_FILE) as fh:
+                traffic = json.load(fh)["rq_forward_kernel"]["hbm_bytes_per_launch_corrected"]
         line = {
             "metric": "item-embeddings quantized/sec (RQ-VAE fwd+bwd)",
             "value": round(value, 1), "unit": "items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +166,7 @@ def main():
                        "codebook_size": CODES, "embed_dim": EMBED, "parallelism": f"row-shard x{world}, 1 flat grad all-reduce"},
             "roofline": {"kernel": "rq_forward_kernel<16,STE>", "bound": "mfma", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None, "launch_ms_mean": round(mean_ms, 5), "launches": len(kernel_ms),
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE+WRITE_SIZE, bytes/launch)" if traffic else None, "launch_ms_mean": round(mean_ms, 5), "launches": len(kernel_ms),
                          "flops_per_row": flops_per_row,
                          "hbm_view": {"algorithmic_bytes_per_row": bytes_per_row,
                                       "achieved_GBps": round(bytes_per_row * B / (mean_ms * 1e-3) / 1e9, 1),
