@@ -82,7 +82,7 @@ def main():
     args = ap.parse_args()
 
     from rqhip import dist as rqdist
-    from rqhip import ops
+    from rqhip import ops, tuning
     from data.schemas import SeqBatch
 
     rank, local_rank, world = rqdist.init_from_env("cuda")
@@ -91,6 +91,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    tuned = tuning.enable_tuned_gemms()   # fp32 library-GEMM selections for the MLPs (rqhip/tuning.py)
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.nn.functional.normalize(torch.randn(B, INPUT_DIM, generator=g), dim=-1).to(device)
@@ -174,6 +175,7 @@ def main():
             "breakdown_ms": {"encoder_fwd": round(enc_ms, 3), "rq_forward_call": round(rq_ms, 3),
                              "model_fwd_total": round(fwd_ms, 3), "backward_total": round(bwd_ms, 3),
                              "adamw": round(opt_ms, 3), "kmeans_init_warmup_s": round(kmeans_s, 3)},
+            "mlp_gemms": "PyTorch-ROCm fp32 (matmul precision highest), TunableOp selections " + ("loaded" if tuned else "off"),
             "final_loss": round(float(out.loss.detach()), 6), "p_unique_ids": round(float(out.p_unique_ids), 6),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,43 @@
+"""Library-GEMM selection for the encoder/decoder MLPs (PyTorch TunableOp).
+
+The MLP GEMMs are plain library GEMMs (hipBLASLt / rocBLAS through PyTorch-ROCm): 98 % of the FLOPs of a
+training step but not part of the hand-written hot path.  Two things matter on MI355X:
+
+* precision: the reference asks for torch.set_float32_matmul_precision("high") (modules/rqvae.py:19), which on its
+  CPU path is plain fp32 but on ROCm selects a reduced-precision "tf32" GEMM class.  Parity with the reference's
+  CPU results needs true fp32, so modules/rqvae.py pins "highest".
+* kernel choice: the default heuristic picks poor fp32 kernels for these tall-skinny shapes (32 TFLOP/s at
+  100 000 x 768 x 512); TunableOp's per-shape selection reaches ~110 TFLOP/s.  The selections for the shipped
+  shapes are committed in tuning/tunableop_gfx950.csv and loaded here with tuning DISABLED, so a run never pays
+  tuning time; set RQ_TUNE_GEMMS=1 to tune shapes that are not in the file (new batch sizes) and write them back.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+TUNING_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuning",
+                           "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms(verbose: bool = False) -> bool:
+    """Turn on TunableOp with the committed selections; returns True when active."""
+    if not torch.cuda.is_available() or os.environ.get("RQ_DISABLE_TUNABLEOP") == "1":
+        return False
+    import torch.cuda.tunable as tunable
+    tune_now = os.environ.get("RQ_TUNE_GEMMS") == "1"
+    if not tune_now and not os.path.exists(TUNING_FILE):
+        return False
+    out = os.environ.get("RQ_TUNE_GEMMS_OUT", TUNING_FILE)
+    tunable.enable(True)
+    tunable.set_filename(out if tune_now else TUNING_FILE)
+    tunable.tuning_enable(tune_now)
+    if tune_now:
+        tunable.set_max_tuning_duration(int(os.environ.get("RQ_TUNE_MS", "30")))
+        tunable.set_max_tuning_iterations(100)
+    if os.path.exists(TUNING_FILE):
+        ok = tunable.read_file(TUNING_FILE)
+        if verbose:
+            print(f"TunableOp: loaded {TUNING_FILE}: {ok}")
+    return True

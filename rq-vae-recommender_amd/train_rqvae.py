@@ -31,6 +31,7 @@ from modules.rqvae import RqVae
 from modules.tokenizer.semids import SemanticIdTokenizer
 from modules.utils import parse_config
 from rqhip import dist as rqdist
+from rqhip import tuning
 
 try:
     import gin
@@ -130,6 +131,7 @@ def train(
     if not torch.cuda.is_available():
         raise RuntimeError("train_rqvae needs a ROCm GPU: the quantisation path has no CPU implementation")
 
+    tuning.enable_tuned_gemms()  # fp32 library-GEMM selections for the encoder/decoder
     rank, local_rank, world = rqdist.init_from_env("cuda")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
