@@ -1,0 +1,58 @@
+"""End-to-end: the gin-driven entry point on the GPU (BASELINE configs 1 and 3 in miniature) -- k-means warm-up,
+optimisation steps, eval, id-diversity statistics, checkpoint, resume."""
+import os
+
+import pytest
+import torch
+
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg_name, tmp_path, monkeypatch, **overrides):
+    import train_rqvae
+    from rqhip import ginlite
+    monkeypatch.setenv("RQ_SYNTH_ITEMS", "3000")
+    try:
+        import gin  # noqa: F401
+        pytest.skip("real gin-config present: bindings below are written for the in-tree subset")
+    except ImportError:
+        pass
+    ginlite.clear_config()
+    ginlite.parse_config_file(os.path.join(PKG, "configs", cfg_name))
+    out_dir = str(tmp_path) + "/"
+    kw = dict(iterations=12, eval_every=6, save_model_every=12, save_dir_root=out_dir, wandb_logging=False,
+              dataset_folder=str(tmp_path / "no_such_dataset"), log_every=4)
+    kw.update(overrides)
+    res = train_rqvae.train(**kw)
+    ginlite.clear_config()
+    return res, out_dir
+
+
+def test_train_amazon_config_short_run_checkpoint_and_resume(tmp_path, monkeypatch):
+    import numpy as np
+    torch.manual_seed(0)
+    np.random.seed(0)
+    res, out_dir = _run("rqvae_amazon.gin", tmp_path, monkeypatch)
+    assert res["loss"] == res["loss"] and res["loss"] < 5.0          # finite, and far below the untrained ~1e1
+    ckpt = os.path.join(out_dir, "checkpoint_11.pt")
+    assert os.path.exists(ckpt)
+    state = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert set(state) == {"iter", "model", "model_config", "optimizer"} and state["iter"] == 11
+    assert {"layers.0.embedding.weight", "encoder.mlp.0.weight", "decoder.mlp.6.weight"} <= set(state["model"])
+    assert state["model"]["layers.0.embedding.weight"].shape == (256, 32)
+    # resume: start_iter = iter + 1, optimizer state restored, k-means init skipped
+    res2, _ = _run("rqvae_amazon.gin", tmp_path, monkeypatch, pretrained_rqvae_path=ckpt, iterations=4,
+                   save_model_every=1000, eval_every=1000)
+    assert res2["loss"] == res2["loss"]
+
+
+def test_train_ml32m_hyperparameters_rotation_trick(tmp_path, monkeypatch):
+    """configs/rqvae_ml32m.gin: D = 64, ROTATION_TRICK, batch 64, k-means init (train() default)."""
+    import numpy as np
+    torch.manual_seed(1)
+    np.random.seed(1)
+    res, out_dir = _run("rqvae_ml32m.gin", tmp_path, monkeypatch, iterations=10, eval_every=5, save_model_every=10)
+    assert res["loss"] == res["loss"]
+    assert os.path.exists(os.path.join(out_dir, "checkpoint_9.pt"))
