@@ -14,7 +14,7 @@ import subprocess
 import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-SO_PATH = os.path.join(_CSRC, "librqhip.so")
+SO_PATH = os.environ.get("RQHIP_SO", os.path.join(_CSRC, "librqhip.so"))  # RQHIP_SO: developer override (A/B builds)
 
 MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
 
