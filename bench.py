@@ -97,7 +97,7 @@ def main():
     X = torch.nn.functional.normalize(torch.randn(B, INPUT_DIM, generator=g), dim=-1).to(device)
     model, kmeans_s = build_model(device, X[: min(20000, B)])
     rqdist.broadcast_module(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)  # one multi-tensor kernel
     reducer = rqdist.FlatGradReducer(model.parameters())
     batch = SeqBatch(None, None, None, X, None, None)
 

@@ -143,6 +143,18 @@ int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int64_t *rank,
                      rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Reconstruction loss (modules/loss.py:5-10 ReconstructionLoss, called at modules/rqvae.py:152), fused.
+ *   forward : out[b] = sum_d (x_hat[b,d] - x[b,d])^2        x_hat, x: [B,N] with row strides ld_* (elements, >= N)
+ *   backward: g_x_hat[b,d] = 2 (x_hat[b,d] - x[b,d]) g_out[b]; g_x = -g_x_hat; either output may be NULL;
+ *             outputs are dense [B,N].
+ */
+int rqhip_recon_loss_forward(const float *x_hat, int64_t ld_hat, const float *x, int64_t ld_x, int64_t B,
+                             int N, float *out, rqhip_stream_t stream);
+int rqhip_recon_loss_backward(const float *x_hat, int64_t ld_hat, const float *x, int64_t ld_x,
+                              const float *g_out, int64_t B, int N, float *g_x_hat, float *g_x,
+                              rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every
  * rqhip_rq_forward call brackets its MAIN kernel (not the codebook-norm prologue) with a hipEvent pair
  * recorded on the call's stream.  rqhip_profile_read synchronises the recorded events and returns the

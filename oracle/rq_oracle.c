@@ -452,6 +452,34 @@ float rqo_kmeans_shift(const float *cent, const float *old, int K, int D) {
     return m;
 }
 
+/* ---- reconstruction loss (modules/loss.py:5-10): out[b] = sum_d (x_hat-x)^2 ------------------------------
+ * Fixed order == csrc/recon_loss.hip: 64 lane partials, lane l owning the 16-byte groups l, l+64, ... (or the
+ * single elements l, l+64, ... when N is not a multiple of 4), each added in ascending address order; then a
+ * 6-round xor butterfly p[l] += p[l ^ m], m = 32..1. */
+int rqo_recon_loss(const float *x_hat, const float *x, int64_t B, int N, float *out) {
+    if (B < 0 || N <= 0 || !x_hat || !x || !out) return RQO_EARG;
+    for (int64_t b = 0; b < B; ++b) {
+        const float *a = x_hat + (size_t)b * N, *c = x + (size_t)b * N;
+        float p[64], q[64];
+        for (int l = 0; l < 64; ++l) {
+            float s = 0.0f;
+            if ((N & 3) == 0) {
+                for (int i = l; i < N / 4; i += 64)
+                    for (int j = 0; j < 4; ++j) { float d = a[4 * i + j] - c[4 * i + j]; s = s + d * d; }
+            } else {
+                for (int i = l; i < N; i += 64) { float d = a[i] - c[i]; s = s + d * d; }
+            }
+            p[l] = s;
+        }
+        for (int m = 32; m >= 1; m >>= 1) {
+            for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ m];
+            memcpy(p, q, sizeof(p));
+        }
+        out[b] = p[0];
+    }
+    return RQO_OK;
+}
+
 /* ---- id statistics -------------------------------------------------------------------------- */
 
 static int tuple_eq(const int64_t *ids, int64_t B, int L, int64_t a, int64_t b) {

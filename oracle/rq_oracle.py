@@ -189,3 +189,12 @@ def count_rows_without_later_duplicate(ids) -> int:
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     L, B = ids.shape
     return int(lib().rqo_count_rows_without_later_duplicate(_p(ids), C.c_int64(B), C.c_int(L)))
+
+
+def recon_loss(x_hat, x) -> np.ndarray:
+    """Row-wise sum of squared differences in the kernel's fixed order (modules/loss.py:5-10)."""
+    x_hat, x = _f(x_hat), _f(x)
+    B, N = x.shape
+    out = np.empty((B,), np.float32)
+    _chk(lib().rqo_recon_loss(_p(x_hat), _p(x), C.c_int64(B), C.c_int(N), _p(out)), "recon_loss")
+    return out

@@ -1,18 +1,22 @@
 """Loss modules with the reference's names and semantics (reference modules/loss.py:5-41).
 
 `QuantizeLoss` exists for API compatibility: inside Quantize/RqVae the same quantity is produced by the
-fused HIP kernel (csrc/rq_forward.hip) and its gradient by csrc/rq_backward.hip.  The reconstruction losses
-act on the decoder output and stay PyTorch-ROCm elementwise ops."""
+fused HIP kernel (csrc/rq_forward.hip) and its gradient by csrc/rq_backward.hip.  `ReconstructionLoss` is a fused
+HIP kernel too (csrc/recon_loss.hip); the categorical variant adds PyTorch-ROCm BCE on the trailing columns."""
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from rqhip.autograd import ReconLossFunction
+
 
 class ReconstructionLoss(nn.Module):
-    """Row-wise squared error, summed over features."""
+    """Row-wise squared error, summed over features: one fused HIP pass (csrc/recon_loss.hip) instead of the
+    sub / pow / sum kernels the expression would launch; GPU tensors only, like the rest of the path."""
 
     def forward(self, x_hat: Tensor, x: Tensor) -> Tensor:
-        err = x_hat - x
-        return (err * err).sum(dim=-1)
+        lead = x.shape[:-1]
+        out = ReconLossFunction.apply(x_hat.reshape(-1, x_hat.shape[-1]), x.reshape(-1, x.shape[-1]))
+        return out.reshape(lead)
 
 
 class CategoricalReconstuctionLoss(nn.Module):  # (sic) the reference's spelling is part of its API

@@ -38,6 +38,8 @@ SIGNATURES = {
     "rqhip_kmeans_update": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "rqhip_dedup_workspace_bytes": (_sz, [_i64]),
     "rqhip_dedup_rank": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_recon_loss_forward": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp]),
+    "rqhip_recon_loss_backward": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),
 }

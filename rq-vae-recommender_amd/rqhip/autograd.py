@@ -73,3 +73,20 @@ class GumbelLevelFunction(torch.autograd.Function):
         g_x, g_cb = ops.gumbel_backward(x, codebook, U, ctx.temperature, ctx.beta, g_emb=_dense(g_emb),
                                         g_loss=_dense(g_loss))
         return g_x, g_cb, None, None, None
+
+
+class ReconLossFunction(torch.autograd.Function):
+    """Row-wise squared error (reference modules/loss.py:5-10) as one HIP pass forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, x_hat: Tensor, x: Tensor):
+        ctx.save_for_backward(x_hat, x)
+        return ops.recon_loss_forward(x_hat, x)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_hat, x = ctx.saved_tensors
+        need_hat, need_x = ctx.needs_input_grad
+        if not (need_hat or need_x):
+            return None, None
+        return ops.recon_loss_backward(x_hat, x, _dense(g_out), need_hat, need_x)

@@ -221,3 +221,38 @@ def profile_read(cap: int = 4096):
     n = C.c_int(0)
     check(_lib.lib().rqhip_profile_read(buf, cap, C.byref(n)), "rqhip_profile_read")
     return [buf[i] for i in range(n.value)]
+
+
+def _rows(t: Tensor, name: str) -> Tensor:
+    """[B,N] fp32 with unit column stride (row stride may exceed N: slices of a wider matrix are fine)."""
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise RqHipError(f"{name} must be a 2-D float32 tensor")
+    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+def recon_loss_forward(x_hat: Tensor, x: Tensor) -> Tensor:
+    """out[b] = sum_d (x_hat - x)^2 (rqhip_recon_loss_forward; reference modules/loss.py:5-10)."""
+    _need_gpu(x_hat, x)
+    x_hat, x = _rows(x_hat, "x_hat"), _rows(x, "x")
+    if x_hat.shape != x.shape:
+        raise RqHipError(f"shape mismatch {tuple(x_hat.shape)} vs {tuple(x.shape)}")
+    B, N = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().rqhip_recon_loss_forward(_ptr(x_hat), x_hat.stride(0), _ptr(x), x.stride(0), B, N, _ptr(out),
+                                                 _stream())
+        check(rc, "rqhip_recon_loss_forward")
+    return out
+
+
+def recon_loss_backward(x_hat: Tensor, x: Tensor, g_out: Tensor, need_hat: bool = True, need_x: bool = False):
+    _need_gpu(x_hat, x, g_out)
+    x_hat, x, g_out = _rows(x_hat, "x_hat"), _rows(x, "x"), _f32c(g_out, "g_out")
+    B, N = x.shape
+    with torch.cuda.device(x.device):
+        g_hat = torch.empty((B, N), dtype=torch.float32, device=x.device) if need_hat else None
+        g_x = torch.empty((B, N), dtype=torch.float32, device=x.device) if need_x else None
+        rc = _lib.lib().rqhip_recon_loss_backward(_ptr(x_hat), x_hat.stride(0), _ptr(x), x.stride(0), _ptr(g_out), B, N,
+                                                  _ptr(g_hat), _ptr(g_x), _stream())
+        check(rc, "rqhip_recon_loss_backward")
+    return g_hat, g_x

@@ -153,7 +153,7 @@ def train(
         codebook_normalize=vae_codebook_normalize, codebook_sim_vq=vae_sim_vq, codebook_mode=vae_codebook_mode,
         n_layers=vae_n_layers, n_cat_features=vae_n_cat_feats, commitment_weight=commitment_weight,
     ).to(device)
-    optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay)
+    optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay, fused=True)  # same update, one kernel
 
     use_wandb = wandb_logging and is_main and _HAVE_WANDB
     if wandb_logging and is_main and not _HAVE_WANDB:

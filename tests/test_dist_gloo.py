@@ -49,14 +49,19 @@ def _worker(rank, world, port, out):
     lo, hi = rqdist.shard_bounds(8)
     reducer.zero_()
     model(X[lo:hi]).pow(2).sum(dim=1).mean().backward()
-    reducer.check_attached()
     flat = reducer.allreduce_mean().clone()
     ref.zero_grad()
     ref(X).pow(2).sum(dim=1).mean().backward()
     want = torch.cat([p.grad.flatten() for p in ref.parameters()])
     assert torch.allclose(flat, want, rtol=1e-5, atol=1e-6), (flat - want).abs().max()
-    for p in model.parameters():   # .grad views see the reduced values: the optimizer needs no copy
+    for p in model.parameters():   # .grad are views of the reduced buffer: the optimizer needs no copy
         assert p.grad.untyped_storage().data_ptr() == reducer.flat.untyped_storage().data_ptr()
+    # a second step re-packs fresh gradients (zero_ drops the views, autograd assigns new tensors)
+    reducer.zero_()
+    assert all(p.grad is None for p in model.parameters())
+    model(X[lo:hi]).pow(2).sum(dim=1).mean().backward()
+    flat2 = reducer.allreduce_mean()
+    assert torch.allclose(flat2, want, rtol=1e-5, atol=1e-6)
 
     # ragged all-gather of id rows
     local = torch.arange(3 + rank).unsqueeze(1).repeat(1, 2) + 100 * rank

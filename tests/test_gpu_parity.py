@@ -264,3 +264,39 @@ def test_gumbel_unsupported_shape_fails_loudly():
     x, cb, U = _gumbel_inputs(8, 32, 4096, 0)
     with pytest.raises(RqHipError, match="Gumbel"):
         ops.gumbel_forward(_gpu(x), _gpu(cb), _gpu(U), 0.2, 0.25)
+
+
+# ---------------------------------------------------------------- reconstruction loss -----------------
+
+@pytest.mark.parametrize("B,N", [(1, 768), (100, 768), (333, 48), (50, 7), (64, 130), (4097, 64)])
+def test_recon_loss_forward_bitexact_backward_exact(B, N):
+    from rqhip import ops
+    rng = np.random.default_rng(B + N)
+    a = rng.standard_normal((B, N)).astype(np.float32)
+    b = rng.standard_normal((B, N)).astype(np.float32)
+    g = rng.random(B).astype(np.float32)
+    out = ops.recon_loss_forward(_gpu(a), _gpu(b)).cpu().numpy()
+    _assert_bitexact(out, o.recon_loss(a, b), "recon loss")
+    gh, gx = ops.recon_loss_backward(_gpu(a), _gpu(b), _gpu(g), True, True)
+    want = ((2.0 * (a - b)) * g[:, None]).astype(np.float32)
+    _assert_bitexact(gh.cpu().numpy(), want, "g_x_hat")
+    _assert_bitexact(gx.cpu().numpy(), -want, "g_x")
+
+
+def test_recon_loss_strided_views_and_autograd():
+    """CategoricalReconstuctionLoss hands column slices of wider matrices (loss.py:22-24): row stride > N."""
+    from modules.loss import CategoricalReconstuctionLoss, ReconstructionLoss
+    torch.manual_seed(0)
+    xh = torch.randn(70, 40, device="cuda", requires_grad=True)
+    x = torch.randn(70, 40, device="cuda")
+    x[:, -6:] = (x[:, -6:] > 0).float()
+    loss = CategoricalReconstuctionLoss(6)(xh, x)
+    ref = ((xh[:, :-6] - x[:, :-6]) ** 2).sum(-1) + torch.nn.functional.binary_cross_entropy_with_logits(
+        xh[:, -6:], x[:, -6:], reduction="none").sum(-1)
+    assert torch.allclose(loss, ref, rtol=1e-5, atol=1e-5)
+    loss.sum().backward()
+    g1 = xh.grad.clone()
+    xh.grad = None
+    ref.sum().backward()
+    assert torch.allclose(g1, xh.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ReconstructionLoss()(xh.detach(), x), ((xh.detach() - x) ** 2).sum(-1), rtol=1e-5)

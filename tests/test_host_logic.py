@@ -154,15 +154,13 @@ def test_device_batcher_epochs_cover_dataset():
     assert next(it).ids.numel() == 10                        # next epoch starts
 
 
-def test_losses_match_their_definitions():
+def test_quantize_loss_definition_and_gpu_only_recon_loss():
     from modules.loss import CategoricalReconstuctionLoss, QuantizeLoss, ReconstructionLoss
+    from rqhip import RqHipError
     a, b = torch.randn(5, 12), torch.randn(5, 12)
-    assert torch.allclose(ReconstructionLoss()(a, b), ((a - b) ** 2).sum(-1))
     ql = QuantizeLoss(0.25)(a, b)
     assert torch.allclose(ql, 1.25 * ((a - b) ** 2).sum(-1), rtol=1e-6)
-    tgt = b.clone()
-    tgt[:, -4:] = (tgt[:, -4:] > 0).float()
-    c = CategoricalReconstuctionLoss(4)(a, tgt)
-    ref = ((a[:, :-4] - tgt[:, :-4]) ** 2).sum(-1) + torch.nn.functional.binary_cross_entropy_with_logits(
-        a[:, -4:], tgt[:, -4:], reduction="none").sum(-1)
-    assert torch.allclose(c, ref)
+    with pytest.raises(RqHipError, match="no CPU fallback"):
+        ReconstructionLoss()(a, b)
+    with pytest.raises(RqHipError):
+        CategoricalReconstuctionLoss(4)(a, b)

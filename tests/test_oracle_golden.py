@@ -159,3 +159,12 @@ def test_argmin_semantics_ties_and_nan():
 def test_empty_batch():
     out = o.rq_forward(np.zeros((0, 8), np.float32), np.ones((2, 4, 8), np.float32), o.MODE_STE)
     assert out["ids"].shape == (2, 0) and out["loss"].shape == (0,)
+
+
+def test_recon_loss_oracle_matches_definition():
+    rng = np.random.default_rng(3)
+    for n in (768, 48, 7, 130):
+        a = rng.standard_normal((9, n)).astype(np.float32)
+        b = rng.standard_normal((9, n)).astype(np.float32)
+        ref = ((a.astype(np.float64) - b) ** 2).sum(-1)
+        np.testing.assert_allclose(o.recon_loss(a, b), ref, rtol=2e-6)
