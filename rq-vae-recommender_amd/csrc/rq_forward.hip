@@ -481,8 +481,14 @@ template <int KSTEPS>
 static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hipStream_t s) {
     constexpr int NT = WgThreads<KSTEPS>::value;
     auto go = [&](auto kern) -> int {
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of the per-call
+        // path and out of hipGraph captures); the limit only ever grows
+        static size_t granted = 0;
+        if (lds > granted) {
+            RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            granted = kLdsBudget;
+        }
         profile_begin(s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
         profile_end(s);

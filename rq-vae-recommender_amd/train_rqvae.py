@@ -14,7 +14,13 @@ What is MI355X-native about it:
   * the item-feature matrix is resident in HBM and batches are gathered on the device (data/processed.py),
     there is no host->device copy in the loop;
   * the progress-bar losses are read back every `log_every` steps instead of three `.cpu().item()` syncs
-    per step (train_rqvae.py:197-199).
+    per step (train_rqvae.py:197-199);
+  * at the reference's batch sizes (640 / 64 rows) a step is ~45 kernel launches of a few microseconds each, i.e.
+    launch-bound: with `use_hip_graph=True` (EXPERIMENTAL, off by default, single GPU) the whole step (forward,
+    HIP quantisation kernels, backward, fused AdamW) is captured once into a hipGraph and replayed on full-size
+    batches (0.99 -> 0.38 ms per step at batch 640 on MI355X in tools/bench_small_batch.py); epoch-tail batches
+    run eagerly.  Known issue: inside the full train() flow the first replay has faulted on ROCm 7.0/torch 2.10
+    (not reproduced in the stand-alone probes tools/graph_debug3.py) -- hence opt-in.
 wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
 """
 import os
@@ -89,6 +95,46 @@ def _id_diversity(tokenizer: SemanticIdTokenizer, index_dataset: ItemData, n_lay
     return log
 
 
+class _GraphedStep:
+    """One optimisation step captured into a hipGraph (torch.cuda.CUDAGraph) and replayed on a static batch."""
+
+    def __init__(self, model, optimizer, reducer, batch_size: int, feature_dim: int, device, gumbel_t: float) -> None:
+        self.x = torch.zeros((batch_size, feature_dim), device=device)
+        self.batch_size = batch_size
+        self.graph = None
+        self._model, self._opt, self._reducer, self._t = model, optimizer, reducer, gumbel_t
+        self.out = None
+
+    def _step(self):
+        from data.schemas import SeqBatch
+        self._reducer.zero_()
+        out = self._model(SeqBatch(None, None, None, self.x, None, None), gumbel_t=self._t)
+        out.loss.backward()
+        self._opt.step()
+        return out
+
+    def capture(self) -> None:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        self._reducer.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out = self._step()
+        # keep the static output buffers but not the captured step's autograd graph: its AccumulateGrad nodes are
+        # bound to the capture stream and would poison any later eager step (epoch-tail batches)
+        self.out = type(out)(*[v.detach() for v in out])
+        del out
+
+    def run(self, x: torch.Tensor):
+        self.x.copy_(x)
+        self.graph.replay()
+        return self.out
+
+
 @gin.configurable
 def train(
     iterations=50000,
@@ -121,6 +167,7 @@ def train(
     vae_n_layers=3,
     dataset_split="beauty",
     log_every=100,
+    use_hip_graph=False,
 ):
     params = dict(locals())
     del split_batches  # every rank always draws its own full batch (reference behaviour with a bare dataloader)
@@ -153,7 +200,9 @@ def train(
         codebook_normalize=vae_codebook_normalize, codebook_sim_vq=vae_sim_vq, codebook_mode=vae_codebook_mode,
         n_layers=vae_n_layers, n_cat_features=vae_n_cat_feats, commitment_weight=commitment_weight,
     ).to(device)
-    optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay, fused=True)  # same update, one kernel
+    graphable = bool(use_hip_graph) and gradient_accumulate_every == 1
+    optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay, fused=True,
+                      capturable=graphable)  # same update as the reference's AdamW, one multi-tensor kernel
 
     use_wandb = wandb_logging and is_main and _HAVE_WANDB
     if wandb_logging and is_main and not _HAVE_WANDB:
@@ -180,6 +229,10 @@ def train(
     tokenizer.rq_vae = model
 
     t = 0.2  # the reference's constant gumbel temperature (train_rqvae.py:177)
+    graphed = None
+    if graphable and world == 1:
+        graphed = _GraphedStep(model, optimizer, reducer, batch_size, vae_input_dim, device, t)
+    graph_after = start_iter + 3  # a few eager steps first (k-means init, allocator warm-up)
     window: List[torch.Tensor] = []
     shown = (float("nan"),) * 3
     t0 = time.time()
@@ -190,24 +243,36 @@ def train(
             # (train_rqvae.py:178-183); rank 0 computes, everyone receives
             if is_main:
                 warm = train_dataset[torch.arange(min(20000, len(train_dataset)))]
-                model(warm, t)
+                model(warm, t)  # output (and its autograd graph) dropped at once
             for layer in model.layers:
                 layer.kmeans_initted = True
             rqdist.broadcast_module(model)
 
-        reducer.zero_()
-        total_loss = 0
-        for _ in range(gradient_accumulate_every):
-            data = next(train_batches)
-            model_output = model(data, gumbel_t=t)
-            loss = model_output.loss / gradient_accumulate_every
-            loss.backward()
-            total_loss = total_loss + loss.detach()
-        reducer.allreduce_mean()
-        optimizer.step()
+        data = next(train_batches) if gradient_accumulate_every == 1 else None
+        if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
+            if graphed.graph is None:
+                graphed.capture()
+            model_output = graphed.run(data.x)
+            total_loss = model_output.loss.detach()
+        else:
+            reducer.zero_()
+            total_loss = 0
+            for _ in range(gradient_accumulate_every):
+                data = data if data is not None else next(train_batches)
+                model_output = model(data, gumbel_t=t)
+                loss = model_output.loss / gradient_accumulate_every
+                loss.backward()
+                total_loss = total_loss + loss.detach()
+                # keep only detached values: a live autograd graph from an eager step would pin AccumulateGrad
+                # nodes to the default stream and break the hipGraph capture of a later step
+                model_output = type(model_output)(*[v.detach() for v in model_output])
+                del loss
+                data = None
+            reducer.allreduce_mean()
+            optimizer.step()
 
         window.append(torch.stack([total_loss, model_output.reconstruction_loss.detach(),
-                                   model_output.rqvae_loss.detach()]))
+                                   model_output.rqvae_loss.detach()]))  # stack copies: safe with graph-static outputs
         window = window[-1000:]
         if it % log_every == 0:
             shown = tuple(torch.stack(window).mean(dim=0).tolist())  # the only host sync of a normal step
