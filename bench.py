@@ -122,7 +122,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ops.profile_read()
     ops.profile_enable(0)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -182,7 +182,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_rows)
         print(json.dumps(line))
     rqdist.barrier()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -30,7 +30,8 @@ def env_world() -> tuple[int, int, int]:
 def init_from_env(device_type: str = "cuda") -> tuple[int, int, int]:
     """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, local, world)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("RQ_FORCE_DIST") == "1"  # exercise the process-group path with a single rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = "nccl" if device_type == "cuda" else "gloo"
@@ -52,7 +53,7 @@ def get_rank() -> int:
 
 
 def barrier() -> None:
-    if world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
@@ -108,7 +109,7 @@ class FlatGradReducer:
     @torch.no_grad()
     def allreduce_mean(self) -> Tensor:
         w = world_size()
-        if w == 1:
+        if w == 1 and not (dist.is_available() and dist.is_initialized()):
             return self.flat
         grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
         torch.cat(grads, out=self.flat)
