@@ -138,6 +138,129 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
 }
 
 
+
+// ---- fused variant for L <= kFusedMaxL: rows + embedding backward in ONE kernel -------------------------------
+// Same arithmetic as rq_backward_kernel (g_res0 bit-identical), but the residual chain of a row stays in
+// registers (L * KSTEPS values per lane) and each row's codeword-gradient vectors go straight into the
+// workgroup's LDS tables: no [L,B,D] round trip through HBM.  Per row: reads res0, ids, upstream gradients
+// (12D + 8L bytes), writes g_res0 (4D) -- the algorithmic traffic of SURVEY.md 8d.
+constexpr int kFusedMaxL = 4;
+constexpr int kFusedThreads = 512;
+
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const RqBwdParams p, float *__restrict__ partial,
+                                                                         int LKD_total) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int D = p.D, L = p.L, K = p.K;
+    const int stride = D + 1;
+    const int tbl = L * K * stride;
+    if (p.g_cb)
+        for (int e = threadIdx.x; e < tbl; e += kFusedThreads) acc[e] = 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int il = lane & 31, h = lane >> 5;
+    constexpr int kWaves = kFusedThreads / 64;
+    const long long waves = (long long)gridDim.x * kWaves;
+    const long long gw = (long long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+
+    for (long long tile = gw; tile < p.n_tiles; tile += waves) {
+        const long long row = tile * 32 + il;
+        const bool ok = row < p.B;
+        const long long rc = ok ? row : p.B - 1;
+
+        float rl[kFusedMaxL][KSTEPS];
+        float e[KSTEPS], o[KSTEPS];
+        int idl[kFusedMaxL];
+        load_pair_row<KSTEPS>(p.res0 + (size_t)rc * D, D, h, rl[0]);
+#pragma unroll
+        for (int l = 0; l < kFusedMaxL; ++l) {
+            if (l < L) {
+                idl[l] = (int)p.ids[(size_t)l * p.B + rc];
+                if (l + 1 < L) {
+                    load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + idl[l]) * D, D, h, e);
+                    const float xsq = (MODE == RQHIP_MODE_ROTATION) ? pair_sumsq<KSTEPS>(rl[l]) : 0.0f;
+                    level_output<KSTEPS, MODE>(rl[l], e, xsq, o);
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk)
+                        if (l + 1 < kFusedMaxL) rl[(l + 1 < kFusedMaxL) ? l + 1 : 0][kk] = rl[l][kk] - o[kk];
+                }
+            }
+        }
+        const float gl = p.g_loss ? p.g_loss[rc] : 0.0f;
+        float G[KSTEPS], gs[KSTEPS];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            G[kk] = 0.0f;
+            const int d = 2 * kk + h;
+            gs[kk] = (p.g_embsum && d < D) ? p.g_embsum[(size_t)rc * D + d] : 0.0f;
+        }
+#pragma unroll
+        for (int l = kFusedMaxL - 1; l >= 0; --l) {
+            if (l < L) {
+                const float(&r)[KSTEPS] = rl[l];
+                load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + idl[l]) * D, D, h, e);
+                const size_t lrow = ((size_t)l * p.B + rc) * D;
+                float A[KSTEPS], gr[KSTEPS];
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const int d = 2 * kk + h;
+                    float a = 0.0f;
+                    if (p.g_embs && d < D) a = p.g_embs[lrow + d];
+                    if (p.g_embsum) a = a + gs[kk];
+                    A[kk] = a - G[kk];
+                    gr[kk] = (p.g_resid && d < D) ? p.g_resid[lrow + d] : 0.0f;
+                }
+                float *tab = acc + (size_t)(l * K + idl[l]) * stride + h;
+                if (MODE == RQHIP_MODE_ROTATION) {
+                    float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
+                    const float xsq = pair_sumsq<KSTEPS>(r);
+                    rotation_lane<KSTEPS>(r, e, xsq, o, w, u, q, scale);
+                    const float aw = pair_dot<KSTEPS>(A, w), aq = pair_dot<KSTEPS>(A, q);
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) {
+                        const float lin = ((A[kk] - 2.0f * (aw * w[kk])) + 2.0f * (aq * u[kk])) * scale;
+                        const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
+                        const float embg = (2.0f * (e[kk] - r[kk])) * gl;
+                        G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
+                        if (p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) {
+                        const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
+                        const float embg = (2.0f * (e[kk] - r[kk])) * gl;
+                        if (MODE == RQHIP_MODE_EVAL) {
+                            const float contrib = A[kk] + embg;
+                            G[kk] = (gr[kk] + G[kk]) + commit;
+                            if (p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, contrib);
+                        } else {
+                            G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
+                            if (p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                        }
+                    }
+                }
+            }
+        }
+        if (ok && p.g_res0) {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 2 * kk + h;
+                if (d < D) p.g_res0[(size_t)row * D + d] = G[kk];
+            }
+        }
+    }
+
+    if (p.g_cb) {
+        __syncthreads();
+        float *out = partial + (size_t)blockIdx.x * LKD_total;
+        for (int e2 = threadIdx.x; e2 < L * K * D; e2 += kFusedThreads) {
+            const int kd = e2 / D, dd = e2 - kd * D;
+            out[e2] = acc[(size_t)kd * stride + dd];
+        }
+    }
+}
+
 // ---- kernel 2: LDS-private scatter of V into per-workgroup codebook-gradient tables -----------------------
 // thread (rs, d): rs = row slot inside the workgroup's step, d = feature.  DR = D rounded up to a power of 2.
 __global__ __launch_bounds__(256) void rq_cbgrad_scatter_kernel(const float *__restrict__ V,
@@ -170,16 +293,38 @@ __global__ __launch_bounds__(256) void rq_cbgrad_scatter_kernel(const float *__r
 }
 
 // ---- kernel 3: fixed-order sum of the per-workgroup partials ------------------------------------------------
-__global__ void rq_cbgrad_reduce_kernel(const float *__restrict__ partial, int G, int n, float *__restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// 64 outputs per 256-thread block; thread (seg, j) sums partials g = seg, seg+4, ... in ascending order, the four
+// segment sums are combined as ((s0 + s1) + (s2 + s3)).
+__global__ __launch_bounds__(256) void rq_cbgrad_reduce_kernel(const float *__restrict__ partial, int G, int n,
+                                                               float *__restrict__ out) {
+    __shared__ float seg_sum[4][64];
+    const int jl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
     float s = 0.0f;
-    for (int g = 0; g < G; ++g) s = s + partial[(size_t)g * n + j];
-    out[j] = s;
+    if (j < n) {
+#pragma unroll 8
+        for (int g = seg; g < G; g += 4) s = s + partial[(size_t)g * n + j];
+    }
+    seg_sum[seg][jl] = s;
+    __syncthreads();
+    if (seg == 0 && j < n) out[j] = (seg_sum[0][jl] + seg_sum[1][jl]) + (seg_sum[2][jl] + seg_sum[3][jl]);
 }
 
 constexpr size_t kScatterLdsBudget = 150 * 1024;
 constexpr int kMaxScatterWgs = 128;
+
+static int fused_wgs(long long B) {
+    long long g = ((B + 31) / 32 + 7) / 8;
+    const long long cap = cu_count();
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// register budget: L * KSTEPS residual values per lane -> D <= 32 (KSTEPS <= 16) only
+static bool fused_fits(int D, int K, int L) {
+    return D <= 32 && L <= kFusedMaxL && (size_t)L * K * (D + 1) * sizeof(float) <= kScatterLdsBudget;
+}
 
 static int scatter_wgs(long long B) {
     long long g = (B + 255) / 256;
@@ -218,7 +363,8 @@ using namespace rqhip;
 extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K) {
     if (B <= 0 || D <= 0 || L <= 0 || K <= 0) return 16;
     const size_t rows = (size_t)L * (size_t)B * (size_t)D * sizeof(float);
-    const size_t partial = scatter_fits_lds(D, K) ? (size_t)scatter_wgs(B) * (size_t)L * K * D * sizeof(float) : 0;
+    const size_t g = fused_fits(D, K, L) ? (size_t)fused_wgs(B) : (size_t)scatter_wgs(B);
+    const size_t partial = scatter_fits_lds(D, K) ? g * (size_t)L * K * D * sizeof(float) : 0;
     return rows + partial;
 }
 
@@ -254,6 +400,41 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     p.ws = reinterpret_cast<float *>(workspace);
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.beta = beta;
     p.atomic_scatter = lds_path ? 0 : 1;
+    if (fused_fits(D, K, L)) {
+        const int G = fused_wgs(B);
+        const int LKD = L * K * D;
+        float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
+        const size_t lds = g_codebooks ? (size_t)L * K * (D + 1) * sizeof(float) : 0;
+        auto go = [&](auto kern) -> int {
+            static bool attr = false;
+            if (!attr) {
+                RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScatterLdsBudget));
+                attr = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD);
+            RQ_CHECK_LAUNCH("rq_backward_fused_kernel");
+            return 0;
+        };
+        int rcf = RQHIP_EARG;
+#define RQ_FUSED_MODES(KS)                                                                          \
+    switch (mode) {                                                                                 \
+        case RQHIP_MODE_EVAL: rcf = go(rq_backward_fused_kernel<KS, RQHIP_MODE_EVAL>); break;        \
+        case RQHIP_MODE_STE: rcf = go(rq_backward_fused_kernel<KS, RQHIP_MODE_STE>); break;          \
+        default: rcf = go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION>); break;                 \
+    }
+        switch (ksteps_for(D)) {
+            case 4: RQ_FUSED_MODES(4) break;
+            case 8: RQ_FUSED_MODES(8) break;
+            default: RQ_FUSED_MODES(16) break;
+        }
+#undef RQ_FUSED_MODES
+        if (rcf || !g_codebooks) return rcf;
+        hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD, g_codebooks);
+        RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+        return RQHIP_OK;
+    }
+
     long long want = (p.n_tiles + 3) / 4;
     long long cap = (long long)cu_count() * 8;
     const int grid = (int)(want < cap ? want : cap);
@@ -289,7 +470,7 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
                            D, DR, K, l0, nl, rows_per_wg, partial, LKD);
         RQ_CHECK_LAUNCH("rq_cbgrad_scatter_kernel");
     }
-    hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 255) / 256), dim3(256), 0, s, partial, G, LKD, g_codebooks);
+    hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD, g_codebooks);
     RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
     return RQHIP_OK;
 }

@@ -104,28 +104,35 @@ def test_forward_vs_reference_golden(name):
     np.testing.assert_allclose(got["embs"][0], g["embeddings"], rtol=1e-5, atol=2e-6)
 
 
-def test_forward_full_size_properties():
-    """BASELINE config 2 size (100k x 32-d latents, 3 x 256): properties that do not need the oracle at
-    full size -- decode(ids) reproduces embs, residual chain closes, loss == (1+beta)*|res-emb|^2 -- plus
-    an oracle check on a random 2k-row subsample."""
+@pytest.mark.parametrize("B,D,K,L,mode", [(100_000, 32, 256, 3, 0), (100_000, 32, 256, 3, 1),
+                                          (262_144, 32, 1024, 4, 0), (131_072, 64, 256, 3, 2)])
+def test_forward_full_size_properties(B, D, K, L, mode):
+    """BASELINE config 2 (100k rows, 3 x 256), a config-4 shard (4 x 1024, LDS streaming mode) and the ml32m width
+    at full size: properties that do not need the oracle on every row -- ids in range, decode(ids) reproduces the
+    codewords, the residual chain closes, emb_sum is the level sum -- plus the oracle on a random 2k-row subsample."""
     from rqhip import ops
     g = torch.Generator().manual_seed(1234)
-    B, D, K, L = 100_000, 32, 256, 3
     x = torch.randn(B, D, generator=g) * 0.5
-    cbs = torch.randn(L, K, D, generator=g) * torch.tensor([0.5, 0.25, 0.12])[:, None, None]
-    out = ops.rq_forward(x.cuda(), cbs.cuda(), 0, 0.25)
+    cbs = torch.randn(L, K, D, generator=g) * torch.tensor([0.5 / (l + 1) for l in range(L)])[:, None, None]
+    out = ops.rq_forward(x.cuda(), cbs.cuda(), mode, 0.25)
     ids = out.ids.cpu()
     assert ids.min() >= 0 and ids.max() < K
-    dec = torch.stack([cbs[l][ids[l]] for l in range(L)])
-    assert torch.equal(dec, out.embs.cpu())
-    res = out.residuals.cpu()
+    embs, res = out.embs.cpu(), out.residuals.cpu()
     assert torch.equal(res[0], x)
     for l in range(L - 1):
-        assert torch.equal(res[l + 1], res[l] - dec[l])
+        assert torch.equal(res[l + 1], res[l] - embs[l])            # rqvae.py:130, bit for bit
+    if mode == 0:
+        dec = torch.stack([cbs[l][ids[l]] for l in range(L)])
+        assert torch.equal(dec, embs)                               # eval: emb_out is the codeword itself
+    acc = embs[0].clone()
+    for l in range(1, L):
+        acc = acc + embs[l]
+    assert torch.equal(acc, out.emb_sum.cpu())
     sel = torch.randperm(B, generator=g)[:2000]
-    ref = o.rq_forward(x[sel].numpy(), cbs.numpy(), 0, 0.25)
+    ref = o.rq_forward(x[sel].numpy(), cbs.numpy(), mode, 0.25)
     assert np.array_equal(ref["ids"], ids[:, sel].numpy())
     _assert_bitexact(out.loss.cpu().numpy()[sel.numpy()], ref["loss"], "loss subsample")
+    _assert_bitexact(out.embs_norm.cpu().numpy()[sel.numpy()], ref["embs_norm"], "norm subsample")
 
 
 # ---------------------------------------------------------------- backward ---------------------------
