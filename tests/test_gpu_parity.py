@@ -307,3 +307,67 @@ def test_recon_loss_strided_views_and_autograd():
     ref.sum().backward()
     assert torch.allclose(g1, xh.grad, rtol=1e-5, atol=1e-6)
     assert torch.allclose(ReconstructionLoss()(xh.detach(), x), ((xh.detach() - x) ** 2).sum(-1), rtol=1e-5)
+
+
+# ---------------------------------------------------------------- property tests ----------------------
+
+def test_forward_property_random_shapes_and_special_values():
+    """Randomised (hypothesis) shapes and adversarial values -- duplicated codes, exact hits, zeros, huge and tiny
+    magnitudes, NaN/Inf sprinkled into rows and codes -- all outputs bit-exact vs the oracle in every mode."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(B=st.integers(1, 200), D=st.sampled_from([1, 3, 8, 16, 24, 32, 33, 64, 100, 128]),
+           K=st.sampled_from([1, 2, 5, 31, 32, 33, 64, 100, 256, 300]), L=st.integers(1, 5), mode=st.integers(0, 2),
+           seed=st.integers(0, 2 ** 16), flavour=st.sampled_from(["normal", "dups", "tiny", "huge", "special", "zeros"]))
+    def run(B, D, K, L, mode, seed, flavour):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((B, D)).astype(np.float32)
+        cbs = rng.standard_normal((L, K, D)).astype(np.float32) * 0.5
+        if flavour == "dups" and K > 1:
+            cbs[:, K - 1] = cbs[:, 0]
+            x[0] = cbs[0, 0]
+            if B > 1:
+                x[1] = 0.5 * (cbs[0, 0] + cbs[0, min(1, K - 1)])      # equidistant in exact arithmetic
+        elif flavour == "tiny":
+            x *= 1e-20
+            cbs *= 1e-19
+        elif flavour == "huge":
+            x *= 3e18
+            cbs[0] *= 1e18
+        elif flavour == "zeros":
+            x[:] = 0
+            cbs[:, ::2] = 0
+        elif flavour == "special":
+            x[rng.integers(0, B), rng.integers(0, D)] = np.nan
+            x[rng.integers(0, B), rng.integers(0, D)] = np.inf
+            cbs[rng.integers(0, L), rng.integers(0, K), rng.integers(0, D)] = -np.inf if seed % 2 else np.nan
+        _check_forward(x, cbs, mode)
+
+    run()
+
+
+def test_backward_property_random_shapes():
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(B=st.integers(1, 300), D=st.sampled_from([3, 8, 16, 32, 33, 64]), K=st.sampled_from([2, 31, 64, 256, 1100]),
+           L=st.integers(1, 6), mode=st.integers(0, 2), seed=st.integers(0, 2 ** 16))
+    def run(B, D, K, L, mode, seed):
+        rng = np.random.default_rng(seed)
+        x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
+        cbs = (rng.standard_normal((L, K, D)) * 0.4).astype(np.float32)
+        ref = o.rq_forward(x, cbs, mode, 0.25)
+        g = dict(g_embs=rng.standard_normal((L, B, D)).astype(np.float32) if seed % 2 else None,
+                 g_embsum=rng.standard_normal((B, D)).astype(np.float32),
+                 g_resid=rng.standard_normal((L, B, D)).astype(np.float32) if seed % 3 == 0 else None,
+                 g_loss=rng.random(B).astype(np.float32))
+        r_res0, r_cb = o.rq_backward(x, cbs, mode, 0.25, ref["ids"], **g)
+        g_res0, g_cb = _run_backward(x, cbs, mode, 0.25, ref["ids"], **g)
+        _assert_bitexact(g_res0, r_res0, f"g_res0 B={B} D={D} K={K} L={L} mode={mode}")
+        scale = max(1e-6, float(np.abs(r_cb).max()))
+        np.testing.assert_allclose(g_cb, r_cb, rtol=1e-4, atol=3e-6 * scale)
+
+    run()
