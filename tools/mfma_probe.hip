@@ -48,6 +48,39 @@ __global__ __launch_bounds__(512) void probe(float *out, int iters, unsigned lon
                 float d = (a + j) - acc[j];
                 if (d < best) { best = d; bidx = it * 16 + j; }
             }
+        } else if (VARIANT == 5) {  // TWO tiles per iteration: chains alternate A,B (independent accumulators), then
+                                    // both epilogues -- no instruction sits between two MFMAs on one accumulator
+            f32x16 ca = {0}, cb = {0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                ca = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b + k, ca, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a + k, cb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float d = (a + j) - ca[j];
+                if (d < best) { best = d; bidx = it * 32 + j; }
+                float e = (b + j) - cb[j];
+                if (e < best) { best = e; bidx = it * 32 + 16 + j; }
+            }
+        } else if (VARIANT == 6) {  // as 5, but the epilogue of the PREVIOUS pair is interleaved between the
+                                    // alternating MFMAs of this pair (distance between dependent MFMAs = 2)
+            f32x16 ca = {0}, cb = {0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                ca = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b + k, ca, 0, 0, 0);
+                {
+                    float d = (a + k) - acc0[k];
+                    if (d < best) { best = d; bidx = it * 32 + k; }
+                }
+                cb = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a + k, cb, 0, 0, 0);
+                {
+                    float e = (b + k) - acc1[k];
+                    if (e < best) { best = e; bidx = it * 32 + 16 + k; }
+                }
+            }
+            acc0 = ca;
+            acc1 = cb;
         } else if (VARIANT == 4) {  // same work, software pipelined: chain(it+1) interleaved with epilogue(it)
             f32x16 acc = {0};
 #pragma unroll
@@ -84,7 +117,7 @@ void run(const char *name, int threads, int iters) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
-    const double mfma = (double)iters * 16;
+    const double mfma = (double)iters * 16 * (VARIANT >= 5 ? 2 : 1);
     const int waves_per_simd = threads / 256;
     printf("%-34s waves/SIMD %d: %8.1f us  memtime %10llu ticks  %7.1f ticks/MFMA/wave  wall-ns/MFMA/SIMD %6.2f  "
            "=> %6.1f TFLOP/s\n",
@@ -102,6 +135,8 @@ int main() {
         run<2>("16 dependent, LDS operands", threads, iters);
         run<3>("chain + epilogue (serial)", threads, iters);
         run<4>("chain || epilogue (pipelined)", threads, iters);
+        run<5>("2 tiles: AB chains, then epilogues", threads, iters / 2);
+        run<6>("2 tiles: AB chains || prev epilogues", threads, iters / 2);
     }
     return 0;
 }
