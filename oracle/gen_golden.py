@@ -84,6 +84,32 @@ def gen_quantize(q):
                 grad_codebook=np32(layer.embedding.weight.grad))
 
 
+def gen_cosine(q):
+    """QuantizeDistance.COSINE (quantize.py:118-124) -- never selected by RqVae, kept for API parity."""
+    for tag, B, D, K, seed, fm, training in (("a", 60, 32, 64, 61, q.QuantizeForwardMode.STE, True),
+                                             ("b", 40, 16, 32, 62, q.QuantizeForwardMode.ROTATION_TRICK, True),
+                                             ("c", 33, 24, 20, 63, q.QuantizeForwardMode.STE, False)):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, D, generator=g)
+        cb = torch.randn(K, D, generator=g) * torch.rand(K, 1, generator=g).add(0.2)   # varied code norms
+        layer = q.Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=fm,
+                           distance_mode=q.QuantizeDistance.COSINE, commitment_weight=0.25)
+        with torch.no_grad():
+            layer.embedding.weight.copy_(cb)
+        layer.train(training)
+        xr = x.clone().requires_grad_(True)
+        out = layer(xr, temperature=0.2)
+        g_emb = torch.randn(B, D, generator=g)
+        g_loss = torch.rand(B, generator=g)
+        (out.embeddings * g_emb).sum().add((out.loss * g_loss).sum()).backward()
+        np.savez_compressed(
+            os.path.join(OUT, f"cosine_{tag}.npz"), x=np32(x), codebook=np32(cb), training=np.bool_(training),
+            rotation=np.bool_(fm == q.QuantizeForwardMode.ROTATION_TRICK),
+            ids=out.ids.numpy().astype(np.int64), embeddings=np32(out.embeddings), loss=np32(out.loss),
+            g_emb=np32(g_emb), g_loss=np32(g_loss), grad_x=np32(xr.grad),
+            grad_codebook=np32(layer.embedding.weight.grad))
+
+
 def gen_gumbel(q):
     """Training-mode GUMBEL_SOFTMAX level (quantize.py:131-136; gumbel.py:8-20).  The uniform noise the
     reference drew is recovered by re-seeding and calling torch.rand with the same shape."""
@@ -236,6 +262,7 @@ def main():
     q, r, km, sem, sch = import_reference()
     gen_quantize(q)
     gen_gumbel(q)
+    gen_cosine(q)
     gen_rqvae(q, r, sch)
     gen_kmeans(km)
     gen_dedup(q, r, sem, sch)

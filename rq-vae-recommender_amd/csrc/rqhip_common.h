@@ -45,9 +45,6 @@ int cu_count();
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
 
-// torch.min(dim) update rule (ATen compare kernel): take v when !(v >= best); a NaN, once taken, stays.
-__device__ __forceinline__ bool torch_min_takes(float v, float best) { return !(v >= best); }
-
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ int shfl_xor32(int v) { return __shfl_xor(v, 32, 64); }
 

@@ -125,14 +125,38 @@ class Quantize(nn.Module):
     def get_item_embeddings(self, item_ids: Tensor) -> Tensor:
         return self.out_proj(self.embedding(item_ids))
 
+    def _forward_cosine(self, x: Tensor) -> QuantizeOutput:
+        """QuantizeDistance.COSINE (reference quantize.py:118-124; RqVae never selects it).  The argmin of
+        -(x/|x|).c_k/|c_k| runs on the HIP kernel as the nearest unit codeword of the unit query (for unit vectors
+        |a-b|^2 = 2 - 2 a.b, the same ordering); everything after the ids -- gather, STE / rotation output, loss --
+        is the reference's expression in PyTorch-ROCm ops, differentiated by autograd."""
+        if self.training and self.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
+            raise NotImplementedError("COSINE distance with GUMBEL_SOFTMAX has no accelerated path")
+        codebook = self.codebook()
+        with torch.no_grad():
+            xn = x / x.norm(dim=1, keepdim=True)
+            cn = codebook / codebook.norm(dim=1, keepdim=True)
+            ids = RqStackFunction.apply(xn, cn.unsqueeze(0), MODE_EVAL, 0.0, False)[2][0]
+        emb = self.get_item_embeddings(ids)
+        if not self.training:
+            return QuantizeOutput(embeddings=emb, ids=ids, loss=self.quantize_loss(query=x, value=emb))
+        if self.forward_mode == QuantizeForwardMode.STE:
+            emb_out = x + (emb - x).detach()
+        elif self.forward_mode == QuantizeForwardMode.ROTATION_TRICK:
+            rot = efficient_rotation_trick_transform(x / (x.norm(dim=-1, keepdim=True) + 1e-8),
+                                                     emb / (emb.norm(dim=-1, keepdim=True) + 1e-8), x)
+            emb_out = rot * (emb.norm(dim=1, keepdim=True) / (x.norm(dim=1, keepdim=True) + 1e-6)).detach()
+        else:
+            raise Exception("Unsupported Quantize forward mode.")
+        return QuantizeOutput(embeddings=emb_out, ids=ids, loss=self.quantize_loss(query=x, value=emb))
+
     def forward(self, x: Tensor, temperature: float) -> QuantizeOutput:
         assert x.shape[-1] == self.embed_dim
         if self.do_kmeans_init and not self.kmeans_initted:
             self._kmeans_init(x=x)
+        if self.distance_mode == QuantizeDistance.COSINE:
+            return self._forward_cosine(x)
         if self.distance_mode != QuantizeDistance.L2:
-            if self.distance_mode == QuantizeDistance.COSINE:
-                raise NotImplementedError(
-                    "QuantizeDistance.COSINE has no HIP kernel yet (RqVae never selects it; see DESIGN.md)")
             raise Exception("Unsupported Quantize distance mode.")
 
         codebook = self.codebook()

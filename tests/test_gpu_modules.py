@@ -212,3 +212,24 @@ def test_rqvae_gumbel_training_step_runs_level_by_level():
     assert m._can_fuse()
     sem = m.get_semantic_ids(x)
     assert sem.sem_ids.shape == (200, 3)
+
+
+@pytest.mark.parametrize("name", ["cosine_a.npz", "cosine_b.npz", "cosine_c.npz"])
+def test_quantize_module_cosine_distance(name):
+    """QuantizeDistance.COSINE (quantize.py:118-124): ids exact vs the reference, outputs and gradients close."""
+    from modules.quantize import Quantize, QuantizeDistance, QuantizeForwardMode
+    g = load_golden(name)
+    K, D = g["codebook"].shape
+    fm = QuantizeForwardMode.ROTATION_TRICK if bool(g["rotation"]) else QuantizeForwardMode.STE
+    q = Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=fm, distance_mode=QuantizeDistance.COSINE).cuda()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(g["codebook"]))
+    q.train(bool(g["training"]))
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    out = q(x, temperature=0.2)
+    assert np.array_equal(out.ids.cpu().numpy(), g["ids"])
+    np.testing.assert_allclose(out.embeddings.detach().cpu().numpy(), g["embeddings"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out.loss.detach().cpu().numpy(), g["loss"], rtol=2e-6, atol=1e-5)
+    ((out.embeddings * torch.from_numpy(g["g_emb"]).cuda()).sum() + (out.loss * torch.from_numpy(g["g_loss"]).cuda()).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(q.embedding.weight.grad.cpu().numpy(), g["grad_codebook"], rtol=2e-5, atol=2e-5)

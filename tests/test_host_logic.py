@@ -119,8 +119,10 @@ def test_quantize_asserts_and_unsupported_modes():
     q = Quantize(embed_dim=8, n_embed=4, do_kmeans_init=False, forward_mode=QuantizeForwardMode.STE)
     with pytest.raises(AssertionError):
         q(torch.randn(3, 7), temperature=0.2)
-    qc = Quantize(embed_dim=8, n_embed=4, do_kmeans_init=False, distance_mode=QuantizeDistance.COSINE)
-    with pytest.raises(NotImplementedError):
+    from rqhip import RqHipError
+    qc = Quantize(embed_dim=8, n_embed=4, do_kmeans_init=False, distance_mode=QuantizeDistance.COSINE,
+                  forward_mode=QuantizeForwardMode.STE)
+    with pytest.raises(RqHipError):          # implemented, but GPU only like everything else
         qc(torch.randn(3, 8), temperature=0.2)
 
 

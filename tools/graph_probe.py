@@ -1,3 +1,5 @@
+"""Developer probe: the train_rqvae step flow (k-means warm-up, eager steps, hipGraph capture, mixed eager/graph
+replays incl. epoch-tail batches) outside train(); works stand-alone, see the note in train_rqvae.py."""
 import os, sys, faulthandler, warnings
 faulthandler.enable(); faulthandler.dump_traceback_later(30, exit=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
