@@ -17,10 +17,10 @@ What is MI355X-native about it:
     per step (train_rqvae.py:197-199);
   * at the reference's batch sizes (640 / 64 rows) a step is ~45 kernel launches of a few microseconds each, i.e.
     launch-bound: with `use_hip_graph=True` (EXPERIMENTAL, off by default, single GPU) the whole step (forward,
-    HIP quantisation kernels, backward, fused AdamW) is captured once into a hipGraph and replayed on full-size
-    batches (0.99 -> 0.38 ms per step at batch 640 on MI355X in tools/bench_small_batch.py); epoch-tail batches
-    run eagerly.  Known issue: inside the full train() flow the first replay has faulted on ROCm 7.0/torch 2.10
-    (not reproduced in the stand-alone probes tools/graph_debug3.py) -- hence opt-in.
+    HIP quantisation kernels, backward, fused AdamW) is captured into a hipGraph and replayed on full-size batches
+    (0.99 -> 0.38 ms per step at batch 640 on MI355X in tools/bench_small_batch.py); epoch-tail batches are
+    skipped, and the graph is re-captured after every eval / tokenisation / checkpoint excursion because replaying
+    across eager GEMMs of new shapes faulted (rocBLAS moves its workspace) -- hence opt-in.
 wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
 """
 import os
@@ -107,9 +107,14 @@ class _GraphedStep:
 
     def _step(self):
         from data.schemas import SeqBatch
+        part = os.environ.get("RQ_GRAPH_PART", "all")  # debugging aid: capture only a prefix of the step
         self._reducer.zero_()
         out = self._model(SeqBatch(None, None, None, self.x, None, None), gumbel_t=self._t)
+        if part == "fwd":
+            return out
         out.loss.backward()
+        if part == "fwdbwd":
+            return out
         self._opt.step()
         return out
 
@@ -133,6 +138,14 @@ class _GraphedStep:
         self.x.copy_(x)
         self.graph.replay()
         return self.out
+
+    def invalidate(self) -> None:
+        """Drop the captured graph; the next full-size step captures a fresh one.  Called after every eager
+        excursion (eval pass, corpus tokenisation, checkpoint): library GEMM workspaces (rocBLAS reallocates its
+        device memory when a new shape needs more) and other lazily created state may have moved under the
+        captured kernels -- replaying across such an excursion faulted or hung on ROCm 7.0."""
+        self.graph = None
+        self.out = None
 
 
 @gin.configurable
@@ -249,6 +262,9 @@ def train(
             rqdist.broadcast_module(model)
 
         data = next(train_batches) if gradient_accumulate_every == 1 else None
+        if graphed is not None and it >= graph_after:
+            while data.x.shape[0] != batch_size:   # graph mode trains on full batches only: epoch tails are skipped
+                data = next(train_batches)
         if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
             if graphed.graph is None:
                 graphed.capture()
@@ -309,6 +325,10 @@ def train(
             os.makedirs(save_dir_root, exist_ok=True)
             torch.save({"iter": it, "model": model.state_dict(), "model_config": model.config,
                         "optimizer": optimizer.state_dict()}, save_dir_root + f"checkpoint_{it}.pt")
+
+        if graphed is not None and ((do_eval and ((it + 1) % eval_every == 0 or last)) or (it + 1) % eval_every == 0
+                                    or last or (it + 1) % save_model_every == 0):
+            graphed.invalidate()
 
         if is_main and log:
             if use_wandb:

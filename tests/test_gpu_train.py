@@ -58,15 +58,15 @@ def test_train_ml32m_hyperparameters_rotation_trick(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join(out_dir, "checkpoint_9.pt"))
 
 
-@pytest.mark.skipif(os.environ.get("RQ_TEST_HIP_GRAPH") != "1", reason="experimental opt-in path (see train_rqvae docstring)")
 def test_hip_graph_step_matches_eager(tmp_path, monkeypatch):
-    """use_hip_graph=True replays the captured step; the loss trajectory equals eager training."""
+    """use_hip_graph=True (opt-in) replays the captured step, re-capturing after eval / tokenisation / checkpoint
+    excursions; the loss stays on the eager trajectory (graph mode skips epoch-tail batches, so not bit-equal)."""
     import numpy as np
     runs = []
     for flag in (False, True):
         torch.manual_seed(7)
         np.random.seed(7)
-        res, _ = _run("rqvae_amazon.gin", tmp_path, monkeypatch, iterations=40, eval_every=1000, save_model_every=1000,
-                      do_eval=False, log_every=1, use_hip_graph=flag, batch_size=500)
+        res, _ = _run("rqvae_amazon.gin", tmp_path, monkeypatch, iterations=40, eval_every=16, save_model_every=1000,
+                      do_eval=True, log_every=1, use_hip_graph=flag, batch_size=500)
         runs.append(res)
     assert abs(runs[0]["loss"] - runs[1]["loss"]) < 2e-3 * max(1.0, abs(runs[0]["loss"])), runs
