@@ -29,13 +29,17 @@ def enable_tuned_gemms(verbose: bool = False) -> bool:
     tune_now = os.environ.get("RQ_TUNE_GEMMS") == "1"
     if not tune_now and not os.path.exists(TUNING_FILE):
         return False
-    out = os.environ.get("RQ_TUNE_GEMMS_OUT", TUNING_FILE)
     tunable.enable(True)
-    tunable.set_filename(out if tune_now else TUNING_FILE)
     tunable.tuning_enable(tune_now)
     if tune_now:
+        # results are (re)written to this file when the process exits
+        tunable.set_filename(os.environ.get("RQ_TUNE_GEMMS_OUT", TUNING_FILE))
         tunable.set_max_tuning_duration(int(os.environ.get("RQ_TUNE_MS", "30")))
         tunable.set_max_tuning_iterations(100)
+    else:
+        # read-only use: keep TunableOp's output name away from the committed file (N ranks of one job would
+        # otherwise all rewrite it at exit)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rq_tunableop_unused_{os.getpid()}.csv"))
     if os.path.exists(TUNING_FILE):
         ok = tunable.read_file(TUNING_FILE)
         if verbose:
