@@ -152,6 +152,12 @@ def gen_rqvae(q, r, sch):
                           n_cat_features=0), q.QuantizeForwardMode.STE, 200, 33),
         ("cat_ste", dict(input_dim=40, embed_dim=8, hidden_dims=[24], codebook_size=16, n_layers=2,
                          n_cat_features=6), q.QuantizeForwardMode.STE, 64, 34),
+        # the two codebook options of train(): vae_codebook_normalize (level-0 codebook + encoder output L2-normalised,
+        # rqvae.py:71,83) and vae_sim_vq (a DxD linear on every codebook, quantize.py:76)
+        ("norm_ste", dict(input_dim=40, embed_dim=16, hidden_dims=[24], codebook_size=32, n_layers=3,
+                          n_cat_features=0, codebook_normalize=True), q.QuantizeForwardMode.STE, 72, 35),
+        ("simvq_rot", dict(input_dim=40, embed_dim=16, hidden_dims=[24], codebook_size=32, n_layers=2,
+                           n_cat_features=0, codebook_sim_vq=True), q.QuantizeForwardMode.ROTATION_TRICK, 72, 36),
     ]
     for tag, kw, mode, B, seed in cfgs:
         torch.manual_seed(seed)

@@ -17,6 +17,10 @@ RQVAE_CFG = {
     "small_rot": dict(input_dim=48, embed_dim=16, hidden_dims=[32, 24], codebook_size=32, n_layers=3, n_cat_features=0),
     "wide_ste": dict(input_dim=64, embed_dim=32, hidden_dims=[48], codebook_size=256, n_layers=4, n_cat_features=0),
     "cat_ste": dict(input_dim=40, embed_dim=8, hidden_dims=[24], codebook_size=16, n_layers=2, n_cat_features=6),
+    "norm_ste": dict(input_dim=40, embed_dim=16, hidden_dims=[24], codebook_size=32, n_layers=3, n_cat_features=0,
+                     codebook_normalize=True),
+    "simvq_rot": dict(input_dim=40, embed_dim=16, hidden_dims=[24], codebook_size=32, n_layers=2, n_cat_features=0,
+                      codebook_sim_vq=True),
 }
 
 

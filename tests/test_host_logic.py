@@ -166,3 +166,16 @@ def test_quantize_loss_definition_and_gpu_only_recon_loss():
         ReconstructionLoss()(a, b)
     with pytest.raises(RqHipError):
         CategoricalReconstuctionLoss(4)(a, b)
+
+
+def test_entry_point_fails_loudly_without_gpu():
+    """`python train_rqvae.py <cfg.gin>` (BASELINE config 1, plumbing): config parsing, enum constants and the
+    train() binding work on a CPU-only box; the run itself stops with a clear error, not a silent CPU fallback."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_train.py")
+    proc = subprocess.run([sys.executable, os.path.join(PKG, "train_rqvae.py"), os.path.join(PKG, "configs", "rqvae_amazon.gin")],
+                          cwd=PKG, capture_output=True, text=True, timeout=300)
+    assert proc.returncode != 0
+    assert "needs a ROCm GPU" in proc.stderr
