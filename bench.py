@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=8192)
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its communicator is
+    # created, so every library's chatter is sent to stderr: fd 1 is parked and only the JSON line goes to it.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     from rqhip import dist as rqdist
     from rqhip import ops, tuning
     from data.schemas import SeqBatch
@@ -145,6 +151,27 @@ def main():
     _, bwd_ms = timed(lambda: out.loss.backward())
     _, opt_ms = timed(lambda: opt.step())
 
+    # secondary scopes of SURVEY.md 8d (untimed region, 10 repetitions each): S-rq = the quantisation stack alone
+    # (HIP forward + HIP backward on the 32-d latents), and tokenisation only (encoder + RQ, eval mode)
+    cbs = torch.stack([l.weight for l in model.layers]).detach()
+    lat = res0.detach()
+    g_sum = torch.randn_like(lat)
+    g_l = torch.full((B,), 1.0 / B, device=device)
+
+    def rq_fwd_bwd():
+        o = ops.rq_forward(lat, cbs, 1, BETA, want_embs=False, want_residuals=False)
+        ops.rq_backward(lat, cbs, 1, BETA, o.ids, g_embsum=g_sum, g_loss=g_l)
+
+    def reps(fn, n=10):
+        fn()
+        return timed(lambda: [fn() for _ in range(n)])[1] / n
+
+    srq_ms = reps(rq_fwd_bwd)
+    model.eval()
+    with torch.no_grad():
+        tok_ms = reps(lambda: model.get_semantic_ids(X))
+    model.train()
+
     if rank == 0:
         items = B * world * args.steps
         value = items / elapsed
@@ -175,12 +202,17 @@ def main():
             "breakdown_ms": {"encoder_fwd": round(enc_ms, 3), "rq_forward_call": round(rq_ms, 3),
                              "model_fwd_total": round(fwd_ms, 3), "backward_total": round(bwd_ms, 3),
                              "adamw": round(opt_ms, 3), "kmeans_init_warmup_s": round(kmeans_s, 3)},
+            "secondary": {"s_rq_items_per_s": round(B / srq_ms * 1e3, 1), "s_rq_ms_fwd_bwd": round(srq_ms, 4),
+                          "tokenize_items_per_s": round(B / tok_ms * 1e3, 1), "tokenize_ms": round(tok_ms, 4),
+                          "note": "per GPU; S-rq = HIP quantisation stack fwd+bwd on 32-d latents, tokenize = "
+                                  "get_semantic_ids (encoder GEMMs + HIP RQ, eval)"},
             "mlp_gemms": "PyTorch-ROCm fp32 (matmul precision highest), TunableOp selections " + ("loaded" if tuned else "off"),
             "final_loss": round(float(out.loss.detach()), 6), "p_unique_ids": round(float(out.p_unique_ids), 6),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_rows)
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     rqdist.barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
