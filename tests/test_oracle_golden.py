@@ -173,3 +173,27 @@ def test_recon_loss_oracle_matches_definition():
         b = rng.standard_normal((9, n)).astype(np.float32)
         ref = ((a.astype(np.float64) - b) ** 2).sum(-1)
         np.testing.assert_allclose(o.recon_loss(a, b), ref, rtol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["rqvae_small_ste.npz", "rqvae_wide_ste.npz"])
+def test_torch_port_cpu_baseline_program_matches_reference(name):
+    """oracle/torch_port.py (what bench.py times as cpu_baseline) computes the reference's training loss and
+    gradients: same weights and batch as the golden fixture -> same loss, reconstruction part and grads."""
+    import torch
+    from oracle import torch_port
+    g = load_golden(name)
+    enc = sorted(k for k in g if k.startswith("param::encoder"))
+    dec = sorted(k for k in g if k.startswith("param::decoder"))
+    m = torch_port.PortModel(input_dim=g["x"].shape[1], hidden=[g[k].shape[0] for k in enc[:-1]],
+                             embed_dim=g[enc[-1]].shape[0], n_levels=_codebooks(g).shape[0],
+                             codebook_size=_codebooks(g).shape[1], beta=float(g["beta"]))
+    m.enc = [torch.tensor(g[k]).requires_grad_(True) for k in enc]
+    m.dec = [torch.tensor(g[k]).requires_grad_(True) for k in dec]
+    m.codebooks = [torch.tensor(c).requires_grad_(True) for c in _codebooks(g)]
+    loss, p_unique = m.step_loss(torch.tensor(g["x"]), stat_rows=g["x"].shape[0])
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g["train_loss"]), rtol=1e-6, atol=1e-5)
+    assert abs(float(p_unique) - float(g["train_p_unique_ids"])) < 1e-7
+    for l, c in enumerate(m.codebooks):
+        np.testing.assert_allclose(c.grad.numpy(), g[f"train_grad::layers.{l}.embedding.weight"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(m.enc[0].grad.numpy(), g["train_grad::" + enc[0][len("param::"):]], rtol=1e-4, atol=1e-7)
