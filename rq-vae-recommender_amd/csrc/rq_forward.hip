@@ -18,8 +18,10 @@
 //   * codebooks are staged in LDS, permuted to [d-quad q][parity h][code c][4] so that a lane's A operands
 //     for four consecutive MFMAs are one conflict-free ds_read_b128.  All L levels stay resident when
 //     they fit in the 160 KiB LDS (3 x 256 x 32: 99 KiB); otherwise one chunk of one level at a time.
-//   * 512-thread workgroups = 2 waves per SIMD: one wave's VALU epilogue (16 distances per lane per
-//     tile) overlaps the other wave's MFMAs.
+//   * 768-thread workgroups = 3 waves per SIMD (512 / 256 threads for D = 64 / 128): one wave's VALU epilogue (16
+//     distances per lane per tile) and level tail overlap the other waves' MFMAs.
+//   * small batches are processed cooperatively: all waves of a workgroup split the codes of ONE row tile and
+//     merge their argmin candidates through LDS (rq_tile<COOP = true>).
 //
 // Arithmetic is bit-identical to oracle/rq_oracle.c (tests/test_gpu_parity.py).
 #include "rqhip_common.h"
@@ -60,6 +62,7 @@ struct RqFwdParams {
     int Kc;               // codes per LDS buffer (multiple of 32)
     int nchunks;          // chunks per level (1 when resident)
     int resident;         // all levels staged once
+    long long coop_first; // first row tile of the cooperative tail (== n_tiles when there is none)
     float beta;
 };
 
@@ -225,7 +228,7 @@ __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, 
 template <int KSTEPS>
 __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
                                            int kbase, int il, int h, const float (&x)[KSTEPS], float xsq,
-                                           float &best, int &bidx) {
+                                           float &best, int &bidx, int t_begin = 0, int t_step = 1) {
     constexpr int KQ = KSTEPS / 4;
     const int ntiles = Kc / 32;
     // code offset of accumulator element j inside a tile, held in registers the optimiser cannot see through:
@@ -234,7 +237,7 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
     int slotreg[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(slotreg[j]) : "n"(8 * (j >> 2) + (j & 3)));
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_begin; t < ntiles; t += t_step) {
         f32x4 a[KQ];
 #pragma unroll
         for (int q = 0; q < KQ; ++q) a[q] = img[(size_t)(q * 2 + h) * Kc + t * 32 + il];
@@ -280,12 +283,208 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
     }
 }
 
+// One 32-row tile through all L levels.
+//   COOP = false: the calling wave owns the tile and scans every staged code itself.
+//   COOP = true : all NT/64 waves of the workgroup work on the SAME tile: wave w scans code tiles w, w+W, ... of each
+//                 level, the per-lane (distance, index) candidates meet in LDS, wave 0 finishes the level (gather,
+//                 loss, output, stores) and hands the next residual to the others through LDS.  Used for
+//                 small batches (at most two row tiles per CU, e.g. the reference's batch 640), where one wave
+//                 per tile would leave most SIMDs empty: 46 -> 26 us at 640 x (3 x 256 x 32).
 // FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP>
+__device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
+                                        long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase) {
+    constexpr int KQ = KSTEPS / 4;
+    constexpr int kWaves = NT / RQ_WAVE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    const int K = p.K, Kc = p.Kc, L = p.L;
+    const bool active = tile < p.n_tiles;
+    const long long row = tile * 32 + il;
+    const bool row_ok = active && row < p.B;
+    const bool writer = row_ok && (!COOP || wave == 0);
+    const size_t level_stride = (size_t)p.B * D;
+
+    float es[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) es[kk] = 0.0f;
+    float lsum = 0.0f;
+    // running output pointers of this lane (advanced per level: no 64-bit multiplies inside the level loop)
+    int64_t *ids_ptr = p.ids + row;
+    float *norm_ptr = p.embs_norm ? p.embs_norm + (size_t)row * L : nullptr;
+    float *embs_ptr = p.embs ? p.embs + (size_t)row * D + h : nullptr;
+    float *resid_ptr = p.residuals ? p.residuals + (size_t)row * D + h : nullptr;
+    RQ_STAMP(1);
+
+    for (int l = 0; l < L; ++l) {
+        RQ_STAMP(2 + 8 * l);
+        const float csqmax_l = csqmax_s[l];
+
+        // |x|^2 (quantize.py:114): parity accumulators, multiply and add separately rounded
+        const float xsq = pair_sumsq<KSTEPS>(r);
+
+        float best = __builtin_inff();
+        int bidx = 0x7fffffff;
+
+        const float *buf = smem + (p.resident ? l * buf_floats : 0);
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const int kbase = ch * Kc;
+            if (!p.resident) {
+                __syncthreads();  // previous chunk fully consumed
+                stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
+                                        kbase, Kc, K, D);
+                __syncthreads();
+            }
+            if (active)
+                scan_codes<KSTEPS>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r, xsq,
+                                   best, bidx, COOP ? wave : 0, COOP ? kWaves : 1);
+        }
+
+        RQ_STAMP(3 + 8 * l);
+        if (COOP) {
+            // candidates of all waves and both lane halves meet in LDS (double-buffered by level parity: one barrier
+            // per level); lexicographic (distance, index) minimum == first-index argmin over the whole codebook
+            // (`phase` counts levels across consecutive cooperative tiles, so the parity keeps alternating)
+            float *cv = cand_s + ((phase + l) & 1) * (2 * NT);
+            int *ci = reinterpret_cast<int *>(cv + NT);
+            cv[threadIdx.x] = best;
+            ci[threadIdx.x] = bidx;
+            __syncthreads();
+            best = __builtin_inff();
+            bidx = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const float ov = cv[w * 64 + hh * 32 + il];
+                    const int oi = ci[w * 64 + hh * 32 + il];
+                    if (ov < best || (ov == best && oi < bidx)) {
+                        best = ov;
+                        bidx = oi;
+                    }
+                }
+            }
+        }
+        const bool do_tail = active && (!COOP || wave == 0);  // cooperative tiles: wave 0 finishes the level alone
+        if (do_tail) {
+            if (!COOP) {
+                // lanes (il,0) and (il,1) scanned disjoint code subsets: keep the smaller, ties -> lower index
+                const float ob = shfl_xor32(best);
+                const int oi = shfl_xor32(bidx);
+                if (ob < best || (ob == best && oi < bidx)) {
+                    best = ob;
+                    bidx = oi;
+                }
+            }
+            if (bidx == 0x7fffffff) bidx = 0;  // every distance was +Inf: torch.min keeps index 0
+            // rows whose distances can be Inf/NaN take torch's exact scan
+            // fast path only when no distance term can overflow (then fma(-2,acc,tt) == tt - 2*acc exactly)
+            const float guard = xsq + csqmax_l;
+            const bool bad = !(guard < 1.0e38f);
+            unsigned long long badmask = __ballot(bad) & 0xffffffffull;
+            if (badmask) {
+                const float *cb_l = p.cb + (size_t)l * K * D;
+                const float *csq_l = p.csq + (size_t)l * p.Kp;
+                while (badmask) {
+                    const int j = __builtin_ctzll(badmask);
+                    badmask &= badmask - 1;
+                    const float xj = __shfl(xsq, j, 64);
+                    const int res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
+                    if (il == j) bidx = res;
+                }
+            }
+
+            RQ_STAMP(4 + 8 * l);
+            // codeword gather (quantize.py:101-102) for this lane's feature parity: from the staged LDS image
+            // when the whole level is resident, else from global memory (L2)
+            float e[KSTEPS];
+            if (p.resident) {
+                const f32x4 *img = reinterpret_cast<const f32x4 *>(buf) + h * Kc + bidx;
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    const f32x4 v = img[q * 2 * Kc];
+                    e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+                }
+            } else {
+                const float *src = p.cb + ((size_t)l * K + bidx) * D + h;
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) e[kk] = (FULLD || 2 * kk + h < D) ? src[2 * kk] : 0.0f;
+            }
+            // QuantizeLoss (loss.py:38-41): both terms equal sum((x-emb)^2)
+            float sa = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const float df = r[kk] - e[kk];
+                sa = sa + df * df;
+            }
+            const float s = pair_sum(sa);
+            const float lv = s + p.beta * s;
+            lsum = (l == 0) ? lv : lsum + lv;
+
+            RQ_STAMP(5 + 8 * l);
+            float o[KSTEPS];
+            level_output<KSTEPS, MODE>(r, e, xsq, o);
+
+            RQ_STAMP(6 + 8 * l);
+            if (writer) {
+                if (h == 0) *ids_ptr = (int64_t)bidx;
+                if (norm_ptr) {  // uniform branch: the sqrt sequence is skipped when norms are not requested
+                    const float onorm = __builtin_sqrtf(pair_sumsq<KSTEPS>(o));
+                    if (h == 0) norm_ptr[l] = onorm;
+                }
+                if (resid_ptr) {
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk)
+                        if (FULLD || 2 * kk + h < D) resid_ptr[2 * kk] = r[kk];
+                }
+                if (embs_ptr) {
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk)
+                        if (FULLD || 2 * kk + h < D) embs_ptr[2 * kk] = o[kk];
+                }
+            }
+            ids_ptr += p.B;
+            if (resid_ptr) resid_ptr += level_stride;
+            if (embs_ptr) embs_ptr += level_stride;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                es[kk] = (l == 0) ? o[kk] : es[kk] + o[kk];
+                r[kk] = r[kk] - o[kk];  // rqvae.py:130
+            }
+        }
+        if (COOP && l + 1 < L) {
+            // the next level's residual goes from wave 0 to the other waves through LDS (one slot per lane and
+            // register; the candidate barrier of the next level orders these reads before the next write)
+            float *rx = cand_s + 4 * NT;
+            if (wave == 0) {
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) rx[kk * 64 + lane] = r[kk];
+            }
+            __syncthreads();
+            if (wave != 0) {
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) r[kk] = rx[kk * 64 + lane];
+            }
+        }
+    }
+
+    RQ_STAMP(100);
+    if (writer) {
+        if (h == 0 && p.loss) p.loss[row] = lsum;
+        if (p.emb_sum) {
+            float *dst = p.emb_sum + (size_t)row * D + h;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                if (FULLD || 2 * kk + h < D) dst[2 * kk] = es[kk];
+        }
+    }
+    RQ_STAMP(101);
+}
+
 template <int KSTEPS, int MODE, bool FULLD, int NT>
 __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *smem = reinterpret_cast<float *>(smem_raw);
-    constexpr int KQ = KSTEPS / 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -300,7 +499,6 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     // round `it`: waves are enumerated wave-major (wave w of every workgroup before wave w+1), so a partly
     // filled last round spreads over all CUs instead of filling the first workgroups only
     const long long wave_slot = (long long)wave * gridDim.x + blockIdx.x;
-    const size_t level_stride = (size_t)p.B * D;  // elements between levels of embs / residuals
 
     auto load_rows = [&](long long tile, float(&v)[KSTEPS]) {
         const long long row = tile * 32 + il;
@@ -316,154 +514,29 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     // per-level max codebook norm (Inf/NaN guard) lives in LDS: no global load inside the level loop, so the
     // in-order vmcnt counter never makes a level wait for the previous level's stores
     float *csqmax_s = smem + (p.resident ? L : 1) * buf_floats;
+    float *cand_s = csqmax_s + 16;  // [2][2*NT]: cooperative-tile candidates
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
     if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
     __syncthreads();
 
+    // full rounds: one tile per wave
     for (int it = 0; it < p.n_iter; ++it) {
         const long long tile = (long long)it * total_waves + wave_slot;
-        const bool active = tile < p.n_tiles;
+        const bool active = tile < p.coop_first;
         if (p.resident && !active) break;
-        const long long row = tile * 32 + il;
-        const bool row_ok = active && row < p.B;
-
-        float r[KSTEPS], es[KSTEPS];
+        float r[KSTEPS];
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            r[kk] = rn[kk];
-            es[kk] = 0.0f;
-        }
+        for (int kk = 0; kk < KSTEPS; ++kk) r[kk] = rn[kk];
         if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
-        float lsum = 0.0f;
-        // running output pointers of this lane (advanced per level: no 64-bit multiplies inside the level loop)
-        int64_t *ids_ptr = p.ids + row;
-        float *norm_ptr = p.embs_norm ? p.embs_norm + (size_t)row * L : nullptr;
-        float *embs_ptr = p.embs ? p.embs + (size_t)row * D + h : nullptr;
-        float *resid_ptr = p.residuals ? p.residuals + (size_t)row * D + h : nullptr;
-        RQ_STAMP(1);
-
-        for (int l = 0; l < L; ++l) {
-            RQ_STAMP(2 + 8 * l);
-            const float csqmax_l = csqmax_s[l];
-
-            // |x|^2 (quantize.py:114): parity accumulators, multiply and add separately rounded
-            const float xsq = pair_sumsq<KSTEPS>(r);
-            float best = __builtin_inff();
-            int bidx = 0;
-
-            const float *buf = smem + (p.resident ? l * buf_floats : 0);
-            for (int ch = 0; ch < p.nchunks; ++ch) {
-                const int kbase = ch * Kc;
-                if (!p.resident) {
-                    __syncthreads();  // previous chunk fully consumed
-                    stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
-                                        kbase, Kc, K, D);
-                    __syncthreads();
-                }
-                if (active)
-                    scan_codes<KSTEPS>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r,
-                                       xsq, best, bidx);
-            }
-
-            RQ_STAMP(3 + 8 * l);
-            if (active) {
-                // lanes (il,0) and (il,1) scanned disjoint code subsets: keep the smaller, ties -> lower index
-                {
-                    const float ob = shfl_xor32(best);
-                    const int oi = shfl_xor32(bidx);
-                    if (ob < best || (ob == best && oi < bidx)) {
-                        best = ob;
-                        bidx = oi;
-                    }
-                }
-                // rows whose distances can be Inf/NaN take torch's exact scan
-                // fast path only when no distance term can overflow (then fma(-2,acc,tt) == tt - 2*acc exactly)
-                const float guard = xsq + csqmax_l;
-                const bool bad = !(guard < 1.0e38f);
-                unsigned long long badmask = __ballot(bad) & 0xffffffffull;
-                if (badmask) {
-                    const float *cb_l = p.cb + (size_t)l * K * D;
-                    const float *csq_l = p.csq + (size_t)l * p.Kp;
-                    while (badmask) {
-                        const int j = __builtin_ctzll(badmask);
-                        badmask &= badmask - 1;
-                        const float xj = __shfl(xsq, j, 64);
-                        const int res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
-                        if (il == j) bidx = res;
-                    }
-                }
-
-                RQ_STAMP(4 + 8 * l);
-                // codeword gather (quantize.py:101-102) for this lane's feature parity: from the staged LDS image
-                // when the whole level is resident, else from global memory (L2)
-                float e[KSTEPS];
-                if (p.resident) {
-                    const f32x4 *img = reinterpret_cast<const f32x4 *>(buf) + h * Kc + bidx;
-#pragma unroll
-                    for (int q = 0; q < KQ; ++q) {
-                        const f32x4 v = img[q * 2 * Kc];
-                        e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
-                    }
-                } else {
-                    const float *src = p.cb + ((size_t)l * K + bidx) * D + h;
-#pragma unroll
-                    for (int kk = 0; kk < KSTEPS; ++kk) e[kk] = (FULLD || 2 * kk + h < D) ? src[2 * kk] : 0.0f;
-                }
-                // QuantizeLoss (loss.py:38-41): both terms equal sum((x-emb)^2)
-                float sa = 0.0f;
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) {
-                    const float df = r[kk] - e[kk];
-                    sa = sa + df * df;
-                }
-                const float s = pair_sum(sa);
-                const float lv = s + p.beta * s;
-                lsum = (l == 0) ? lv : lsum + lv;
-
-                RQ_STAMP(5 + 8 * l);
-                float o[KSTEPS];
-                level_output<KSTEPS, MODE>(r, e, xsq, o);
-
-                RQ_STAMP(6 + 8 * l);
-                if (row_ok) {
-                    if (h == 0) *ids_ptr = (int64_t)bidx;
-                    if (norm_ptr) {  // uniform branch: the sqrt sequence is skipped when norms are not requested
-                        const float onorm = __builtin_sqrtf(pair_sumsq<KSTEPS>(o));
-                        if (h == 0) norm_ptr[l] = onorm;
-                    }
-                    if (resid_ptr) {
-#pragma unroll
-                        for (int kk = 0; kk < KSTEPS; ++kk)
-                            if (FULLD || 2 * kk + h < D) resid_ptr[2 * kk] = r[kk];
-                    }
-                    if (embs_ptr) {
-#pragma unroll
-                        for (int kk = 0; kk < KSTEPS; ++kk)
-                            if (FULLD || 2 * kk + h < D) embs_ptr[2 * kk] = o[kk];
-                    }
-                }
-                ids_ptr += p.B;
-                if (resid_ptr) resid_ptr += level_stride;
-                if (embs_ptr) embs_ptr += level_stride;
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) {
-                    es[kk] = (l == 0) ? o[kk] : es[kk] + o[kk];
-                    r[kk] = r[kk] - o[kk];  // rqvae.py:130
-                }
-            }
-        }
-
-        RQ_STAMP(100);
-        if (row_ok) {
-            if (h == 0 && p.loss) p.loss[row] = lsum;
-            if (p.emb_sum) {
-                float *dst = p.emb_sum + (size_t)row * D + h;
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk)
-                    if (FULLD || 2 * kk + h < D) dst[2 * kk] = es[kk];
-            }
-        }
-        RQ_STAMP(101);
+        rq_tile<KSTEPS, MODE, FULLD, NT, false>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
+    }
+    // cooperative tail (resident mode only): one tile per workgroup at a time
+    int phase = 0;
+    for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        float r[KSTEPS];
+        load_rows(tile, r);
+        rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
+        phase += L;
     }
 }
 
@@ -515,6 +588,10 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
 
 using namespace rqhip;
 
+static inline bool f_resident_small(int resident, long long n_tiles, long long cap) {
+    return resident && n_tiles <= 2 * cap;
+}
+
 static inline int pad32(int k) { return (k + 63) & ~63; }  // code tiles are processed in pairs
 
 extern "C" size_t rqhip_rq_forward_workspace_bytes(int L, int K) {
@@ -559,7 +636,7 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     p.embs_norm = embs_norm;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
     const size_t level_bytes = (size_t)Kp * (Dp + 1) * sizeof(float);
-    if (level_bytes * L + 64 <= (size_t)kLdsBudget) {
+    if (level_bytes * L + 64 + (4 * 768 + 64 * ksteps) * sizeof(float) <= (size_t)kLdsBudget) {
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
         p.resident = 0;
@@ -569,15 +646,23 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
         if (kc < 64) kc = 64;
         p.Kc = kc; p.nchunks = (Kp + kc - 1) / kc;
     }
-    const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1) + 16 * sizeof(float);
+    const int nt_threads = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256);
+    const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1) + 16 * sizeof(float) +
+                       (size_t)(4 * nt_threads + 64 * ksteps) * sizeof(float);
     const int cus = cu_count();
     const int wg_per_cu = (lds * 2 <= (size_t)kLdsBudget) ? 2 : 1;
     const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
     long long cap = (long long)cus * wg_per_cu;
+    // small batches (at most two row tiles per CU): every tile is cooperative, one workgroup per tile
+    const bool all_coop = f_resident_small(p.resident, p.n_tiles, cap);
+    if (all_coop) want = p.n_tiles;
     const int grid = (int)(want < cap ? want : cap);
     const long long total_waves = (long long)grid * waves_per_wg;
-    p.n_iter = (int)((p.n_tiles + total_waves - 1) / total_waves);
+    // (Also tried: cooperative processing of just the partly filled last round of a big batch -- 53 tiles at
+    // 100 000 rows.  No gain: the workgroup has to wait for all its waves to finish the full round first.)
+    p.coop_first = all_coop ? 0 : p.n_tiles;
+    p.n_iter = (int)((p.coop_first + total_waves - 1) / total_waves);
 
     switch (ksteps) {
         case 4: return launch_mode<4>(p, mode, grid, lds, s);
