@@ -143,6 +143,32 @@ int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int64_t *rank,
                      rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Decoder-side consumers of semantic ids: exact integer tuple matching.
+ *
+ * Prefix index -- replaces EncoderDecoderRetrievalModel._check_valid_prefix (modules/model.py:169-182), the
+ *   [N, P, h] equality tensor rebuilt at every beam step of generate() (model.py:349,364).
+ *   corpus [N, H] int64, row stride ld elements (>= H): the model's `codebooks` buffer (model.py:75), i.e.
+ *   tokenizer.cached_ids[:, :n_layers] (train_decoder.py:131).  Any int64 values are accepted.
+ *   rqhip_prefix_index_build: fills `index` (rqhip_prefix_index_bytes(N, H) bytes, caller-owned, opaque) with
+ *     the set of all prefixes of length 1..H of all corpus rows.  Build once per corpus.
+ *   rqhip_prefix_lookup: valid[q] = 1 iff prefix[q, 0:h] equals corpus[n, 0:h] for some n; prefix [P, h]
+ *     int64 with row stride ldp (>= h), 0 <= h <= H (h = 0: valid iff N > 0, as all()/any() give), valid [P]
+ *     bytes (a torch.bool buffer).  `corpus`, N, H, ld must be the ones the index was built from: the index
+ *     stores row numbers and every hit is confirmed against the corpus row itself.
+ * Top-k match -- the array step of TopKAccumulator.accumulate (evaluate/metrics.py:16-25):
+ *   rank[b] = the first k with top_k[b, k, :] == actual[b, :], or -1; actual [B, D], top_k [B, K, D], dense.
+ */
+#define RQHIP_MAX_PREFIX_LEN 16
+size_t rqhip_prefix_index_bytes(int64_t N, int H);
+int rqhip_prefix_index_build(const int64_t *corpus, int64_t N, int H, int64_t ld, void *index,
+                             size_t index_bytes, rqhip_stream_t stream);
+int rqhip_prefix_lookup(const void *index, size_t index_bytes, const int64_t *corpus, int64_t N, int H,
+                        int64_t ld, const int64_t *prefix, int64_t P, int h, int64_t ldp, uint8_t *valid,
+                        rqhip_stream_t stream);
+int rqhip_topk_first_match(const int64_t *actual, const int64_t *top_k, int64_t B, int K, int D,
+                           int64_t *rank, rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Reconstruction loss (modules/loss.py:5-10 ReconstructionLoss, called at modules/rqvae.py:152), fused.
  *   forward : out[b] = sum_d (x_hat[b,d] - x[b,d])^2        x_hat, x: [B,N] with row strides ld_* (elements, >= N)
  *   backward: g_x_hat[b,d] = 2 (x_hat[b,d] - x[b,d]) g_out[b]; g_x = -g_x_hat; either output may be NULL;

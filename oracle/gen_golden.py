@@ -262,9 +262,71 @@ def gen_dedup(q, r, sem, sch):
     np.savez_compressed(os.path.join(OUT, "dedup_a.npz"), x=np32(X), corpus_ids=ids.numpy().astype(np.int64), **save)
 
 
+def gen_sid_match():
+    """Decoder-side consumers: EncoderDecoderRetrievalModel._check_valid_prefix
+    (modules/model.py:169-182, called unbound on a stand-in `self` that only carries `.codebooks`) and
+    TopKAccumulator (evaluate/metrics.py:7-28)."""
+    _install_stubs()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from modules import model as m  # noqa  (pulls in transformers' T5; ~15 s)
+    from evaluate.metrics import TopKAccumulator
+
+    def ref_valid(corpus, prefix, batch_size):
+        self_ = types.SimpleNamespace(codebooks=torch.from_numpy(corpus))
+        return m.EncoderDecoderRetrievalModel._check_valid_prefix(self_, torch.from_numpy(prefix),
+                                                                  batch_size=batch_size).numpy()
+
+    for tag, N, H, K, P, seed in (("a", 500, 3, 8, 300, 71), ("b", 2000, 4, 256, 700, 72), ("c", 1, 3, 5, 40, 73)):
+        rng = np.random.default_rng(seed)
+        corpus = rng.integers(0, K, size=(N, H)).astype(np.int64)
+        if tag == "b":
+            corpus[:, -1] = rng.integers(0, 3, size=N)     # dedup-like last column
+            corpus[7] = [2**40 + 5, -3, 2**33, 0]            # full 64-bit values must be compared, not hashes
+        save = {"corpus": corpus}
+        for h in range(1, H + 1):
+            real = corpus[rng.integers(0, N, size=P // 2), :h]
+            rand = rng.integers(-1 if tag == "b" else 0, K + 1, size=(P - P // 2, h)).astype(np.int64)
+            prefix = np.concatenate([real, rand], axis=0)
+            if tag == "b" and h >= 2:
+                prefix[0, :h] = corpus[7, :h]
+                prefix[1, :h] = corpus[7, :h]
+                prefix[1, 0] = 5                              # same low 32 bits as 2**40+5: must NOT match row 7
+            prefix = prefix[rng.permutation(P)]
+            save[f"prefix_h{h}"] = prefix
+            save[f"valid_h{h}"] = ref_valid(corpus, prefix, batch_size=97)
+        np.savez_compressed(os.path.join(OUT, f"prefix_{tag}.npz"), **save)
+
+    for tag, B, K, D, vocab, seed in (("a", 64, 10, 3, 6, 81), ("b", 33, 20, 4, 256, 82)):
+        rng = np.random.default_rng(seed)
+        acc = TopKAccumulator(ks=[1, 5, 10])
+        save = {}
+        for part in range(2):
+            actual = rng.integers(0, vocab, size=(B, D)).astype(np.int64)
+            top_k = rng.integers(0, vocab, size=(B, K, D)).astype(np.int64)
+            for b in range(0, B, 2):                          # plant matches at assorted ranks, some twice
+                k = int(rng.integers(0, K))
+                top_k[b, k] = actual[b]
+                if b % 4 == 0:
+                    top_k[b, min(K - 1, k + 2)] = actual[b]
+            pos = (torch.from_numpy(actual)[:, None, :] == torch.from_numpy(top_k)).all(-1)
+            found, rank = pos.max(-1)
+            save[f"actual_{part}"] = actual
+            save[f"top_k_{part}"] = top_k
+            save[f"rank_{part}"] = np.where(found.numpy(), rank.numpy(), -1).astype(np.int64)
+            acc.accumulate(actual=torch.from_numpy(actual), top_k=torch.from_numpy(top_k))
+        red = acc.reduce()
+        save["metric_names"] = np.array(sorted(red))
+        save["metric_values"] = np.array([red[k] for k in sorted(red)], dtype=np.float64)
+        np.savez_compressed(os.path.join(OUT, f"topk_{tag}.npz"), **save)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-sid-match" in sys.argv:
+        gen_sid_match()
+        return
     q, r, km, sem, sch = import_reference()
     gen_quantize(q)
     gen_gumbel(q)
@@ -272,6 +334,7 @@ def main():
     gen_rqvae(q, r, sch)
     gen_kmeans(km)
     gen_dedup(q, r, sem, sch)
+    gen_sid_match()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {total / 1024:.0f} KiB -> {os.path.abspath(OUT)}")
 

@@ -510,3 +510,38 @@ int64_t rqo_count_rows_without_later_duplicate(const int64_t *ids, int64_t B, in
     }
     return n;
 }
+
+/* ---- decoder-side consumers of semantic ids ------------------------------- */
+
+/* modules/model.py:169-182 (_check_valid_prefix): valid[q] = any_n all_c corpus[n,c] == prefix[q,c], c < h.
+ * corpus [N,H] dense, prefix [P,h] dense.  Brute force like the reference, O(N P h): small inputs only.
+ * h == 0: all() over no columns is true, so valid iff N > 0. */
+int rqo_prefix_valid(const int64_t *corpus, int64_t N, int H, const int64_t *prefix, int64_t P, int h,
+                     uint8_t *valid) {
+    if (N < 0 || P < 0 || H < 0 || h < 0 || h > H || (P > 0 && !valid)) return RQO_EARG;
+    for (int64_t q = 0; q < P; ++q) {
+        int any = 0;
+        for (int64_t n = 0; n < N && !any; ++n) {
+            int all = 1;
+            for (int c = 0; c < h && all; ++c) all = corpus[n * H + c] == prefix[q * h + c];
+            any = all;
+        }
+        valid[q] = (uint8_t)any;
+    }
+    return RQO_OK;
+}
+
+/* evaluate/metrics.py:16-19: pos_match.all(-1).max(-1) -> (match_found, rank of the first match).
+ * rank[b] = first k with top_k[b,k,:] == actual[b,:], or -1.  actual [B,D], top_k [B,K,D]. */
+int rqo_topk_first_match(const int64_t *actual, const int64_t *top_k, int64_t B, int K, int D, int64_t *rank) {
+    if (B < 0 || K < 0 || D < 0 || (B > 0 && !rank)) return RQO_EARG;
+    for (int64_t b = 0; b < B; ++b) {
+        rank[b] = -1;
+        for (int k = 0; k < K && rank[b] < 0; ++k) {
+            int all = 1;
+            for (int d = 0; d < D && all; ++d) all = actual[b * D + d] == top_k[(b * K + k) * D + d];
+            if (all) rank[b] = k;
+        }
+    }
+    return RQO_OK;
+}

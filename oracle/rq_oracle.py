@@ -191,6 +191,41 @@ def count_rows_without_later_duplicate(ids) -> int:
     return int(lib().rqo_count_rows_without_later_duplicate(_p(ids), C.c_int64(B), C.c_int(L)))
 
 
+def prefix_valid(corpus, prefix) -> np.ndarray:
+    """modules/model.py:169-182: which prefix rows [P,h] occur as the first h ids of a corpus row [N,H]."""
+    corpus = np.ascontiguousarray(corpus, dtype=np.int64)
+    prefix = np.ascontiguousarray(prefix, dtype=np.int64)
+    N, H = corpus.shape
+    P, h = prefix.shape
+    valid = np.empty((P,), np.uint8)
+    _chk(lib().rqo_prefix_valid(_p(corpus), C.c_int64(N), C.c_int(H), _p(prefix), C.c_int64(P), C.c_int(h),
+                                _p(valid)), "prefix_valid")
+    return valid.astype(bool)
+
+
+def topk_first_match(actual, top_k) -> np.ndarray:
+    """evaluate/metrics.py:16-19: first position k with top_k[b,k,:] == actual[b,:], or -1."""
+    actual = np.ascontiguousarray(actual, dtype=np.int64)
+    top_k = np.ascontiguousarray(top_k, dtype=np.int64)
+    B, D = actual.shape
+    K = top_k.shape[1]
+    rank = np.empty((B,), np.int64)
+    _chk(lib().rqo_topk_first_match(_p(actual), _p(top_k), C.c_int64(B), C.c_int(K), C.c_int(D), _p(rank)),
+         "topk_first_match")
+    return rank
+
+
+def topk_metrics(rank, ks=(1, 5, 10)) -> dict:
+    """evaluate/metrics.py:19-25 + reduce(): ndcg and hit rates from first-match positions (-1 = no match)."""
+    rank = np.asarray(rank, np.int64)
+    hit = rank >= 0
+    gain = (np.float32(1.0) / np.log2(rank[hit].astype(np.float32) + np.float32(2.0))).astype(np.float32)
+    out = {"ndcg": float(gain.sum(dtype=np.float64)) / len(rank)}
+    for k in ks:
+        out[f"h@{k}"] = float(np.count_nonzero(rank[hit] < k)) / len(rank)
+    return out
+
+
 def recon_loss(x_hat, x) -> np.ndarray:
     """Row-wise sum of squared differences in the kernel's fixed order (modules/loss.py:5-10)."""
     x_hat, x = _f(x_hat), _f(x)

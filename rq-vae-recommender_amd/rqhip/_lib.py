@@ -38,6 +38,10 @@ SIGNATURES = {
     "rqhip_kmeans_update": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "rqhip_dedup_workspace_bytes": (_sz, [_i64]),
     "rqhip_dedup_rank": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_prefix_index_bytes": (_sz, [_i64, _int]),
+    "rqhip_prefix_index_build": (_int, [_vp, _i64, _int, _i64, _vp, _sz, _vp]),
+    "rqhip_prefix_lookup": (_int, [_vp, _sz, _vp, _i64, _int, _i64, _vp, _i64, _int, _i64, _vp, _vp]),
+    "rqhip_topk_first_match": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
     "rqhip_recon_loss_forward": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp]),
     "rqhip_recon_loss_backward": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
     "rqhip_profile_enable": (_int, [_int]),

@@ -169,6 +169,74 @@ def dedup_rank(ids: Tensor, codebook_size: int = 0, *, want_rank: bool = True):
     return rank, n
 
 
+def _i64_rows(t: Tensor, name: str) -> Tensor:
+    """int64 [rows, cols] with unit column stride (a column slice of a wider table is taken as is)."""
+    if t.dtype != torch.int64 or t.dim() != 2:
+        raise RqHipError(f"{name} must be an int64 2-D tensor, got {t.dtype} {tuple(t.shape)}")
+    cols = t.shape[1]
+    if cols > 0 and (t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < cols)):
+        t = t.contiguous()
+    return t
+
+
+def _row_stride(t: Tensor) -> int:
+    return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
+
+
+def prefix_index_build(corpus: Tensor) -> Tensor:
+    """Set of all prefixes of the corpus' semantic-id rows (rqhip_prefix_index_build).  corpus [N,H] int64
+    (row-strided views are fine) -> opaque uint8 index tensor; keep `corpus` alive and unchanged next to it."""
+    _need_gpu(corpus)
+    corpus = _i64_rows(corpus, "corpus")
+    N, H = corpus.shape
+    dev = corpus.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        nbytes = l.rqhip_prefix_index_bytes(N, H)
+        if nbytes == 0:
+            raise RqHipError(f"prefix_index_build: unsupported corpus shape {tuple(corpus.shape)}")
+        index = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        rc = l.rqhip_prefix_index_build(_ptr(corpus), N, H, _row_stride(corpus), _ptr(index), nbytes, _stream())
+        check(rc, "rqhip_prefix_index_build")
+    return index
+
+
+def prefix_lookup(index: Tensor, corpus: Tensor, prefix: Tensor) -> Tensor:
+    """valid[q] = prefix[q] occurs as the first h ids of some corpus row (rqhip_prefix_lookup); reference
+    modules/model.py:169-182.  prefix [P,h] int64 -> bool [P]."""
+    _need_gpu(index, corpus, prefix)
+    corpus = _i64_rows(corpus, "corpus")
+    prefix = _i64_rows(prefix, "prefix")
+    N, H = corpus.shape
+    P, h = prefix.shape
+    dev = corpus.device
+    with torch.cuda.device(dev):
+        valid = torch.empty((P,), dtype=torch.bool, device=dev)
+        rc = _lib.lib().rqhip_prefix_lookup(_ptr(index), index.numel(), _ptr(corpus), N, H, _row_stride(corpus),
+                                            _ptr(prefix), P, h, _row_stride(prefix), _ptr(valid), _stream())
+        check(rc, "rqhip_prefix_lookup")
+    return valid
+
+
+def topk_first_match(actual: Tensor, top_k: Tensor) -> Tensor:
+    """rank[b] = first k with top_k[b,k,:] == actual[b,:], else -1 (rqhip_topk_first_match); the array step of
+    the reference's TopKAccumulator.accumulate (evaluate/metrics.py:16-25).  actual [B,D], top_k [B,K,D] int64."""
+    _need_gpu(actual, top_k)
+    if actual.dtype != torch.int64 or top_k.dtype != torch.int64 or actual.dim() != 2 or top_k.dim() != 3:
+        raise RqHipError("topk_first_match: actual [B,D] and top_k [B,K,D] must be int64")
+    B, D = actual.shape
+    if top_k.shape[0] != B or top_k.shape[2] != D:
+        raise RqHipError(f"topk_first_match: top_k {tuple(top_k.shape)} does not match actual {tuple(actual.shape)}")
+    K = top_k.shape[1]
+    actual, top_k = actual.contiguous(), top_k.contiguous()
+    dev = actual.device
+    with torch.cuda.device(dev):
+        rank = torch.empty((B,), dtype=torch.int64, device=dev)
+        rc = _lib.lib().rqhip_topk_first_match(_ptr(actual), _ptr(top_k), B, K, D, _ptr(rank), _stream())
+        check(rc, "rqhip_topk_first_match")
+    return rank
+
+
 def gumbel_forward(x: Tensor, codebook: Tensor, U: Tensor, temperature: float, beta: float):
     """One GUMBEL_SOFTMAX level, training (rqhip_gumbel_forward) -> (ids [B], emb [B,D], loss [B])."""
     _need_gpu(x, codebook, U)

@@ -17,7 +17,8 @@ def _declared_functions():
 def test_header_declares_the_expected_surface():
     names = _declared_functions()
     for must in ("rqhip_rq_forward", "rqhip_rq_backward", "rqhip_gumbel_forward", "rqhip_gumbel_backward",
-                 "rqhip_kmeans_assign", "rqhip_kmeans_update", "rqhip_dedup_rank", "rqhip_version",
+                 "rqhip_kmeans_assign", "rqhip_kmeans_update", "rqhip_dedup_rank", "rqhip_prefix_index_build",
+                 "rqhip_prefix_lookup", "rqhip_topk_first_match", "rqhip_version",
                  "rqhip_last_error"):
         assert must in names
 
@@ -43,6 +44,21 @@ def test_version_and_error_string_without_gpu():
     assert b"null pointer" in l.rqhip_last_error()
     rc = l.rqhip_kmeans_assign(None, -1, 32, None, 8, None, None)
     assert rc == -1
+
+
+def test_sid_match_argument_checks_without_gpu():
+    from rqhip import _lib
+    l = _lib.lib()
+    # 2 x N slots (power of two, at least 64) of 4 bytes per prefix length
+    assert l.rqhip_prefix_index_bytes(1000, 3) == 2048 * 4 * 3
+    assert l.rqhip_prefix_index_bytes(10, 1) == 64 * 4
+    assert l.rqhip_prefix_index_bytes(-1, 3) == 0 and l.rqhip_prefix_index_bytes(5, 0) == 0
+    assert l.rqhip_prefix_index_build(None, 5, 3, 3, None, 0, None) == -1       # null corpus
+    assert l.rqhip_prefix_index_build(None, 0, 3, 2, None, 0, None) == -1       # row stride < H
+    assert b"ld >= H" in l.rqhip_last_error()
+    assert l.rqhip_prefix_lookup(None, 0, None, 0, 3, 3, None, 4, 5, 5, None, None) == -1   # h > H
+    assert l.rqhip_topk_first_match(None, None, 4, 10, 3, None, None) == -1
+    assert l.rqhip_topk_first_match(None, None, 0, 10, 3, None, None) == 0      # empty batch: nothing to do
 
 
 def test_workspace_queries():

@@ -147,6 +147,38 @@ def test_dedup_column_matches_precompute_corpus_ids():
     assert mism == 0.0, f"{mism:.4f} of rows differ"
 
 
+@pytest.mark.parametrize("name", _names("prefix_*.npz"))
+def test_prefix_valid_matches_check_valid_prefix(name):
+    """modules/model.py:169-182 run by oracle/gen_golden.py -> valid_h*; the C restatement must agree exactly."""
+    g = load_golden(name)
+    corpus = g["corpus"]
+    seen = set()
+    for h in range(1, corpus.shape[1] + 1):
+        got = o.prefix_valid(corpus, g[f"prefix_h{h}"])
+        assert np.array_equal(got, g[f"valid_h{h}"])
+        seen.update(np.unique(got).tolist())
+    if corpus.shape[0] > 1:
+        assert seen == {False, True}  # both outcomes occur in the fixture
+    # h == 0: all() over no columns -> every prefix is valid when the corpus is not empty
+    assert o.prefix_valid(corpus, np.zeros((3, 0), np.int64)).all()
+    assert not o.prefix_valid(np.zeros((0, 3), np.int64), np.zeros((3, 2), np.int64)).any()
+
+
+@pytest.mark.parametrize("name", _names("topk_*.npz"))
+def test_topk_first_match_and_metrics_match_topk_accumulator(name):
+    """evaluate/metrics.py:16-28: first-match positions bit-exact, reduced metrics to fp32 rounding."""
+    g = load_golden(name)
+    ranks = []
+    for part in range(2):
+        r = o.topk_first_match(g[f"actual_{part}"], g[f"top_k_{part}"])
+        assert np.array_equal(r, g[f"rank_{part}"])
+        ranks.append(r)
+    assert (np.concatenate(ranks) == -1).any() and (np.concatenate(ranks) > 0).any()
+    got = o.topk_metrics(np.concatenate(ranks))
+    for k, v in zip(g["metric_names"].tolist(), g["metric_values"].tolist()):
+        assert abs(got[k] - v) <= 1e-6, (k, got[k], v)
+
+
 def test_argmin_semantics_ties_and_nan():
     """quantize.py:128 / torch.min: first index on ties, a NaN distance wins."""
     x = np.zeros((3, 4), np.float32)
