@@ -25,6 +25,7 @@
 //
 // Arithmetic is bit-identical to oracle/rq_oracle.c (tests/test_gpu_parity.py).
 #include "rqhip_common.h"
+#include <stdlib.h>
 #include "rq_rowmath.h"
 
 namespace rqhip {
@@ -32,12 +33,21 @@ namespace rqhip {
 #ifdef RQ_TIMING
 // developer-only phase timestamps of wave 0 / workgroup 0 (build with EXTRA=-DRQ_TIMING; tools/phase_timing.py)
 __device__ unsigned long long rq_dbg[256];
+// per-wave trace (100 MHz constant clock): [workgroup*16 + wave][slot]; slot 0 = kernel entry, 1 = staged,
+// 2.. = end of each tile this wave processed
+__device__ unsigned long long rq_trace[4096 * 16 * 8];
+#define RQ_TRACE(slot)                                                                               \
+    do {                                                                                             \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && (slot) < 8)                              \
+            rq_trace[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #define RQ_STAMP(i)                                                                         \
     do {                                                                                    \
         if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 256) rq_dbg[(i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define RQ_STAMP(i) do { } while (0)
+#define RQ_TRACE(slot) do { } while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -225,57 +235,90 @@ __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, 
 // distance = (|x|^2 + |c|^2) - (2x).c, strict '<' in ascending code order == first-index ties.  The MFMAs of
 // one wave overlap the VALU epilogue of the other wave on the same SIMD; interleaving them inside one wave
 // measured slower (an instruction between two MFMAs on one accumulator costs ~40 cycles, tools/mfma_probe.hip).
+__device__ __forceinline__ float rq_min(float a, float b) {  // plain v_min_f32: no sNaN canonicalisation moves
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 rq_pk_add(f32x2 a, f32x2 b) {  // two IEEE fp32 adds in one issue slot
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float rq_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int KSTEPS>
 __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
                                            int kbase, int il, int h, const float (&x)[KSTEPS], float xsq,
                                            float &best, int &bidx, int t_begin = 0, int t_step = 1) {
     constexpr int KQ = KSTEPS / 4;
     const int ntiles = Kc / 32;
-    // code offset of accumulator element j inside a tile, held in registers the optimiser cannot see through:
-    // as compile-time constants LLVM turns the index tournament below into a ~400-instruction decode of the
-    // comparison masks
-    int slotreg[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(slotreg[j]) : "n"(8 * (j >> 2) + (j & 3)));
+    // The code operands (A) of the NEXT group of four matrix instructions are fetched from LDS before the current
+    // group is issued: a wave issues in order and stalls on each dependent MFMA, so a load placed after a group
+    // (where the compiler puts it to save four registers) exposes the LDS latency once per group.
+    const f32x2 xsq2 = {xsq, xsq};
+    auto lda = [&](int t, int q) { return img[(size_t)(q * 2 + h) * Kc + t * 32 + il]; };
+    f32x4 cur = lda(t_begin < ntiles ? t_begin : 0, 0);
     for (int t = t_begin; t < ntiles; t += t_step) {
-        f32x4 a[KQ];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) a[q] = img[(size_t)(q * 2 + h) * Kc + t * 32 + il];
+        const int tn = (t + t_step < ntiles) ? t + t_step : t;
         const float *cq = csq_s + t * 32 + 4 * h;
         f32x4 c4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) c4[g] = *reinterpret_cast<const f32x4 *>(cq + 8 * g);
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x2 dp[8];  // distances, two per packed instruction (v_pk_add_f32 / v_pk_fma_f32: same IEEE results)
 #pragma unroll
-        for (int sidx = 0; sidx < KSTEPS; ++sidx)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx >> 2][sidx & 3], x[sidx], acc, 0, 0, 0);
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 nxt = (q + 1 < KQ) ? lda(t, q + 1) : lda(tn, 0);
+            if (q == KQ - 1) {
+                // |x|^2 + |c|^2 (quantize.py:113-115), issued while the previous group still occupies the pipe
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr)
+                    dp[pr] = rq_pk_add(xsq2, f32x2{c4[pr >> 1][2 * (pr & 1)], c4[pr >> 1][2 * (pr & 1) + 1]});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i], x[4 * q + i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
         // acc[j]: code = 32 t + 8 (j>>2) + 4 h + (j&3), item = il.   dist = (|x|^2 + |c|^2) - 2 (x.c): the
         // doubling is exact, so one FMA gives the separately rounded  tt - (2 acc)  (quantize.py:113-117).
-        float dv[16];
-        int ds[16];
+        float d[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float tt = xsq + c4[j >> 2][j & 3];
-            dv[j] = __builtin_fmaf(-2.0f, acc[j], tt);
-            ds[j] = slotreg[j];
+        for (int pr = 0; pr < 8; ++pr) {
+            const f32x2 v = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, f32x2{acc[2 * pr], acc[2 * pr + 1]}, dp[pr]);
+            d[2 * pr] = v.x;
+            d[2 * pr + 1] = v.y;
         }
-        // tournament instead of a 16-long dependent chain; the right element wins only on strict '<', so the
-        // lower code index survives ties at every round (== a left-to-right scan)
-#define RQ_TOURNAMENT_ROUND(W)                                    \
-    _Pragma("unroll") for (int j = 0; j < 16; j += 2 * (W)) {    \
-        const bool take = dv[j + (W)] < dv[j];                   \
-        dv[j] = take ? dv[j + (W)] : dv[j];                      \
-        ds[j] = take ? ds[j + (W)] : ds[j];                      \
-    }
-        RQ_TOURNAMENT_ROUND(1)
-        RQ_TOURNAMENT_ROUND(2)
-        RQ_TOURNAMENT_ROUND(4)
-        RQ_TOURNAMENT_ROUND(8)
-#undef RQ_TOURNAMENT_ROUND
-        const float tmin = dv[0];
-        const int slot = ds[0];
-        // branch-free merge: with a branch the compiler sinks the whole slot tournament into it and rebuilds the
-        // slot from the comparison masks with a ~300-instruction select chain
+        // Argmin of the lane's 16 distances, first index on ties.  fp32 MFMAs and ordinary VALU instructions share
+        // the SIMD's datapath on gfx950 (tools/overlap_probe.hip: the two never overlap), so every VALU instruction
+        // here costs matrix time.  A minimum tree (11 min/min3) followed by a top-down walk ("is the minimum in
+        // the left half?" -- 4 compares, 11 selects) needs ~2/3 of the issue cycles of a compare-and-select
+        // tournament that drags the index along (15 compares, 30 selects).
+        const float a01 = rq_min(d[0], d[1]), a45 = rq_min(d[4], d[5]);
+        const float b01 = rq_min(d[8], d[9]), b45 = rq_min(d[12], d[13]);
+        const float a03 = rq_min3(a01, d[2], d[3]), a47 = rq_min3(a45, d[6], d[7]);
+        const float b03 = rq_min3(b01, d[10], d[11]), b47 = rq_min3(b45, d[14], d[15]);
+        const float a07 = rq_min(a03, a47), b07 = rq_min(b03, b47);
+        const float tmin = rq_min(a07, b07);
+        const bool c3 = a07 != tmin;                       // not in elements 0..7
+        const float q03 = c3 ? b03 : a03;
+        const bool c2 = q03 != tmin;                       // not in the first quarter of that half
+        const float s01 = c3 ? b01 : a01, s45 = c3 ? b45 : a45;
+        const float p01 = c2 ? s45 : s01;
+        const bool c1 = p01 != tmin;                       // not in the first pair of that quarter
+        const float t0 = c3 ? d[8] : d[0], t2 = c3 ? d[10] : d[2], t4 = c3 ? d[12] : d[4], t6 = c3 ? d[14] : d[6];
+        const float u0 = c2 ? t4 : t0, u2 = c2 ? t6 : t2;
+        const float e0 = c1 ? u2 : u0;
+        const bool c0 = e0 != tmin;                        // not the first element of that pair
+        // element j = 8 c3 + 4 c2 + 2 c1 + c0 holds code offset 8 (j >> 2) + (j & 3) = 16 c3 + 8 c2 + 2 c1 + c0
+        const int slot = (c3 ? 16 : 0) | (c2 ? 8 : 0) | (c1 ? 2 : 0) | (c0 ? 1 : 0);
         const int cand = kbase + t * 32 + 4 * h + slot;
         const bool better = tmin < best;
         best = better ? tmin : best;
@@ -509,6 +552,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     };
 
     RQ_STAMP(0);
+    RQ_TRACE(0);
     float rn[KSTEPS];  // rows of the NEXT tile, fetched one tile ahead
     load_rows(wave_slot, rn);
     // per-level max codebook norm (Inf/NaN guard) lives in LDS: no global load inside the level loop, so the
@@ -518,7 +562,21 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
     if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
     __syncthreads();
+    RQ_TRACE(1);
+    int trace_slot = 2;
+    (void)trace_slot;
 
+    // cooperative tiles first (resident mode only), one per workgroup at a time: the waves of a workgroup are
+    // in step right after the staging barrier, so nobody waits for a straggler of a full round
+    int phase = 0;
+    for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        float r[KSTEPS];
+        load_rows(tile, r);
+        rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
+        phase += L;
+        RQ_TRACE(trace_slot);
+        ++trace_slot;
+    }
     // full rounds: one tile per wave
     for (int it = 0; it < p.n_iter; ++it) {
         const long long tile = (long long)it * total_waves + wave_slot;
@@ -529,20 +587,24 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
         for (int kk = 0; kk < KSTEPS; ++kk) r[kk] = rn[kk];
         if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
         rq_tile<KSTEPS, MODE, FULLD, NT, false>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
-    }
-    // cooperative tail (resident mode only): one tile per workgroup at a time
-    int phase = 0;
-    for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        float r[KSTEPS];
-        load_rows(tile, r);
-        rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
-        phase += L;
+        RQ_TRACE(trace_slot);
+        ++trace_slot;
     }
 }
 
 #ifdef RQ_TIMING
 extern "C" int rqhip_debug_read(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rqhip::rq_dbg), sizeof(unsigned long long) * 256);
+}
+extern "C" int rqhip_debug_trace(unsigned long long *out, int clear) {
+    const size_t bytes = sizeof(unsigned long long) * 4096 * 16 * 8;
+    if (clear) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(rqhip::rq_trace));
+        if (e != hipSuccess) return (int)e;
+        return (int)hipMemset(ptr, 0, bytes);
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rqhip::rq_trace), bytes);
 }
 #endif
 
@@ -659,9 +721,14 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     if (all_coop) want = p.n_tiles;
     const int grid = (int)(want < cap ? want : cap);
     const long long total_waves = (long long)grid * waves_per_wg;
-    // (Also tried: cooperative processing of just the partly filled last round of a big batch -- 53 tiles at
-    // 100 000 rows.  No gain: the workgroup has to wait for all its waves to finish the full round first.)
+    // a partly filled last round (53 tiles at 100 000 rows) would run as lone waves, one per CU, for a whole tile
+    // time: when it is at most one tile per workgroup it is done cooperatively instead, BEFORE the full rounds
+    // (after them the workgroup would first have to wait for its slowest wave: measured, no gain)
     p.coop_first = all_coop ? 0 : p.n_tiles;
+    if (!all_coop && p.resident && getenv("RQ_COOP_HEAD")) {
+        const long long rem = p.n_tiles % total_waves;
+        if (rem > 0 && rem <= (long long)grid * atoi(getenv("RQ_COOP_HEAD"))) p.coop_first = p.n_tiles - rem;
+    }
     p.n_iter = (int)((p.coop_first + total_waves - 1) / total_waves);
 
     switch (ksteps) {

@@ -54,3 +54,31 @@ for i in sorted(names):
     if buf[i]:
         print(f"{names[i]:28s} +{buf[i] - t0:8d} ticks  (delta {buf[i] - prev:7d})")
         prev = buf[i]
+
+# ---- whole-kernel picture: per-wave trace (100 MHz clock -> 10 ns ticks) --------------------------------
+import numpy as np  # noqa: E402
+
+lib.rqhip_debug_trace(None, 1)
+torch.cuda.synchronize()
+rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, 0, C.c_float(0.25),
+                          vp(ids.data_ptr()), None, None, vp(es.data_ptr()), vp(loss.data_ptr()),
+                          vp(norm.data_ptr()), vp(ws.data_ptr()), C.c_size_t(wsb), None)
+torch.cuda.synchronize()
+tr = np.zeros((4096, 16, 8), np.uint64)
+assert lib.rqhip_debug_trace(tr.ctypes.data_as(C.c_void_p), 0) == 0
+used = tr[:, :, 0] > 0
+t0 = tr[:, :, 0][used].min()
+rel = (tr.astype(np.int64) - np.int64(t0)) / 100.0  # microseconds
+rel[tr == 0] = np.nan
+print(f"\nper-wave trace, {int(used.sum())} waves in {int(used.any(axis=1).sum())} workgroups (us since first wave entered):")
+for slot, name in ((0, "kernel entry"), (1, "codebooks staged"), (2, "tile 1 done"), (3, "tile 2 done"), (4, "tile 3 done")):
+    v = rel[:, :, slot][used & (tr[:, :, slot] > 0)]
+    if v.size:
+        q = np.percentile(v, [0, 10, 50, 90, 100])
+        print(f"  {name:18s} n={v.size:6d}  min {q[0]:7.2f}  p10 {q[1]:7.2f}  median {q[2]:7.2f}  p90 {q[3]:7.2f}  max {q[4]:7.2f}")
+d1 = rel[:, :, 2] - rel[:, :, 1]
+print("  tile-1 duration by wave index within the workgroup (median us):",
+      " ".join(f"{np.nanmedian(d1[:, w]):.1f}" for w in range(16) if used[:, w].any()))
+d2 = rel[:, :, 3] - rel[:, :, 2]
+if np.isfinite(d2).any():
+    print(f"  tile-2 duration: n={int(np.isfinite(d2).sum())} median {np.nanmedian(d2):.1f} us, max {np.nanmax(d2):.1f} us")
