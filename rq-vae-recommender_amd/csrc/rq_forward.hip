@@ -54,6 +54,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int kCoopWaves = 4;   // waves sharing one cooperative row tile: one per SIMD
+constexpr int kCoopSteps = 32;  // LDS counters, one per (cooperative tile, level): at most 2 tiles x 16 levels
+// floats of LDS behind the staged codebooks: candidates [2][4 waves][32] x (value, index) + the counters
+constexpr int kCoopLdsFloats = 4 * kCoopWaves * 32 + kCoopSteps;
+
 // workgroup size is a template parameter of the kernel (NT): more waves per SIMD hide the VALU epilogue and the
 // per-level tail of one wave behind the MFMAs of the others, as far as the register budget of KSTEPS allows
 constexpr int kLdsBudget = 160 * 1024;
@@ -328,17 +333,19 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
 
 // One 32-row tile through all L levels.
 //   COOP = false: the calling wave owns the tile and scans every staged code itself.
-//   COOP = true : all NT/64 waves of the workgroup work on the SAME tile: wave w scans code tiles w, w+W, ... of each
-//                 level, the per-lane (distance, index) candidates meet in LDS, wave 0 finishes the level (gather,
-//                 loss, output, stores) and hands the next residual to the others through LDS.  Used for
-//                 small batches (at most two row tiles per CU, e.g. the reference's batch 640), where one wave
-//                 per tile would leave most SIMDs empty: 46 -> 26 us at 640 x (3 x 256 x 32).
+//   COOP = true : the first kCoopWaves (4: one per SIMD) waves of the workgroup work on the SAME tile: wave w scans code
+//                 tiles w, w+4, ... of each level, the per-item (distance, index) candidates meet in LDS, and every
+//                 one of the four then finishes the level redundantly (gather, loss, output: cheap next to a scan;
+//                 no hand-over of the next residual), wave 0 stores.  They synchronise through an LDS counter per
+//                 level, not s_barrier, so the other waves of the workgroup are not involved.  Used (a) for small
+//                 batches (at most two row tiles per CU, e.g. the reference's batch 640), where one wave per tile
+//                 would leave most SIMDs empty, and (b) for the partly filled last round of a big batch, whose
+//                 tiles would otherwise each put a whole extra tile on one SIMD (+17 us for 53 of 3125 tiles).
 // FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
 template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP>
 __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
                                         long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase) {
     constexpr int KQ = KSTEPS / 4;
-    constexpr int kWaves = NT / RQ_WAVE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int il = lane & 31, h = lane >> 5;
     const int K = p.K, Kc = p.Kc, L = p.L;
@@ -380,45 +387,51 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             }
             if (active)
                 scan_codes<KSTEPS>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r, xsq,
-                                   best, bidx, COOP ? wave : 0, COOP ? kWaves : 1);
+                                   best, bidx, COOP ? wave : 0, COOP ? kCoopWaves : 1);
         }
 
         RQ_STAMP(3 + 8 * l);
+        // lanes (il,0) and (il,1) scanned disjoint code subsets: keep the smaller, ties -> lower index
+        // (lexicographic (distance, index) minimum == first-index argmin over the union)
+        if (active) {
+            const float ob = shfl_xor32(best);
+            const int oi = shfl_xor32(bidx);
+            if (ob < best || (ob == best && oi < bidx)) {
+                best = ob;
+                bidx = oi;
+            }
+        }
         if (COOP) {
-            // candidates of all waves and both lane halves meet in LDS (double-buffered by level parity: one barrier
-            // per level); lexicographic (distance, index) minimum == first-index argmin over the whole codebook
-            // (`phase` counts levels across consecutive cooperative tiles, so the parity keeps alternating)
-            float *cv = cand_s + ((phase + l) & 1) * (2 * NT);
-            int *ci = reinterpret_cast<int *>(cv + NT);
-            cv[threadIdx.x] = best;
-            ci[threadIdx.x] = bidx;
-            __syncthreads();
+            // the four waves' candidates meet in LDS, double-buffered by level parity; `phase` counts levels across
+            // consecutive cooperative tiles so that parity and counter index keep advancing.  Counter (phase+l) is
+            // used exactly once: it reaches kCoopWaves when every wave has published its candidates.
+            const int step = phase + l;
+            float *cv = cand_s + (step & 1) * (2 * kCoopWaves * 32);
+            int *ci = reinterpret_cast<int *>(cv + kCoopWaves * 32);
+            int *cnt = reinterpret_cast<int *>(cand_s + 4 * kCoopWaves * 32);
+            if (h == 0) {
+                cv[wave * 32 + il] = best;
+                ci[wave * 32 + il] = bidx;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(&cnt[step & (kCoopSteps - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&cnt[step & (kCoopSteps - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCoopWaves)
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             best = __builtin_inff();
             bidx = 0x7fffffff;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const float ov = cv[w * 64 + hh * 32 + il];
-                    const int oi = ci[w * 64 + hh * 32 + il];
-                    if (ov < best || (ov == best && oi < bidx)) {
-                        best = ov;
-                        bidx = oi;
-                    }
-                }
-            }
-        }
-        const bool do_tail = active && (!COOP || wave == 0);  // cooperative tiles: wave 0 finishes the level alone
-        if (do_tail) {
-            if (!COOP) {
-                // lanes (il,0) and (il,1) scanned disjoint code subsets: keep the smaller, ties -> lower index
-                const float ob = shfl_xor32(best);
-                const int oi = shfl_xor32(bidx);
-                if (ob < best || (ob == best && oi < bidx)) {
-                    best = ob;
+            for (int w = 0; w < kCoopWaves; ++w) {
+                const float ov = cv[w * 32 + il];
+                const int oi = ci[w * 32 + il];
+                if (ov < best || (ov == best && oi < bidx)) {
+                    best = ov;
                     bidx = oi;
                 }
             }
+        }
+        const bool do_tail = active;
+        if (do_tail) {
             if (bidx == 0x7fffffff) bidx = 0;  // every distance was +Inf: torch.min keeps index 0
             // rows whose distances can be Inf/NaN take torch's exact scan
             // fast path only when no distance term can overflow (then fma(-2,acc,tt) == tt - 2*acc exactly)
@@ -495,20 +508,6 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 r[kk] = r[kk] - o[kk];  // rqvae.py:130
             }
         }
-        if (COOP && l + 1 < L) {
-            // the next level's residual goes from wave 0 to the other waves through LDS (one slot per lane and
-            // register; the candidate barrier of the next level orders these reads before the next write)
-            float *rx = cand_s + 4 * NT;
-            if (wave == 0) {
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) rx[kk * 64 + lane] = r[kk];
-            }
-            __syncthreads();
-            if (wave != 0) {
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) r[kk] = rx[kk * 64 + lane];
-            }
-        }
     }
 
     RQ_STAMP(100);
@@ -558,25 +557,15 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     // per-level max codebook norm (Inf/NaN guard) lives in LDS: no global load inside the level loop, so the
     // in-order vmcnt counter never makes a level wait for the previous level's stores
     float *csqmax_s = smem + (p.resident ? L : 1) * buf_floats;
-    float *cand_s = csqmax_s + 16;  // [2][2*NT]: cooperative-tile candidates
+    float *cand_s = csqmax_s + 16;  // cooperative-tile candidates and counters (kCoopLdsFloats)
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
+    if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 4 * kCoopWaves * 32)[tid] = 0;
     if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
     __syncthreads();
     RQ_TRACE(1);
     int trace_slot = 2;
     (void)trace_slot;
 
-    // cooperative tiles first (resident mode only), one per workgroup at a time: the waves of a workgroup are
-    // in step right after the staging barrier, so nobody waits for a straggler of a full round
-    int phase = 0;
-    for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        float r[KSTEPS];
-        load_rows(tile, r);
-        rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
-        phase += L;
-        RQ_TRACE(trace_slot);
-        ++trace_slot;
-    }
     // full rounds: one tile per wave
     for (int it = 0; it < p.n_iter; ++it) {
         const long long tile = (long long)it * total_waves + wave_slot;
@@ -589,6 +578,19 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
         rq_tile<KSTEPS, MODE, FULLD, NT, false>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
         RQ_TRACE(trace_slot);
         ++trace_slot;
+    }
+    // cooperative tiles (resident mode only), one per workgroup at a time, by the first four waves -- the oldest
+    // wave of each SIMD, which finishes its own tile of a full round first
+    if (wave < kCoopWaves) {
+        int phase = 0;
+        for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+            float r[KSTEPS];
+            load_rows(tile, r);
+            rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
+            phase += L;
+            RQ_TRACE(trace_slot);
+            ++trace_slot;
+        }
     }
 }
 
@@ -698,19 +700,18 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     p.embs_norm = embs_norm;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
     const size_t level_bytes = (size_t)Kp * (Dp + 1) * sizeof(float);
-    if (level_bytes * L + 64 + (4 * 768 + 64 * ksteps) * sizeof(float) <= (size_t)kLdsBudget) {
+    if (level_bytes * L + 64 + kCoopLdsFloats * sizeof(float) <= (size_t)kLdsBudget) {
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
         p.resident = 0;
-        int kc = (int)(((size_t)kLdsBudget / 2 - 64) / ((size_t)(Dp + 1) * sizeof(float)));  // <= 80 KiB: 2 WG/CU
+        int kc = (int)(((size_t)kLdsBudget / 2 - 64 - kCoopLdsFloats * sizeof(float)) / ((size_t)(Dp + 1) * sizeof(float)));  // <= 80 KiB: 2 WG/CU
         kc &= ~63;
         if (kc > Kp) kc = Kp;
         if (kc < 64) kc = 64;
         p.Kc = kc; p.nchunks = (Kp + kc - 1) / kc;
     }
-    const int nt_threads = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256);
     const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1) + 16 * sizeof(float) +
-                       (size_t)(4 * nt_threads + 64 * ksteps) * sizeof(float);
+                       (size_t)kCoopLdsFloats * sizeof(float);
     const int cus = cu_count();
     const int wg_per_cu = (lds * 2 <= (size_t)kLdsBudget) ? 2 : 1;
     const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
@@ -721,13 +722,12 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     if (all_coop) want = p.n_tiles;
     const int grid = (int)(want < cap ? want : cap);
     const long long total_waves = (long long)grid * waves_per_wg;
-    // a partly filled last round (53 tiles at 100 000 rows) would run as lone waves, one per CU, for a whole tile
-    // time: when it is at most one tile per workgroup it is done cooperatively instead, BEFORE the full rounds
-    // (after them the workgroup would first have to wait for its slowest wave: measured, no gain)
+    // a partly filled last round (53 of 3125 tiles at 100 000 rows) puts a whole extra tile on one SIMD of each CU it
+    // lands on; when it is at most one tile per workgroup it is done cooperatively instead, a quarter per SIMD
     p.coop_first = all_coop ? 0 : p.n_tiles;
-    if (!all_coop && p.resident && getenv("RQ_COOP_HEAD")) {
+    if (!all_coop && p.resident && !getenv("RQ_NO_COOP_TAIL")) {
         const long long rem = p.n_tiles % total_waves;
-        if (rem > 0 && rem <= (long long)grid * atoi(getenv("RQ_COOP_HEAD"))) p.coop_first = p.n_tiles - rem;
+        if (rem > 0 && rem <= grid) p.coop_first = p.n_tiles - rem;
     }
     p.n_iter = (int)((p.coop_first + total_waves - 1) / total_waves);
 
