@@ -704,7 +704,8 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
         p.resident = 0;
-        int kc = (int)(((size_t)kLdsBudget / 2 - 64 - kCoopLdsFloats * sizeof(float)) / ((size_t)(Dp + 1) * sizeof(float)));  // <= 80 KiB: 2 WG/CU
+        // one workgroup per CU (its waves fill the register file), so a chunk may use the whole LDS
+        int kc = (int)(((size_t)kLdsBudget - 64 - kCoopLdsFloats * sizeof(float)) / ((size_t)(Dp + 1) * sizeof(float)));
         kc &= ~63;
         if (kc > Kp) kc = Kp;
         if (kc < 64) kc = 64;
@@ -713,7 +714,7 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1) + 16 * sizeof(float) +
                        (size_t)kCoopLdsFloats * sizeof(float);
     const int cus = cu_count();
-    const int wg_per_cu = (lds * 2 <= (size_t)kLdsBudget) ? 2 : 1;
+    const int wg_per_cu = 1;  // 768 / 512 / 256 threads at <= 168 / 256 / 512 VGPRs: one workgroup fills a CU
     const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
     long long cap = (long long)cus * wg_per_cu;
