@@ -256,6 +256,50 @@ __device__ __forceinline__ float rq_min3(float a, float b, float c) {
     return r;
 }
 
+
+// ---- row <-> "pair layout" conversion for the full-width kernels (D == 2*KSTEPS) ------------------------------
+// The MFMA B operand wants lane (il, h) to hold the features d = 2 kk + h of row il.  Loading them directly makes every
+// load/store instruction touch 32 cache lines 4 bytes at a time (16 instructions per 128-byte row).  Instead each
+// lane half moves one contiguous half of the row as float4s -- lane (il,0) bytes [0, 2D), lane (il,1) bytes [2D, 4D)
+// -- and the two halves trade the components of the wrong parity with v_permlane32_swap (gfx950): a quarter of the
+// memory instructions, 16 bytes per lane each.
+//   raw[4j+c]  (before) : lane (il,h) holds feature h*KSTEPS + 4j + c
+//   swap(raw[4j+0], raw[4j+1]) -> r[2j],   r[KSTEPS/2 + 2j]      swap(raw[4j+2], raw[4j+3]) -> r[2j+1], r[KSTEPS/2 + 2j+1]
+// The swap is its own inverse, so the same two instructions turn pair-layout registers back into row chunks.
+__device__ __forceinline__ void rq_swap32(float a, float b, float &a_out, float &b_out) {
+    // a_out = {lanes 0-31: a, lanes 32-63: b of lane-32};  b_out = {lanes 0-31: a of lane+32, lanes 32-63: b}
+    // (inline asm: with __builtin_amdgcn_permlane32_swap this compiler drops the second result when two swaps
+    // share a source register; the s_nop covers the VALU-write -> permlane-swap hazard the assembler cannot see)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a_out = a;
+    b_out = b;
+}
+template <int KSTEPS>
+__device__ __forceinline__ void rows_to_pairs(const float (&raw)[KSTEPS], float (&r)[KSTEPS]) {
+#pragma unroll
+    for (int j = 0; j < KSTEPS / 4; ++j) {
+        rq_swap32(raw[4 * j + 0], raw[4 * j + 1], r[2 * j], r[KSTEPS / 2 + 2 * j]);
+        rq_swap32(raw[4 * j + 2], raw[4 * j + 3], r[2 * j + 1], r[KSTEPS / 2 + 2 * j + 1]);
+    }
+}
+template <int KSTEPS>
+__device__ __forceinline__ void pairs_to_rows(const float (&r)[KSTEPS], float (&raw)[KSTEPS]) {
+#pragma unroll
+    for (int j = 0; j < KSTEPS / 4; ++j) {
+        rq_swap32(r[2 * j], r[KSTEPS / 2 + 2 * j], raw[4 * j + 0], raw[4 * j + 1]);
+        rq_swap32(r[2 * j + 1], r[KSTEPS / 2 + 2 * j + 1], raw[4 * j + 2], raw[4 * j + 3]);
+    }
+}
+// store KSTEPS pair-layout registers of this lane as its half of row `dst_row` (dst_row = base + row*D, 16-byte aligned)
+template <int KSTEPS>
+__device__ __forceinline__ void store_pair_row(float *dst_row, int h, const float (&r)[KSTEPS]) {
+    float raw[KSTEPS];
+    pairs_to_rows<KSTEPS>(r, raw);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(dst_row + h * KSTEPS);
+#pragma unroll
+    for (int j = 0; j < KSTEPS / 4; ++j) dst[j] = f32x4{raw[4 * j], raw[4 * j + 1], raw[4 * j + 2], raw[4 * j + 3]};
+}
+
 template <int KSTEPS>
 __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
                                            int kbase, int il, int h, const float (&x)[KSTEPS], float xsq,
@@ -362,8 +406,9 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
     // running output pointers of this lane (advanced per level: no 64-bit multiplies inside the level loop)
     int64_t *ids_ptr = p.ids + row;
     float *norm_ptr = p.embs_norm ? p.embs_norm + (size_t)row * L : nullptr;
-    float *embs_ptr = p.embs ? p.embs + (size_t)row * D + h : nullptr;
-    float *resid_ptr = p.residuals ? p.residuals + (size_t)row * D + h : nullptr;
+    // (full-width kernels store float4 row chunks: pointer to the row; otherwise to this lane's first feature)
+    float *embs_ptr = p.embs ? p.embs + (size_t)row * D + (FULLD ? 0 : h) : nullptr;
+    float *resid_ptr = p.residuals ? p.residuals + (size_t)row * D + (FULLD ? 0 : h) : nullptr;
     RQ_STAMP(1);
 
     for (int l = 0; l < L; ++l) {
@@ -489,14 +534,22 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                     if (h == 0) norm_ptr[l] = onorm;
                 }
                 if (resid_ptr) {
+                    if (FULLD) {
+                        store_pair_row<KSTEPS>(resid_ptr, h, r);
+                    } else {
 #pragma unroll
-                    for (int kk = 0; kk < KSTEPS; ++kk)
-                        if (FULLD || 2 * kk + h < D) resid_ptr[2 * kk] = r[kk];
+                        for (int kk = 0; kk < KSTEPS; ++kk)
+                            if (2 * kk + h < D) resid_ptr[2 * kk] = r[kk];
+                    }
                 }
                 if (embs_ptr) {
+                    if (FULLD) {
+                        store_pair_row<KSTEPS>(embs_ptr, h, o);
+                    } else {
 #pragma unroll
-                    for (int kk = 0; kk < KSTEPS; ++kk)
-                        if (FULLD || 2 * kk + h < D) embs_ptr[2 * kk] = o[kk];
+                        for (int kk = 0; kk < KSTEPS; ++kk)
+                            if (2 * kk + h < D) embs_ptr[2 * kk] = o[kk];
+                    }
                 }
             }
             ids_ptr += p.B;
@@ -514,10 +567,14 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
     if (writer) {
         if (h == 0 && p.loss) p.loss[row] = lsum;
         if (p.emb_sum) {
-            float *dst = p.emb_sum + (size_t)row * D + h;
+            if (FULLD) {
+                store_pair_row<KSTEPS>(p.emb_sum + (size_t)row * D, h, es);
+            } else {
+                float *dst = p.emb_sum + (size_t)row * D + h;
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk)
-                if (FULLD || 2 * kk + h < D) dst[2 * kk] = es[kk];
+                for (int kk = 0; kk < KSTEPS; ++kk)
+                    if (2 * kk + h < D) dst[2 * kk] = es[kk];
+            }
         }
     }
     RQ_STAMP(101);
@@ -542,12 +599,31 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     // filled last round spreads over all CUs instead of filling the first workgroups only
     const long long wave_slot = (long long)wave * gridDim.x + blockIdx.x;
 
+    // rows of a tile as this lane fetches them: full-width kernels take their half of the row as float4s ("raw",
+    // see rows_to_pairs), the others their features d = 2 kk + h one by one
     auto load_rows = [&](long long tile, float(&v)[KSTEPS]) {
         const long long row = tile * 32 + il;
         const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
-        const float *src = p.res0 + (size_t)rowc * D + h;
+        if (FULLD) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.res0 + (size_t)rowc * D + h * KSTEPS);
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) v[kk] = (FULLD || 2 * kk + h < D) ? src[2 * kk] : 0.0f;
+            for (int j = 0; j < KSTEPS / 4; ++j) {
+                const f32x4 q = src[j];
+                v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+            }
+        } else {
+            const float *src = p.res0 + (size_t)rowc * D + h;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) v[kk] = (2 * kk + h < D) ? src[2 * kk] : 0.0f;
+        }
+    };
+    auto unpack_rows = [&](const float(&raw)[KSTEPS], float(&v)[KSTEPS]) {
+        if (FULLD) {
+            rows_to_pairs<KSTEPS>(raw, v);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) v[kk] = raw[kk];
+        }
     };
 
     RQ_STAMP(0);
@@ -560,8 +636,11 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     float *cand_s = csqmax_s + 16;  // cooperative-tile candidates and counters (kCoopLdsFloats)
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
     if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 4 * kCoopWaves * 32)[tid] = 0;
+    RQ_STAMP(200);
     if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
+    RQ_STAMP(201);
     __syncthreads();
+    RQ_STAMP(202);
     RQ_TRACE(1);
     int trace_slot = 2;
     (void)trace_slot;
@@ -572,8 +651,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
         const bool active = tile < p.coop_first;
         if (p.resident && !active) break;
         float r[KSTEPS];
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) r[kk] = rn[kk];
+        unpack_rows(rn, r);
         if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
         rq_tile<KSTEPS, MODE, FULLD, NT, false>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
         RQ_TRACE(trace_slot);
@@ -584,8 +662,9 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     if (wave < kCoopWaves) {
         int phase = 0;
         for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-            float r[KSTEPS];
-            load_rows(tile, r);
+            float raw[KSTEPS], r[KSTEPS];
+            load_rows(tile, raw);
+            unpack_rows(raw, r);
             rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
             phase += L;
             RQ_TRACE(trace_slot);
@@ -632,7 +711,9 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
         RQ_CHECK_LAUNCH("rq_forward_kernel");
         return 0;
     };
-    const bool full = p.D == 2 * KSTEPS;
+    // full-width kernels move rows as float4s: every row pointer must be 16-byte aligned (rows are 8*KSTEPS bytes)
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool full = p.D == 2 * KSTEPS && al16(p.res0) && al16(p.embs) && al16(p.residuals) && al16(p.emb_sum);
     switch (mode) {
         case RQHIP_MODE_EVAL:
             return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_EVAL, true, NT>)

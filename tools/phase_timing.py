@@ -45,12 +45,12 @@ for _ in range(3):
 buf = (C.c_ulonglong * 256)()
 assert lib.rqhip_debug_read(buf) == 0
 t0 = buf[0]
-names = {0: "kernel start", 1: "x loaded (after staging)", 100: "levels done", 101: "final stores issued"}
+names = {200: "rows requested", 201: "staging issued (own part)", 202: "staging barrier passed", 0: "kernel start", 1: "x loaded (after staging)", 100: "levels done", 101: "final stores issued"}
 for l in range(L):
     names.update({2 + 8 * l: f"L{l} start", 3 + 8 * l: f"L{l} scan done", 4 + 8 * l: f"L{l} argmin merged",
                   5 + 8 * l: f"L{l} gather+loss done", 6 + 8 * l: f"L{l} output math done"})
 prev = t0
-for i in sorted(names):
+for i in sorted(names, key=lambda i: buf[i]):
     if buf[i]:
         print(f"{names[i]:28s} +{buf[i] - t0:8d} ticks  (delta {buf[i] - prev:7d})")
         prev = buf[i]
