@@ -89,6 +89,25 @@ def test_forward_all_equal_rows_and_zero_codebook():
     assert (got["ids"] == 0).all()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_forward_rows_not_16_byte_aligned(mode):
+    """The full-width kernels move rows as float4s; a contiguous view that starts 4 bytes into its storage must
+    take the element-wise path and give the same bits."""
+    from rqhip import ops
+    rng = np.random.default_rng(21)
+    B, D, K, L = 333, 32, 256, 3
+    x = (rng.standard_normal((B, D)) * 0.6).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, D)) * 0.4).astype(np.float32)
+    store = torch.zeros(B * D + 1, dtype=torch.float32, device="cuda")
+    xv = store[1:].view(B, D)
+    xv.copy_(_gpu(x))
+    assert xv.data_ptr() % 16 == 4 and xv.is_contiguous()
+    out = ops.rq_forward(xv, _gpu(cbs), mode, 0.25)
+    ref = o.rq_forward(x, cbs, mode, 0.25)
+    for k in ("ids", "embs", "residuals", "emb_sum", "loss", "embs_norm"):
+        _assert_bitexact(getattr(out, k).cpu().numpy(), ref[k], f"{k} (unaligned rows, mode {mode})")
+
+
 def test_forward_empty_batch():
     got = _run_forward(np.zeros((0, 32), np.float32), np.ones((3, 256, 32), np.float32), 1)
     assert got["ids"].shape == (3, 0) and got["loss"].shape == (0,)

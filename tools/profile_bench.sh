@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 900 -- 'bash tools/profile_bench.sh'
+# Pass 1: --kernel-trace --stats of the default bench (no CPU baseline leg).  Passes 2, 3: one PMC counter each
+# (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only -- never combined with sys/hip traces.  Outputs under
+# gpurun_out/prof_r01/; tools/summarize_profile.py turns them into the files committed under profiles/.
+set -u
+REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$REPO/gpurun_out/prof_r01"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 python "$REPO/bench.py" --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench -- \
+    python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o pmc -- \
+        python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$c.err"
+done
+find "$OUT" -name "*.csv" | sed "s#$REPO/##"
+tail -c 600 "$OUT/bench_n1.json"

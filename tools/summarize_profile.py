@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_r01/ (written by tools/profile_bench.sh on the GPU box) into the committed evidence:
+   profiles/r01_bench_kernel_stats.csv, r01_bench_kernel_stats_summary.txt, r01_bench_n1.json, r01_pmc_traffic.json
+usage: python tools/summarize_profile.py [gpurun_out/prof_r01]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r01")
+DST = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(SRC, pattern), recursive=True))
+    if not hits:
+        raise SystemExit(f"missing {pattern} under {SRC}")
+    return hits[-1]
+
+
+bench = json.loads(open(os.path.join(SRC, "bench_n1.json")).read().strip().splitlines()[-1])
+with open(os.path.join(DST, "r01_bench_n1.json"), "w") as f:
+    f.write(json.dumps(bench) + "\n")
+
+stats = one("stats/**/*kernel_stats.csv")
+shutil.copyfile(stats, os.path.join(DST, "r01_bench_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(DST, "r01_bench_kernel_stats_summary.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (MI355X, round 1)\n")
+    f.write(f"# bench line of the same build: profiles/r01_bench_n1.json ({bench['value'] / 1e6:.2f} M items/s, "
+            f"{bench['ms_per_step']:.2f} ms/step; roofline launch mean {bench['roofline']['launch_ms_mean'] * 1e3:.1f} us by HIP events)\n")
+    f.write("# top kernels by total time; names shortened; full CSV: r01_bench_kernel_stats.csv\n\n")
+    f.write(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}\n")
+    for r in rows[:40]:
+        f.write(f"{r['Name'][:70]:70s} {int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.1f} "
+                f"{float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f}\n")
+    ours = [r for r in rows if "rqhip::" in r["Name"]]
+    f.write("\n# hand-written kernels (librqhip.so)\n")
+    for r in ours:
+        f.write(f"{r['Name'][:70]:70s} {int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.1f} "
+                f"{float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f}\n")
+
+pmc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 5 "
+                  "--warmup 2 --no-cpu-baseline   (tools/profile_bench.sh)",
+       "note": "KB per launch; max = the B=100000 launches (mean includes the 20000-row k-means warm-up launch). gfx950 "
+               "correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE under-reports coalesced streaming reads by "
+               "2x -> doubled by the consumer (bench.py); WRITE_SIZE uncorrected.",
+       "kernels": {}}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    path = one(f"pmc_{counter}/**/*counter_collection.csv")
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if "rqhip::" not in r["Kernel_Name"] or r["Counter_Name"] != counter:
+            continue
+        per.setdefault(r["Kernel_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+        per[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])  # one row per XCD/dimension: sum
+    for name, d in per.items():
+        vals = list(d.values())
+        k = pmc["kernels"].setdefault(name, {})
+        k[f"{counter}_KB_max"] = max(vals)
+        k[f"{counter}_KB_mean"] = sum(vals) / len(vals)
+        k["launches_fetch" if counter == "FETCH_SIZE" else "launches_write"] = len(vals)
+fwk = [k for k in pmc["kernels"] if "rq_forward_kernel" in k and "FETCH_SIZE_KB_max" in pmc["kernels"][k]
+       and "WRITE_SIZE_KB_max" in pmc["kernels"][k]]
+if fwk:
+    v = pmc["kernels"][fwk[0]]
+    rows = bench["config"]["rows_per_gpu_per_step"]
+    corrected = (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024.0
+    algorithmic = bench["roofline"]["hbm_view"]["algorithmic_bytes_per_row"] * rows
+    pmc["rq_forward_kernel"] = {"rows_per_launch": rows, "hbm_bytes_per_launch_corrected": corrected,
+                                "algorithmic_bytes_per_launch": algorithmic, "ratio": corrected / algorithmic}
+with open(os.path.join(DST, "r01_pmc_traffic.json"), "w") as f:
+    json.dump(pmc, f, indent=1)
+    f.write("\n")
+fw = [k for k in pmc["kernels"] if "rq_forward_kernel" in k]
+for k in fw:
+    v = pmc["kernels"][k]
+    print(k, "-> traffic per launch (2*FETCH+WRITE) =", (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024 / 1e6, "MB")
+print("wrote profiles/r01_*")
