@@ -10,11 +10,20 @@ OUT="$REPO/gpurun_out/prof_r01"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 python "$REPO/bench.py" --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench -- \
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
     python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o pmc -- \
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
         python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$c.err"
 done
+# keep what summarize_profile.py reads (gpurun copies back at most 64 MiB): the stats table, and the counter rows
+# of the hand-written kernels; drop the per-dispatch traces
+for f in $(find "$OUT" -name "*counter_collection.csv"); do
+    { head -1 "$f"; grep "rqhip::" "$f"; } > "$f.tmp" && mv "$f.tmp" "$f"
+done
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
+find "$OUT" -name "*.csv" -size +8M -delete
+du -sh "$OUT"; tail -3 "$OUT/stats.err"
 find "$OUT" -name "*.csv" | sed "s#$REPO/##"
 tail -c 600 "$OUT/bench_n1.json"
