@@ -144,10 +144,15 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
 // registers (L * KSTEPS values per lane) and each row's codeword-gradient vectors go straight into the
 // workgroup's LDS tables: no [L,B,D] round trip through HBM.  Per row: reads res0, ids, upstream gradients
 // (12D + 8L bytes), writes g_res0 (4D) -- the algorithmic traffic of SURVEY.md 8d.
+#ifndef RQ_BWD_ATOMICS
+#define RQ_BWD_ATOMICS 1  // developer switch (tools/): 0 removes the LDS scatter to time the rest
+#endif
 constexpr int kFusedMaxL = 4;
 constexpr int kFusedThreads = 512;
 
-template <int KSTEPS, int MODE>
+// VEC: D == 2*KSTEPS and every row pointer 16-byte aligned -> rows and codewords move as float4 half-rows +
+// v_permlane32_swap (rq_rowmath.h) instead of 4 bytes per lane and instruction.
+template <int KSTEPS, int MODE, bool VEC>
 __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const RqBwdParams p, float *__restrict__ partial,
                                                                          int LKD_total) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
@@ -170,17 +175,22 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
         const long long rc = ok ? row : p.B - 1;
 
         float rl[kFusedMaxL][KSTEPS];
-        float e[KSTEPS], o[KSTEPS];
+        float el[kFusedMaxL][KSTEPS];  // the codeword of every level, gathered once
+        float o[KSTEPS];
         int idl[kFusedMaxL];
-        load_pair_row<KSTEPS>(p.res0 + (size_t)rc * D, D, h, rl[0]);
+        auto fetch = [&](const float *row_base, float(&v)[KSTEPS]) {
+            if (VEC) load_pair_row_vec<KSTEPS>(row_base, h, v);
+            else load_pair_row<KSTEPS>(row_base, D, h, v);
+        };
+        fetch(p.res0 + (size_t)rc * D, rl[0]);
 #pragma unroll
         for (int l = 0; l < kFusedMaxL; ++l) {
             if (l < L) {
                 idl[l] = (int)p.ids[(size_t)l * p.B + rc];
+                fetch(p.cb + ((size_t)l * K + idl[l]) * D, el[l]);
                 if (l + 1 < L) {
-                    load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + idl[l]) * D, D, h, e);
                     const float xsq = (MODE == RQHIP_MODE_ROTATION) ? pair_sumsq<KSTEPS>(rl[l]) : 0.0f;
-                    level_output<KSTEPS, MODE>(rl[l], e, xsq, o);
+                    level_output<KSTEPS, MODE>(rl[l], el[l], xsq, o);
 #pragma unroll
                     for (int kk = 0; kk < KSTEPS; ++kk)
                         if (l + 1 < kFusedMaxL) rl[(l + 1 < kFusedMaxL) ? l + 1 : 0][kk] = rl[l][kk] - o[kk];
@@ -192,24 +202,28 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             G[kk] = 0.0f;
-            const int d = 2 * kk + h;
-            gs[kk] = (p.g_embsum && d < D) ? p.g_embsum[(size_t)rc * D + d] : 0.0f;
+            gs[kk] = 0.0f;
         }
+        if (p.g_embsum) fetch(p.g_embsum + (size_t)rc * D, gs);
 #pragma unroll
         for (int l = kFusedMaxL - 1; l >= 0; --l) {
             if (l < L) {
                 const float(&r)[KSTEPS] = rl[l];
-                load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + idl[l]) * D, D, h, e);
+                const float(&e)[KSTEPS] = el[l];
                 const size_t lrow = ((size_t)l * p.B + rc) * D;
                 float A[KSTEPS], gr[KSTEPS];
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
-                    const int d = 2 * kk + h;
-                    float a = 0.0f;
-                    if (p.g_embs && d < D) a = p.g_embs[lrow + d];
+                    A[kk] = 0.0f;
+                    gr[kk] = 0.0f;
+                }
+                if (p.g_embs) fetch(p.g_embs + lrow, A);
+                if (p.g_resid) fetch(p.g_resid + lrow, gr);
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    float a = A[kk];
                     if (p.g_embsum) a = a + gs[kk];
                     A[kk] = a - G[kk];
-                    gr[kk] = (p.g_resid && d < D) ? p.g_resid[lrow + d] : 0.0f;
                 }
                 float *tab = acc + (size_t)(l * K + idl[l]) * stride + h;
                 if (MODE == RQHIP_MODE_ROTATION) {
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                         const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
                         const float embg = (2.0f * (e[kk] - r[kk])) * gl;
                         G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
-                        if (p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                        if (RQ_BWD_ATOMICS && p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
                     }
                 } else {
 #pragma unroll
@@ -233,20 +247,24 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                         if (MODE == RQHIP_MODE_EVAL) {
                             const float contrib = A[kk] + embg;
                             G[kk] = (gr[kk] + G[kk]) + commit;
-                            if (p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, contrib);
+                            if (RQ_BWD_ATOMICS && p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, contrib);
                         } else {
                             G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
-                            if (p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                            if (RQ_BWD_ATOMICS && p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
                         }
                     }
                 }
             }
         }
         if (ok && p.g_res0) {
+            if (VEC) {
+                store_pair_row<KSTEPS>(p.g_res0 + (size_t)row * D, h, G);
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const int d = 2 * kk + h;
-                if (d < D) p.g_res0[(size_t)row * D + d] = G[kk];
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const int d = 2 * kk + h;
+                    if (d < D) p.g_res0[(size_t)row * D + d] = G[kk];
+                }
             }
         }
     }
@@ -417,11 +435,23 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
             return 0;
         };
         int rcf = RQHIP_EARG;
-#define RQ_FUSED_MODES(KS)                                                                          \
-    switch (mode) {                                                                                 \
-        case RQHIP_MODE_EVAL: rcf = go(rq_backward_fused_kernel<KS, RQHIP_MODE_EVAL>); break;        \
-        case RQHIP_MODE_STE: rcf = go(rq_backward_fused_kernel<KS, RQHIP_MODE_STE>); break;          \
-        default: rcf = go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION>); break;                 \
+        auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+        const bool vec = D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) &&
+                         al16(g_resid) && al16(g_res0);
+#define RQ_FUSED_MODES(KS)                                                                                            \
+    switch (mode) {                                                                                                   \
+        case RQHIP_MODE_EVAL:                                                                                         \
+            rcf = vec ? go(rq_backward_fused_kernel<KS, RQHIP_MODE_EVAL, true>)                                       \
+                      : go(rq_backward_fused_kernel<KS, RQHIP_MODE_EVAL, false>);                                     \
+            break;                                                                                                    \
+        case RQHIP_MODE_STE:                                                                                          \
+            rcf = vec ? go(rq_backward_fused_kernel<KS, RQHIP_MODE_STE, true>)                                        \
+                      : go(rq_backward_fused_kernel<KS, RQHIP_MODE_STE, false>);                                      \
+            break;                                                                                                    \
+        default:                                                                                                      \
+            rcf = vec ? go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION, true>)                                   \
+                      : go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION, false>);                                 \
+            break;                                                                                                    \
     }
         switch (ksteps_for(D)) {
             case 4: RQ_FUSED_MODES(4) break;
