@@ -30,6 +30,9 @@ struct RqBwdParams {
     long long B, n_tiles;
     int D, L, K;
     float beta;
+    // fused kernel only: this launch scatters the codeword gradients of levels [l_begin, l_end) (the ones whose tables
+    // fit LDS together) and writes g_res0 iff write_rows
+    int l_begin, l_end, write_rows;
 };
 
 template <int KSTEPS, int MODE>
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int D = p.D, L = p.L, K = p.K;
     const int stride = D + 1;
-    const int tbl = L * K * stride;
+    const int tbl = (p.l_end - p.l_begin) * K * stride;
     if (p.g_cb)
         for (int e = threadIdx.x; e < tbl; e += kFusedThreads) acc[e] = 0.0f;
     __syncthreads();
@@ -225,7 +228,8 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                     if (p.g_embsum) a = a + gs[kk];
                     A[kk] = a - G[kk];
                 }
-                float *tab = acc + (size_t)(l * K + idl[l]) * stride + h;
+                const bool mine = p.g_cb && ok && l >= p.l_begin && l < p.l_end;  // this launch owns level l's table
+                float *tab = acc + (size_t)((l - p.l_begin) * K + idl[l]) * stride + h;
                 if (MODE == RQHIP_MODE_ROTATION) {
                     float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
                     const float xsq = pair_sumsq<KSTEPS>(r);
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                         const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
                         const float embg = (2.0f * (e[kk] - r[kk])) * gl;
                         G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
-                        if (RQ_BWD_ATOMICS && p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                        if (RQ_BWD_ATOMICS && mine && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
                     }
                 } else {
 #pragma unroll
@@ -247,16 +251,16 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                         if (MODE == RQHIP_MODE_EVAL) {
                             const float contrib = A[kk] + embg;
                             G[kk] = (gr[kk] + G[kk]) + commit;
-                            if (RQ_BWD_ATOMICS && p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, contrib);
+                            if (RQ_BWD_ATOMICS && mine && 2 * kk + h < D) atomicAdd(tab + 2 * kk, contrib);
                         } else {
                             G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
-                            if (RQ_BWD_ATOMICS && p.g_cb && ok && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                            if (RQ_BWD_ATOMICS && mine && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
                         }
                     }
                 }
             }
         }
-        if (ok && p.g_res0) {
+        if (ok && p.g_res0 && p.write_rows) {
             if (VEC) {
                 store_pair_row<KSTEPS>(p.g_res0 + (size_t)row * D, h, G);
             } else {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
     if (p.g_cb) {
         __syncthreads();
         float *out = partial + (size_t)blockIdx.x * LKD_total;
-        for (int e2 = threadIdx.x; e2 < L * K * D; e2 += kFusedThreads) {
+        for (int e2 = threadIdx.x; e2 < (p.l_end - p.l_begin) * K * D; e2 += kFusedThreads) {
             const int kd = e2 / D, dd = e2 - kd * D;
             out[e2] = acc[(size_t)kd * stride + dd];
         }
@@ -341,7 +345,12 @@ static int fused_wgs(long long B) {
 
 // register budget: L * KSTEPS residual values per lane -> D <= 32 (KSTEPS <= 16) only
 static bool fused_fits(int D, int K, int L) {
-    return D <= 32 && L <= kFusedMaxL && (size_t)L * K * (D + 1) * sizeof(float) <= kScatterLdsBudget;
+    return D <= 32 && L <= kFusedMaxL && (size_t)K * (D + 1) * sizeof(float) <= kScatterLdsBudget;
+}
+// levels whose LDS tables fit together: the fused kernel runs once per such group
+static int fused_levels_per_pass(int D, int K, int L) {
+    int n = (int)(kScatterLdsBudget / ((size_t)K * (D + 1) * sizeof(float)));
+    return n < 1 ? 1 : (n > L ? L : n);
 }
 
 static int scatter_wgs(long long B) {
@@ -420,24 +429,33 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     p.atomic_scatter = lds_path ? 0 : 1;
     if (fused_fits(D, K, L)) {
         const int G = fused_wgs(B);
-        const int LKD = L * K * D;
         float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
-        const size_t lds = g_codebooks ? (size_t)L * K * (D + 1) * sizeof(float) : 0;
-        auto go = [&](auto kern) -> int {
-            static bool attr = false;
-            if (!attr) {
-                RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScatterLdsBudget));
-                attr = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD);
-            RQ_CHECK_LAUNCH("rq_backward_fused_kernel");
-            return 0;
-        };
-        int rcf = RQHIP_EARG;
         auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
         const bool vec = D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) &&
                          al16(g_resid) && al16(g_res0);
+        // one launch per group of levels whose tables fit LDS together (all of them for 3 x 256 x 32; one level at a
+        // time for K = 1024): every launch replays the cheap register chain, the first one writes g_res0
+        const int per_pass = g_codebooks ? fused_levels_per_pass(D, K, L) : L;
+        for (int l0 = 0; l0 < L; l0 += per_pass) {
+            p.l_begin = l0;
+            p.l_end = (l0 + per_pass < L) ? l0 + per_pass : L;
+            p.write_rows = (l0 == 0);
+            const int nl = p.l_end - p.l_begin;
+            const int LKD = nl * K * D;
+            const size_t lds = g_codebooks ? (size_t)nl * K * (D + 1) * sizeof(float) : 0;
+            auto go = [&](auto kern) -> int {
+                static bool attr = false;
+                if (!attr) {
+                    RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)kScatterLdsBudget));
+                    attr = true;
+                }
+                hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD);
+                RQ_CHECK_LAUNCH("rq_backward_fused_kernel");
+                return 0;
+            };
+            int rcf = RQHIP_EARG;
 #define RQ_FUSED_MODES(KS)                                                                                            \
     switch (mode) {                                                                                                   \
         case RQHIP_MODE_EVAL:                                                                                         \
@@ -453,15 +471,18 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
                       : go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION, false>);                                 \
             break;                                                                                                    \
     }
-        switch (ksteps_for(D)) {
-            case 4: RQ_FUSED_MODES(4) break;
-            case 8: RQ_FUSED_MODES(8) break;
-            default: RQ_FUSED_MODES(16) break;
-        }
+            switch (ksteps_for(D)) {
+                case 4: RQ_FUSED_MODES(4) break;
+                case 8: RQ_FUSED_MODES(8) break;
+                default: RQ_FUSED_MODES(16) break;
+            }
 #undef RQ_FUSED_MODES
-        if (rcf || !g_codebooks) return rcf;
-        hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD, g_codebooks);
-        RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+            if (rcf) return rcf;
+            if (!g_codebooks) break;  // nothing to scatter: the first launch has written g_res0
+            hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD,
+                               g_codebooks + (size_t)l0 * K * D);
+            RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+        }
         return RQHIP_OK;
     }
 

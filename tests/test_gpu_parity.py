@@ -166,7 +166,7 @@ def _run_backward(x, cbs, mode, beta, ids, **g):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,D,K,L", [(1, 32, 256, 3), (333, 32, 256, 3), (64, 64, 256, 3), (100, 16, 32, 1),
-                                     (77, 24, 100, 4), (40, 128, 64, 2), (2000, 32, 1024, 4)])
+                                     (77, 24, 100, 4), (40, 128, 64, 2), (2000, 32, 1024, 4), (500, 32, 512, 3)])
 @pytest.mark.parametrize("which", ["all", "train_like"])
 def test_backward_vs_oracle(mode, B, D, K, L, which):
     rng = np.random.default_rng(B + D + K + L + mode)
