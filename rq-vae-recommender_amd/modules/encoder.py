@@ -1,13 +1,36 @@
 """Bias-free Linear+ReLU stack (API and state_dict keys of reference modules/encoder.py:7-38).
 
-The encoder/decoder GEMMs stay on PyTorch-ROCm (rocBLAS/hipBLASLt fp32); SURVEY.md section 8f lists fusing
-them around the RQ kernel as the next step.  Parameter names are `mlp.{0,2,4,...}.weight`, as in the
-reference, so checkpoints load in both directions."""
+The encoder/decoder GEMMs stay library GEMMs on PyTorch-ROCm (fp32, `rqhip/tuning.py` picks the kernels).  On the
+GPU every Linear that is followed by a ReLU runs as ONE hipBLASLt call with the ReLU in the GEMM epilogue
+(`torch._addmm_activation` with a zero bias) instead of a GEMM plus an elementwise pass over the activations:
+-0.29 ms of a 6.1 ms step at 100 000 rows (`tools/relu_epilogue_probe.py`).  The op has no autograd formula, so
+`_LinearReLU` supplies the two backward GEMMs and the ReLU mask itself -- the same three kernels autograd runs
+for linear + relu.  Parameter names are `mlp.{0,2,4,...}.weight`, as in the reference, so checkpoints load in both
+directions."""
 from typing import List
 
+import torch
 from torch import Tensor, nn
 
 from modules.normalize import L2NormalizationLayer
+
+
+class _LinearReLU(torch.autograd.Function):
+    """relu(x @ w.T) for 2-D fp32 ROCm tensors, ReLU fused into the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, zero_bias: Tensor) -> Tensor:
+        y = torch._addmm_activation(zero_bias, x, w.t())
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, w, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
+        gx = g.mm(w) if ctx.needs_input_grad[0] else None      # and the two GEMMs it does for linear
+        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
 
 
 class MLP(nn.Module):
@@ -27,7 +50,28 @@ class MLP(nn.Module):
                 stack.append(nn.Dropout(dropout))
         stack.append(L2NormalizationLayer() if normalize else nn.Identity())
         self.mlp = stack
+        self._zeros = {}  # zero "bias" vectors for the fused epilogue call, per width (not parameters, not saved)
+
+    def _zero_bias(self, n: int, like: Tensor) -> Tensor:
+        z = self._zeros.get(n)
+        if z is None or z.device != like.device:
+            z = torch.zeros(n, dtype=like.dtype, device=like.device)
+            self._zeros[n] = z
+        return z
 
     def forward(self, x: Tensor) -> Tensor:
         assert x.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {x.shape[-1]}"
-        return self.mlp(x)
+        if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+            return self.mlp(x)
+        layers = list(self.mlp)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            if (isinstance(layer, nn.Linear) and layer.bias is None and i + 1 < len(layers)
+                    and isinstance(layers[i + 1], nn.ReLU)):
+                x = _LinearReLU.apply(x, layer.weight, self._zero_bias(layer.out_features, x))
+                i += 2
+            else:
+                x = layer(x)
+                i += 1
+        return x
