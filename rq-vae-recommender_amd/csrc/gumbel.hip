@@ -49,7 +49,13 @@ __host__ __device__ inline size_t gumbel_lds_floats(int D, int K, int Kpad, bool
     return n;
 }
 
-template <bool BACKWARD>
+// REGACC (backward, K <= 256, D <= 32): the dense codebook gradient -- every row touches every code -- is summed
+// in registers, lane owns codes lane + 64 g (g < 4) x all 32 features = 128 accumulators, and only meets the other
+// three waves of the workgroup in LDS once, after the row loop.  The first version did one ds_add_f32 per
+// (row, code, feature): 819 M LDS float atomics for 100 000 rows at ~2 cycles per lane and CU = 6 ms per level.
+constexpr int kGAccPerLane = 4, kGAccD = 32;
+
+template <bool BACKWARD, bool REGACC>
 __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D, K = p.K, Kpad = p.Kpad, KS = K + 1;
@@ -65,9 +71,14 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
         const int k = e / D, d = e - k * D;
         Ct[(size_t)d * KS + k] = p.cb[e];
     }
-    if (BACKWARD)
+    if (BACKWARD && !REGACC)
         for (int e = threadIdx.x; e < K * (D + 1); e += kGThreads) gC[e] = 0.0f;
     __syncthreads();
+    float gacc[REGACC ? kGAccPerLane : 1][REGACC ? kGAccD : 1];
+#pragma unroll
+    for (int g = 0; g < (REGACC ? kGAccPerLane : 1); ++g)
+#pragma unroll
+        for (int d = 0; d < (REGACC ? kGAccD : 1); ++d) gacc[g][d] = 0.0f;
     for (int k = threadIdx.x; k < Kpad; k += kGThreads) {
         float v = __builtin_inff();
         if (k < K) {  // sumsq2 of code k (parity accumulators)
@@ -91,6 +102,7 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
         if (lane + 64 < D) xs[lane + 64] = p.x[(size_t)row * D + lane + 64];
         __builtin_amdgcn_wave_barrier();
         float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll 8
         for (int d = 0; d < D; ++d) {
             const float v = xs[d];
             const float q = v * v;
@@ -106,7 +118,9 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
             if (g < per_lane) {
                 const int k = lane + 64 * g;
                 float acc = 0.0f;
-                for (int d = 0; d < D; ++d) acc = __builtin_fmaf(xs[d], Ct[(size_t)d * KS + (k < K ? k : 0)], acc);
+                const float *ck = Ct + (k < K ? k : 0);
+#pragma unroll 8
+                for (int d = 0; d < D; ++d) acc = __builtin_fmaf(xs[d], ck[(size_t)d * KS], acc);
                 const float t = xsq + csq[k];
                 const float dv = (k < K) ? t - 2.0f * acc : __builtin_inff();
                 dist[g] = dv;
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
         {
             const float *c0 = Ct + (size_t)(lane < D ? lane : 0) * KS;
             const float *c1 = Ct + (size_t)(lane + 64 < D ? lane + 64 : 0) * KS;
+#pragma unroll 8
             for (int k = 0; k < K; ++k) {
                 const float wk = ws[k];
                 e0 = __builtin_fmaf(wk, c0[k], e0);
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
         __builtin_amdgcn_wave_barrier();
         // quantize loss on (x, emb): parity accumulators over d, every lane redundantly
         float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 8
         for (int d = 0; d < D; ++d) {
             const float df = xs[d] - es[d];
             const float q = df * df;
@@ -214,7 +230,9 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
                 if (g < per_lane) {
                     const int k = lane + 64 * g;
                     float acc = 0.0f;
-                    for (int d = 0; d < D; ++d) acc = __builtin_fmaf(ges[d], Ct[(size_t)d * KS + (k < K ? k : 0)], acc);
+                    const float *ck = Ct + (k < K ? k : 0);
+#pragma unroll 8
+                    for (int d = 0; d < D; ++d) acc = __builtin_fmaf(ges[d], ck[(size_t)d * KS], acc);
                     dw[g] = (k < K) ? acc : 0.0f;
                     swl = __builtin_fmaf(y[g], dw[g], swl);
                 }
@@ -240,6 +258,7 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
                 const float *c1 = Ct + (size_t)(lane + 64 < D ? lane + 64 : 0) * KS;
                 float g0 = (lane < D) ? (2.0f * xs[lane]) * sdd : 0.0f;
                 float g1 = (lane + 64 < D) ? (2.0f * xs[lane + 64]) * sdd : 0.0f;
+#pragma unroll 8
                 for (int k = 0; k < K; ++k) {
                     const float m2 = -2.0f * dds[k];
                     g0 = __builtin_fmaf(m2, c0[k], g0);
@@ -250,16 +269,33 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
                     p.g_x[(size_t)row * D + lane + 64] = g1 + ((2.0f * p.beta) * (xs[lane + 64] - e1)) * gl;
             }
             // dense codebook gradient: gC[k][d] += w_k ge_d + 2 dd_k (C[k][d] - x_d), lanes over k
+            if (REGACC) {
 #pragma unroll
-            for (int g = 0; g < kGMaxPerLane; ++g) {
-                if (g < per_lane) {
-                    const int k = lane + 64 * g;
-                    if (k < K) {
-                        const float wk = y[g], d2 = 2.0f * dw[g];
-                        float *row_g = gC + (size_t)k * (D + 1);
-                        for (int d = 0; d < D; ++d) {
-                            const float v = __builtin_fmaf(d2, Ct[(size_t)d * KS + k] - xs[d], wk * ges[d]);
-                            atomicAdd(row_g + d, v);  // ds_add_f32: 4 waves share the table
+                for (int d = 0; d < kGAccD; ++d) {
+                    if (d < D) {
+                        const float xd = xs[d], gd = ges[d];
+#pragma unroll
+                        for (int g = 0; g < kGAccPerLane; ++g) {
+                            const int k = lane + 64 * g;
+                            if (g < per_lane && k < K) {
+                                const float v = __builtin_fmaf(2.0f * dw[g], Ct[(size_t)d * KS + k] - xd, y[g] * gd);
+                                gacc[g][d] = gacc[g][d] + v;
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < kGMaxPerLane; ++g) {
+                    if (g < per_lane) {
+                        const int k = lane + 64 * g;
+                        if (k < K) {
+                            const float wk = y[g], d2 = 2.0f * dw[g];
+                            float *row_g = gC + (size_t)k * (D + 1);
+                            for (int d = 0; d < D; ++d) {
+                                const float v = __builtin_fmaf(d2, Ct[(size_t)d * KS + k] - xs[d], wk * ges[d]);
+                                atomicAdd(row_g + d, v);  // ds_add_f32: 4 waves share the table
+                            }
                         }
                     }
                 }
@@ -268,6 +304,27 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
         __builtin_amdgcn_wave_barrier();
     }
 
+    if (BACKWARD && REGACC) {
+        // the four waves' register tables meet in the workgroup's LDS table, one wave at a time (plain stores and
+        // read-modify-writes between barriers, wave order fixed: no atomics, deterministic)
+        for (int w = 0; w < kGWaves; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int g = 0; g < kGAccPerLane; ++g) {
+                    const int k = lane + 64 * g;
+                    if (k < K) {
+#pragma unroll
+                        for (int d = 0; d < kGAccD; ++d)
+                            if (d < D) {
+                                float *cell = gC + (size_t)k * (D + 1) + d;
+                                *cell = (w == 0) ? gacc[g][d] : *cell + gacc[g][d];
+                            }
+                    }
+                }
+            }
+        }
+    }
     if (BACKWARD) {
         __syncthreads();
         float *out = p.partial + (size_t)blockIdx.x * K * D;
@@ -328,11 +385,11 @@ extern "C" int rqhip_gumbel_forward(const float *x, int64_t B, int D, const floa
     const size_t lds = gumbel_lds_floats(D, K, p.Kpad, false) * sizeof(float);
     static bool attr_fwd = false;
     if (!attr_fwd) {
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<false>),
+        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<false, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_fwd = true;
     }
-    hipLaunchKernelGGL(gumbel_kernel<false>, dim3(gumbel_grid(B)), dim3(kGThreads), lds,
+    hipLaunchKernelGGL((gumbel_kernel<false, false>), dim3(gumbel_grid(B)), dim3(kGThreads), lds,
                        reinterpret_cast<hipStream_t>(stream), p);
     RQ_CHECK_LAUNCH("gumbel_kernel<fwd>");
     return RQHIP_OK;
@@ -370,11 +427,16 @@ extern "C" int rqhip_gumbel_backward(const float *x, int64_t B, int D, const flo
     const size_t lds = gumbel_lds_floats(D, K, p.Kpad, true) * sizeof(float);
     static bool attr_bwd = false;
     if (!attr_bwd) {
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<true>),
+        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<true, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<true, true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_bwd = true;
     }
-    hipLaunchKernelGGL(gumbel_kernel<true>, dim3(grid), dim3(kGThreads), lds, s, p);
+    if (K <= 64 * kGAccPerLane && D <= kGAccD)
+        hipLaunchKernelGGL((gumbel_kernel<true, true>), dim3(grid), dim3(kGThreads), lds, s, p);
+    else
+        hipLaunchKernelGGL((gumbel_kernel<true, false>), dim3(grid), dim3(kGThreads), lds, s, p);
     RQ_CHECK_LAUNCH("gumbel_kernel<bwd>");
     const int n = K * D;
     hipLaunchKernelGGL(gumbel_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p.partial, grid, n, g_codebook);
