@@ -13,6 +13,7 @@
 // Limits: D <= 128 and the LDS footprint below must fit 160 KiB (K*D <= ~16k floats for backward);
 // otherwise RQHIP_EUNSUPPORTED.  Transcendentals (logf/expf) differ from glibc's in the last ulp: results
 // match the oracle to ~1e-6 relative, not bit for bit; ids (noise-free argmin) are exact.
+#include "gumbel_mfma.h"
 #include "rqhip_common.h"
 
 namespace rqhip {
@@ -379,6 +380,13 @@ extern "C" int rqhip_gumbel_forward(const float *x, int64_t B, int D, const floa
         return RQHIP_EARG;
     }
     if (B == 0) return RQHIP_OK;
+    if (B >= gumbel_mfma_min_rows() && gumbel_mfma_supported(D, K, x, U, emb, nullptr) &&
+        (reinterpret_cast<uintptr_t>(codebook) & 15u) == 0) {
+        GumbelMfmaParams mp = {};
+        mp.x = x; mp.cb = codebook; mp.U = U; mp.ids = ids; mp.emb = emb; mp.loss = loss;
+        mp.B = B; mp.K = K; mp.temperature = temperature; mp.beta = beta;
+        return gumbel_mfma_forward(mp, reinterpret_cast<hipStream_t>(stream));
+    }
     GumbelParams p = {};
     p.x = x; p.cb = codebook; p.U = U; p.ids = ids; p.emb = emb; p.loss = loss;
     p.B = B; p.D = D; p.K = K; p.Kpad = (K + 63) & ~63; p.temperature = temperature; p.beta = beta;
@@ -415,10 +423,24 @@ extern "C" int rqhip_gumbel_backward(const float *x, int64_t B, int D, const flo
         RQ_RETURN_IF_HIP(hipMemsetAsync(g_codebook, 0, sizeof(float) * (size_t)K * D, s));
         return RQHIP_OK;
     }
-    const int grid = gumbel_grid(B);
+    const bool mfma = B >= gumbel_mfma_min_rows() && gumbel_mfma_supported(D, K, x, U, g_emb, g_x) &&
+                      (reinterpret_cast<uintptr_t>(codebook) & 15u) == 0;
+    const int grid = mfma ? gumbel_mfma_backward_grid(B) : gumbel_grid(B);
     if (!workspace || workspace_bytes < (size_t)grid * K * D * sizeof(float)) {
         set_error("gumbel_backward: workspace too small");
         return RQHIP_EWORKSPACE;
+    }
+    if (mfma) {
+        GumbelMfmaParams mp = {};
+        mp.x = x; mp.cb = codebook; mp.U = U; mp.g_emb = g_emb; mp.g_loss = g_loss; mp.g_x = g_x;
+        mp.partial = reinterpret_cast<float *>(workspace);
+        mp.B = B; mp.K = K; mp.temperature = temperature; mp.beta = beta;
+        rc = gumbel_mfma_backward(mp, s);
+        if (rc) return rc;
+        const int n = K * D;
+        hipLaunchKernelGGL(gumbel_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mp.partial, grid, n, g_codebook);
+        RQ_CHECK_LAUNCH("gumbel_reduce_kernel");
+        return RQHIP_OK;
     }
     GumbelParams p = {};
     p.x = x; p.cb = codebook; p.U = U; p.g_emb = g_emb; p.g_loss = g_loss; p.g_x = g_x;

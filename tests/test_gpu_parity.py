@@ -285,6 +285,24 @@ def test_gumbel_vs_reference_golden(name):
     np.testing.assert_allclose(g_cb.cpu().numpy(), g["grad_codebook"], rtol=2e-3, atol=5e-5 * sc)
 
 
+@pytest.mark.parametrize("B,K,T", [(4096, 256, 0.2), (4133, 64, 0.5), (5000, 128, 0.2), (4100, 32, 1.0)])
+def test_gumbel_matrix_path_vs_oracle(B, K, T):
+    """From 4096 rows of width 32 the Gumbel level runs on the matrix instructions (csrc/gumbel_mfma.hip), 32 rows
+    per wave; same bars as the one-row-per-wave kernels: ids exact, everything else to rounding."""
+    test_gumbel_forward_backward_vs_oracle(B, 32, K, T)
+
+
+def test_gumbel_matrix_path_small_batches(monkeypatch):
+    """The same kernels forced on for a ragged small batch (rows past the end of the last tile must not contribute)."""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = ['tests', '.', 'rq-vae-recommender_amd']; import test_gpu_parity as t; "
+            "t.test_gumbel_forward_backward_vs_oracle(77, 32, 256, 0.2); t.test_gumbel_forward_backward_vs_oracle(1, 32, 64, 0.3)")
+    env = dict(os.environ, RQ_GUMBEL_MFMA_MIN_ROWS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gumbel_unsupported_shape_fails_loudly():
     from rqhip import RqHipError, ops
     x, cb, U = _gumbel_inputs(8, 32, 4096, 0)
