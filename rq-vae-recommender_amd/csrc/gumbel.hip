@@ -8,7 +8,8 @@
 // stride K+1: conflict-free both for lanes-over-k and lanes-over-d), and the only HBM traffic is x, the
 // uniform noise U (the dominant 4K bytes per row) and the outputs.  The dense codebook gradient (every row
 // touches every code) is accumulated in an LDS table per workgroup and reduced across workgroups in fixed
-// order.  Not the shipped configs' mode (both use STE / rotation), so v1 favours simplicity: VALU FMAs, no MFMA.
+// order.  This file is the general one-row-per-wave implementation (VALU FMAs); for the shipped latent width
+// (D == 32, K <= 256) and batches of >= 4096 rows the entry points below hand over to gumbel_mfma.hip.
 //
 // Limits: D <= 128 and the LDS footprint below must fit 160 KiB (K*D <= ~16k floats for backward);
 // otherwise RQHIP_EUNSUPPORTED.  Transcendentals (logf/expf) differ from glibc's in the last ulp: results
