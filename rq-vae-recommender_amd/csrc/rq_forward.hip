@@ -764,7 +764,8 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     // a partly filled last round (53 of 3125 tiles at 100 000 rows) puts a whole extra tile on one SIMD of each CU it
     // lands on; when it is at most one tile per workgroup it is done cooperatively instead, a quarter per SIMD
     p.coop_first = all_coop ? 0 : p.n_tiles;
-    if (!all_coop && p.resident && !getenv("RQ_NO_COOP_TAIL")) {
+    static const bool coop_tail = getenv("RQ_NO_COOP_TAIL") == nullptr;  // developer A/B switch, read once
+    if (!all_coop && p.resident && coop_tail) {
         const long long rem = p.n_tiles % total_waves;
         if (rem > 0 && rem <= grid) p.coop_first = p.n_tiles - rem;
     }
