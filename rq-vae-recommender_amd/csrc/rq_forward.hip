@@ -55,7 +55,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCoopWaves = 4;   // waves sharing one cooperative row tile: one per SIMD
-constexpr int kCoopSteps = 32;  // LDS counters, one per (cooperative tile, level): at most 2 tiles x 16 levels
+constexpr int kCoopSteps = 32;  // LDS counters, used round-robin by (cooperative tile, level)
 // floats of LDS behind the staged codebooks: candidates [2][4 waves][32] x (value, index) + the counters
 constexpr int kCoopLdsFloats = 4 * kCoopWaves * 32 + kCoopSteps;
 
@@ -339,7 +339,7 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
 //                 one of the four then finishes the level redundantly (gather, loss, output: cheap next to a scan;
 //                 no hand-over of the next residual), wave 0 stores.  They synchronise through an LDS counter per
 //                 level, not s_barrier, so the other waves of the workgroup are not involved.  Used (a) for small
-//                 batches (at most two row tiles per CU, e.g. the reference's batch 640), where one wave per tile
+//                 batches (at most four row tiles per CU, e.g. the reference's batch 640), where one wave per tile
 //                 would leave most SIMDs empty, and (b) for the partly filled last round of a big batch, whose
 //                 tiles would otherwise each put a whole extra tile on one SIMD (+17 us for 53 of 3125 tiles).
 // FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
@@ -405,8 +405,8 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         }
         if (COOP) {
             // the four waves' candidates meet in LDS, double-buffered by level parity; `phase` counts levels across
-            // consecutive cooperative tiles so that parity and counter index keep advancing.  Counter (phase+l) is
-            // used exactly once: it reaches kCoopWaves when every wave has published its candidates.
+            // consecutive cooperative tiles so that parity and counter index keep advancing.  Counter slot
+            // (phase+l) mod kCoopSteps has been bumped by every wave once it has published its candidates.
             const int step = phase + l;
             float *cv = cand_s + (step & 1) * (2 * kCoopWaves * 32);
             int *ci = reinterpret_cast<int *>(cv + kCoopWaves * 32);
@@ -416,8 +416,10 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 ci[wave * 32 + il] = bidx;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // (counters are never reset: the r-th reuse of a slot waits for kCoopWaves * (r + 1))
+            const int want = kCoopWaves * (step / kCoopSteps + 1);
             if (lane == 0) __hip_atomic_fetch_add(&cnt[step & (kCoopSteps - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(&cnt[step & (kCoopSteps - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kCoopWaves)
+            while (__hip_atomic_load(&cnt[step & (kCoopSteps - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
                 __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             best = __builtin_inff();
@@ -618,6 +620,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     // wave of each SIMD, which finishes its own tile of a full round first
     if (wave < kCoopWaves) {
         int phase = 0;
+        // (fetching the next cooperative tile's rows under the current one was measured: no gain)
         for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
             float raw[KSTEPS], r[KSTEPS];
             load_rows(tile, raw);
@@ -691,7 +694,7 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
 using namespace rqhip;
 
 static inline bool f_resident_small(int resident, long long n_tiles, long long cap) {
-    return resident && n_tiles <= 2 * cap;
+    return resident && n_tiles <= 4 * cap;
 }
 
 static inline int pad32(int k) { return (k + 63) & ~63; }  // code tiles are processed in pairs
@@ -756,7 +759,7 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
     long long cap = (long long)cus * wg_per_cu;
-    // small batches (at most two row tiles per CU): every tile is cooperative, one workgroup per tile
+    // small batches (at most four row tiles per CU): every tile is cooperative, one workgroup per tile at a time
     const bool all_coop = f_resident_small(p.resident, p.n_tiles, cap);
     if (all_coop) want = p.n_tiles;
     const int grid = (int)(want < cap ? want : cap);

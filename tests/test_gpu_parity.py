@@ -49,7 +49,9 @@ def _check_forward(x, cbs, mode, beta=0.25):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,D,K,L", [(1, 32, 256, 3), (33, 32, 256, 3), (640, 32, 256, 3), (4099, 32, 256, 3),
                                      (64, 64, 256, 3), (100, 16, 32, 3), (50, 8, 5, 2), (77, 24, 100, 4),
-                                     (65, 30, 70, 2), (40, 128, 64, 2), (300, 32, 1024, 4), (96, 64, 2048, 2)])
+                                     (65, 30, 70, 2), (40, 128, 64, 2), (300, 32, 1024, 4), (96, 64, 2048, 2),
+                                     # cooperative tiles, several per workgroup x 16 levels: the LDS step counters wrap
+                                     (30000, 16, 32, 16), (20000, 32, 256, 3)])
 def test_forward_bitexact_vs_oracle(mode, B, D, K, L):
     rng = np.random.default_rng(B * 131 + D * 7 + K + L + mode)
     x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
