@@ -53,7 +53,7 @@ class SemIdPrefixIndex:
         if prefix.device != self.codebooks.device:  # the reference moves its codebooks to the prefix (model.py:173-174)
             self.to(prefix.device)
         if self._index is None:
-            self.to(prefix.device)
+            self._build()  # on a CPU tensor this raises RqHipError: the lookup has no CPU implementation
         if prefix.shape[0] == 0:
             # the reference ends in torch.cat([]) here (model.py:182)
             raise RuntimeError("check_valid_prefix: expected a non-empty batch of prefixes")

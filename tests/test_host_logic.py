@@ -114,6 +114,40 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         kmeans_init_(torch.zeros(4, 8), torch.randn(16, 8))
 
 
+def test_decoder_side_consumers_have_no_cpu_path_and_keep_the_reference_signatures():
+    """evaluate/metrics.py:7-28 and modules/model.py:169-182 mirrors: same constructor / method names and argument
+    checks as the reference; the matching itself is HIP only."""
+    from evaluate.metrics import TopKAccumulator
+    from modules.sid_prefix import SemIdPrefixIndex
+    from rqhip import RqHipError
+    acc = TopKAccumulator()
+    assert acc.ks == [1, 5, 10] and acc.total == 0 and acc.reduce.__name__ == "reduce"
+    with pytest.raises(RqHipError, match="no CPU fallback"):
+        acc.accumulate(actual=torch.zeros((2, 3), dtype=torch.int64), top_k=torch.zeros((2, 4, 3), dtype=torch.int64))
+    with pytest.raises(ValueError):
+        SemIdPrefixIndex(torch.zeros((4, 3), dtype=torch.int32))
+    index = SemIdPrefixIndex(torch.arange(12).reshape(4, 3))         # CPU codebooks: index is built on first use
+    assert index.num_items == 4 and index._index is None
+    with pytest.raises(RqHipError, match="no CPU fallback"):
+        index.check_valid_prefix(torch.tensor([[0, 1]]))
+
+
+def test_mlp_fused_linear_relu_function_matches_plain_ops():
+    """modules/encoder.py: the autograd wrapper around the ReLU-epilogue GEMM (GPU path) computes what Linear + ReLU
+    compute; checked here on CPU, where aten::_addmm_activation also exists."""
+    from modules.encoder import MLP, _LinearReLU
+    torch.manual_seed(3)
+    x = torch.randn(9, 8, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(5, 8, dtype=torch.float64, requires_grad=True)
+    zero = torch.zeros(5, dtype=torch.float64)
+    assert torch.autograd.gradcheck(lambda a, b: _LinearReLU.apply(a, b, zero), (x, w))
+    y = _LinearReLU.apply(x, w, zero)
+    assert torch.allclose(y, torch.relu(x @ w.t()))
+    m = MLP(8, [6, 4], 3)                                              # CPU tensors take the plain nn.Sequential path
+    out = m(torch.randn(5, 8))
+    assert out.shape == (5, 3) and list(m.state_dict()) == ["mlp.0.weight", "mlp.2.weight", "mlp.4.weight"]
+
+
 def test_quantize_asserts_and_unsupported_modes():
     from modules.quantize import Quantize, QuantizeDistance, QuantizeForwardMode
     q = Quantize(embed_dim=8, n_embed=4, do_kmeans_init=False, forward_mode=QuantizeForwardMode.STE)
