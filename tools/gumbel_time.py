@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU box): one Gumbel-softmax level forward / backward (rqhip_gumbel_forward / _backward) at
+three batch sizes, next to the cost of drawing the uniform noise U with torch.rand."""
 import os, sys, time
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rq-vae-recommender_amd"))
 import torch
 from rqhip import ops
