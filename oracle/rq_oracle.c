@@ -14,6 +14,8 @@
  *   distributions/gumbel.py:8-20  sample_gumbel / gumbel_softmax_sample
  *   init/kmeans.py:33-72          Kmeans (assign, update, stop test)
  *   modules/tokenizer/semids.py:92-108  dedup column of precompute_corpus_ids
+ *   modules/model.py:169-182      _check_valid_prefix (valid-prefix mask of the beam search)
+ *   evaluate/metrics.py:16-25     TopKAccumulator.accumulate (first-match rank)
  *
  * The reference computes these with PyTorch CPU ops whose floating-point reduction order is
  * not specified (MKL sgemm, vectorised sums).  This file FIXES an order for every reduction --
