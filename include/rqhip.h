@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 100 /* major*10000 + minor*100 + patch */
+#define RQHIP_VERSION 200 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin */
 
 #define RQHIP_OK 0
 #define RQHIP_EARG (-1)         /* bad pointer / size / mode */
@@ -66,13 +66,23 @@ int rqhip_device_cu_count(int *cu_count);
  *   emb_sum   [B,D]   or NULL          -- sum over levels of embs, ((e0+e1)+e2)+...
  *   loss      [B]     or NULL          -- sum over levels of the quantize loss
  *   embs_norm [B,L]   or NULL          -- L2 norm of embs per level
+ *   tie_margin [L,B]  or NULL          -- how decisively each level's argmin was taken (SURVEY.md section 8b
+ *                                         `tie_margin_flags`): (d2 - d1) / (|x|^2 + |c_id|^2), d1 = dist[id],
+ *                                         d2 = smallest distance among the OTHER codes (a duplicate of the minimum
+ *                                         counts: margin 0); 0 for rows that took the exact non-finite scan and when
+ *                                         the quotient is NaN, +Inf when K == 1.  Two correct fp32 evaluations of
+ *                                         quantize.py:113-117 (this kernel's FMA chain, the reference's BLAS) differ by
+ *                                         a few ulp of |x|^2 + |c|^2, so ids can only differ on rows whose margin is
+ *                                         below ~1e-6: a caller that needs the reference's ids bit for bit adjudicates
+ *                                         exactly those rows (tests/test_gpu_reference_parity.py does, in fp64).
+ *                                         Requesting it selects a kernel variant with ~10 % more work per code.
  *   workspace rqhip_rq_forward_workspace_bytes(L,K) bytes of scratch (codebook norms)
  * Limits: 1 <= D <= 128, 1 <= K <= 65536, 1 <= L <= 16.
  */
 size_t rqhip_rq_forward_workspace_bytes(int L, int K);
 int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                      int mode, float beta, int64_t *ids, float *embs, float *residuals,
-                     float *emb_sum, float *loss, float *embs_norm, void *workspace,
+                     float *emb_sum, float *loss, float *embs_norm, float *tie_margin, void *workspace,
                      size_t workspace_bytes, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

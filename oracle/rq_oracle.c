@@ -139,9 +139,27 @@ static void rotation_row(const float *x, const float *emb, int D, float *out,
  * loss      [B]     or NULL   sum over levels of QuantizeLoss               (rqvae.py:128)
  * embs_norm [B,L]   or NULL   ||emb_out_l||_2                               (rqvae.py:158)
  */
+/* tie_margin [L,B] or NULL: how decisively each level's argmin was taken (SURVEY.md section 7 "hard parts",
+ *   section 8b `tie_margin_flags`).  margin = (d2 - d1) / (|x|^2 + |c_id|^2) with d1 = dist[id] and
+ *   d2 = min over k != id of dist[k] (a duplicate of the minimum counts: margin 0); 0 for rows whose
+ *   distances may be non-finite (|x|^2 + max_k|c_k|^2 not < 1e38, the kernel's exact-scan rows) and whenever the
+ *   quotient is NaN; +Inf when K == 1.  The reference's BLAS sums the same products in another order, so its
+ *   distances differ from these by a few ulp of (|x|^2 + |c|^2): rows with margin below ~1e-6 are the ones
+ *   whose id may legitimately differ between two correct fp32 evaluations. */
+int rqo_rq_forward_ex(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                      int mode, float beta, int64_t *ids, float *embs, float *residuals,
+                      float *emb_sum, float *loss, float *embs_norm, float *tie_margin);
+
 int rqo_rq_forward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                    int mode, float beta, int64_t *ids, float *embs, float *residuals,
                    float *emb_sum, float *loss, float *embs_norm) {
+    return rqo_rq_forward_ex(res0, B, D, codebooks, L, K, mode, beta, ids, embs, residuals, emb_sum, loss,
+                             embs_norm, 0);
+}
+
+int rqo_rq_forward_ex(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                      int mode, float beta, int64_t *ids, float *embs, float *residuals,
+                      float *emb_sum, float *loss, float *embs_norm, float *tie_margin) {
     if (B < 0 || D <= 0 || L <= 0 || K <= 0 || !res0 || !codebooks || !ids) return RQO_EARG;
     if (mode != RQO_MODE_EVAL && mode != RQO_MODE_STE && mode != RQO_MODE_ROTATION) return RQO_EARG;
     float *csq = (float *)malloc(sizeof(float) * (size_t)L * K);
@@ -163,6 +181,19 @@ int rqo_rq_forward(const float *res0, int64_t B, int D, const float *codebooks, 
             l2_dist_row(res, cb, csq + (size_t)l * K, K, D, dist);
             int64_t id = argmin_torch(dist, K);
             ids[(size_t)l * B + i] = id;
+            if (tie_margin) {
+                const float *cq = csq + (size_t)l * K;
+                float xsq = sumsq2(res, D), cmax = 0.0f, m = 0.0f;
+                int nan = 0;
+                for (int k = 0; k < K; ++k) { if (cq[k] != cq[k]) nan = 1; else if (cq[k] > cmax) cmax = cq[k]; }
+                if (!nan && (xsq + cmax) < 1.0e38f) {
+                    float d2 = INFINITY;
+                    for (int k = 0; k < K; ++k) if (k != id && dist[k] < d2) d2 = dist[k];
+                    m = (d2 - dist[id]) / (xsq + cq[id]);
+                    if (m != m) m = 0.0f;
+                }
+                tie_margin[(size_t)l * B + i] = m;
+            }
             const float *emb = cb + (size_t)id * D;
             /* QuantizeLoss (loss.py:38-41): both terms are sum((x-emb)^2), bit-identical */
             for (int d = 0; d < D; ++d) diff[d] = res[d] - emb[d];

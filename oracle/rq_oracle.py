@@ -58,9 +58,9 @@ def _chk(rc: int, what: str) -> None:
         raise RuntimeError(f"oracle {what} failed with code {rc}")
 
 
-def rq_forward(res0, codebooks, mode: int, beta: float = 0.25):
+def rq_forward(res0, codebooks, mode: int, beta: float = 0.25, want_margin: bool = False):
     """L chained quantisation levels.  Returns dict(ids [L,B], embs [L,B,D], residuals [L,B,D],
-    emb_sum [B,D], loss [B], embs_norm [B,L])."""
+    emb_sum [B,D], loss [B], embs_norm [B,L]) and, with want_margin, tie_margin [L,B] (see rq_oracle.c)."""
     res0, codebooks = _f(res0), _f(codebooks)
     B, D = res0.shape
     L, K, D2 = codebooks.shape
@@ -68,10 +68,12 @@ def rq_forward(res0, codebooks, mode: int, beta: float = 0.25):
     out = dict(ids=np.empty((L, B), np.int64), embs=np.empty((L, B, D), np.float32),
                residuals=np.empty((L, B, D), np.float32), emb_sum=np.empty((B, D), np.float32),
                loss=np.empty((B,), np.float32), embs_norm=np.empty((B, L), np.float32))
-    rc = lib().rqo_rq_forward(_p(res0), C.c_int64(B), C.c_int(D), _p(codebooks), C.c_int(L), C.c_int(K),
-                              C.c_int(mode), C.c_float(beta), _p(out["ids"]), _p(out["embs"]),
-                              _p(out["residuals"]), _p(out["emb_sum"]), _p(out["loss"]),
-                              _p(out["embs_norm"]))
+    if want_margin:
+        out["tie_margin"] = np.empty((L, B), np.float32)
+    rc = lib().rqo_rq_forward_ex(_p(res0), C.c_int64(B), C.c_int(D), _p(codebooks), C.c_int(L), C.c_int(K),
+                                 C.c_int(mode), C.c_float(beta), _p(out["ids"]), _p(out["embs"]),
+                                 _p(out["residuals"]), _p(out["emb_sum"]), _p(out["loss"]),
+                                 _p(out["embs_norm"]), _p(out.get("tie_margin")))
     _chk(rc, "rq_forward")
     return out
 

@@ -61,8 +61,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCoopWaves = 4;   // waves sharing one cooperative row tile: one per SIMD
 constexpr int kCoopSteps = 32;  // LDS counters, used round-robin by (cooperative tile, level)
-// floats of LDS behind the staged codebooks: candidates [2][4 waves][32] x (value, index) + the counters
-constexpr int kCoopLdsFloats = 4 * kCoopWaves * 32 + kCoopSteps;
+// floats of LDS behind the staged codebooks: candidates [2][4 waves][32] x (value, index, runner-up) + the counters
+constexpr int kCoopCandFloats = 3 * kCoopWaves * 32;   // one parity buffer
+constexpr int kCoopLdsFloats = 2 * kCoopCandFloats + kCoopSteps;
 
 // workgroup size is a template parameter of the kernel (NT): more waves per SIMD hide the VALU epilogue and the
 // per-level tail of one wave behind the MFMAs of the others, as far as the register budget of KSTEPS allows
@@ -75,6 +76,7 @@ struct RqFwdParams {
     const float *csqmax;  // [L]     (workspace) NaN-propagating max of csq per level
     int64_t *ids;
     float *embs, *residuals, *emb_sum, *loss, *embs_norm;
+    float *tie_margin;    // [L,B] or nullptr: relative top-2 distance margin of every level's argmin
     long long B;
     long long n_tiles;    // ceil(B/32)
     int n_iter;           // tiles per wave (grid-stride)
@@ -260,12 +262,25 @@ __device__ __forceinline__ float rq_min3(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float rq_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (smallest, runner-up) of the union of two sets given each set's (smallest, runner-up); duplicates count
+__device__ __forceinline__ void rq_merge2(float lo1, float hi1, float lo2, float hi2, float &lo, float &hi) {
+    lo = rq_min(lo1, lo2);
+    hi = rq_min3(rq_max(lo1, lo2), hi1, hi2);
+}
 
 
-template <int KSTEPS>
+// MARGIN: also track `second`, the smallest distance over all codes but the winner (the runner-up of the argmin;
+// a duplicate of the minimum counts), for the tie-margin output: a (min, runner-up) tournament over the lane's 16
+// distances, 26 VALU instructions more per 32 codes than the plain minimum tree.
+template <int KSTEPS, bool MARGIN>
 __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
                                            int kbase, int il, int h, const float (&x)[KSTEPS], float xsq,
-                                           float &best, int &bidx, int t_begin = 0, int t_step = 1) {
+                                           float &best, int &bidx, float &second, int t_begin = 0, int t_step = 1) {
     constexpr int KQ = KSTEPS / 4;
     const int ntiles = Kc / 32;
     // The code operands (A) of the NEXT group of four matrix instructions are fetched from LDS before the current
@@ -312,12 +327,31 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
         // here costs matrix time.  A minimum tree (11 min/min3) followed by a top-down walk ("is the minimum in
         // the left half?" -- 4 compares, 11 selects) needs ~2/3 of the issue cycles of a compare-and-select
         // tournament that drags the index along (15 compares, 30 selects).
-        const float a01 = rq_min(d[0], d[1]), a45 = rq_min(d[4], d[5]);
-        const float b01 = rq_min(d[8], d[9]), b45 = rq_min(d[12], d[13]);
-        const float a03 = rq_min3(a01, d[2], d[3]), a47 = rq_min3(a45, d[6], d[7]);
-        const float b03 = rq_min3(b01, d[10], d[11]), b47 = rq_min3(b45, d[14], d[15]);
-        const float a07 = rq_min(a03, a47), b07 = rq_min(b03, b47);
-        const float tmin = rq_min(a07, b07);
+        float a01, a45, b01, b45, a03, a47, b03, b47, a07, b07, tmin;
+        if (MARGIN) {
+            float lo1[8], hi1[8], lo2[4], hi2[4], hi3a, hi3b, t2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                lo1[i] = rq_min(d[2 * i], d[2 * i + 1]);
+                hi1[i] = rq_max(d[2 * i], d[2 * i + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rq_merge2(lo1[2 * i], hi1[2 * i], lo1[2 * i + 1], hi1[2 * i + 1], lo2[i], hi2[i]);
+            rq_merge2(lo2[0], hi2[0], lo2[1], hi2[1], a07, hi3a);
+            rq_merge2(lo2[2], hi2[2], lo2[3], hi2[3], b07, hi3b);
+            rq_merge2(a07, hi3a, b07, hi3b, tmin, t2);
+            a01 = lo1[0]; a45 = lo1[2]; b01 = lo1[4]; b45 = lo1[6];
+            a03 = lo2[0]; a47 = lo2[1]; b03 = lo2[2]; b47 = lo2[3];
+            // runner-up over everything scanned so far (uses `best` before this tile's update)
+            second = rq_min3(second, t2, rq_max(best, tmin));
+        } else {
+            a01 = rq_min(d[0], d[1]); a45 = rq_min(d[4], d[5]);
+            b01 = rq_min(d[8], d[9]); b45 = rq_min(d[12], d[13]);
+            a03 = rq_min3(a01, d[2], d[3]); a47 = rq_min3(a45, d[6], d[7]);
+            b03 = rq_min3(b01, d[10], d[11]); b47 = rq_min3(b45, d[14], d[15]);
+            a07 = rq_min(a03, a47); b07 = rq_min(b03, b47);
+            tmin = rq_min(a07, b07);
+        }
         const bool c3 = a07 != tmin;                       // not in elements 0..7
         const float q03 = c3 ? b03 : a03;
         const bool c2 = q03 != tmin;                       // not in the first quarter of that half
@@ -348,7 +382,7 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
 //                 would leave most SIMDs empty, and (b) for the partly filled last round of a big batch, whose
 //                 tiles would otherwise each put a whole extra tile on one SIMD (+17 us for 53 of 3125 tiles).
 // FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
-template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP>
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN>
 __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
                                         long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase) {
     constexpr int KQ = KSTEPS / 4;
@@ -380,7 +414,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         // |x|^2 (quantize.py:114): parity accumulators, multiply and add separately rounded
         const float xsq = pair_sumsq<KSTEPS>(r);
 
-        float best = __builtin_inff();
+        float best = __builtin_inff(), second = __builtin_inff();
         int bidx = 0x7fffffff;
 
         const float *buf = smem + (p.resident ? l * buf_floats : 0);
@@ -393,8 +427,8 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 __syncthreads();
             }
             if (active)
-                scan_codes<KSTEPS>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r, xsq,
-                                   best, bidx, COOP ? wave : 0, COOP ? kCoopWaves : 1);
+                scan_codes<KSTEPS, MARGIN>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r,
+                                           xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
         }
 
         RQ_STAMP(3 + 8 * l);
@@ -403,6 +437,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         if (active) {
             const float ob = shfl_xor32(best);
             const int oi = shfl_xor32(bidx);
+            if (MARGIN) second = rq_min3(second, shfl_xor32(second), rq_max(best, ob));
             if (ob < best || (ob == best && oi < bidx)) {
                 best = ob;
                 bidx = oi;
@@ -413,12 +448,14 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             // consecutive cooperative tiles so that parity and counter index keep advancing.  Counter slot
             // (phase+l) mod kCoopSteps has been bumped by every wave once it has published its candidates.
             const int step = phase + l;
-            float *cv = cand_s + (step & 1) * (2 * kCoopWaves * 32);
+            float *cv = cand_s + (step & 1) * kCoopCandFloats;
             int *ci = reinterpret_cast<int *>(cv + kCoopWaves * 32);
-            int *cnt = reinterpret_cast<int *>(cand_s + 4 * kCoopWaves * 32);
+            float *c2 = cv + 2 * kCoopWaves * 32;
+            int *cnt = reinterpret_cast<int *>(cand_s + 2 * kCoopCandFloats);
             if (h == 0) {
                 cv[wave * 32 + il] = best;
                 ci[wave * 32 + il] = bidx;
+                if (MARGIN) c2[wave * 32 + il] = second;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             // (counters are never reset: the r-th reuse of a slot waits for kCoopWaves * (r + 1))
@@ -428,11 +465,13 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             best = __builtin_inff();
+            second = __builtin_inff();
             bidx = 0x7fffffff;
 #pragma unroll
             for (int w = 0; w < kCoopWaves; ++w) {
                 const float ov = cv[w * 32 + il];
                 const int oi = ci[w * 32 + il];
+                if (MARGIN) second = rq_min3(second, c2[w * 32 + il], rq_max(best, ov));
                 if (ov < best || (ov == best && oi < bidx)) {
                     best = ov;
                     bidx = oi;
@@ -457,6 +496,13 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                     const int res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
                     if (il == j) bidx = res;
                 }
+            }
+            if (MARGIN) {
+                // relative top-2 margin of this level's argmin (see include/rqhip.h); 0 for exact-scan rows
+                const float cwin = p.resident ? buf[KSTEPS * 2 * Kc + bidx] : p.csq[(size_t)l * p.Kp + bidx];
+                float m = (second - best) / (xsq + cwin);
+                if (bad || m != m) m = 0.0f;
+                if (writer && h == 0) p.tie_margin[(size_t)l * p.B + row] = m;
             }
 
             RQ_STAMP(4 + 8 * l);
@@ -544,7 +590,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
     RQ_STAMP(101);
 }
 
-template <int KSTEPS, int MODE, bool FULLD, int NT>
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool MARGIN>
 __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *smem = reinterpret_cast<float *>(smem_raw);
@@ -599,7 +645,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     float *csqmax_s = smem + (p.resident ? L : 1) * buf_floats;
     float *cand_s = csqmax_s + 16;  // cooperative-tile candidates and counters (kCoopLdsFloats)
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
-    if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 4 * kCoopWaves * 32)[tid] = 0;
+    if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 2 * kCoopCandFloats)[tid] = 0;
     RQ_STAMP(200);
     if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
     RQ_STAMP(201);
@@ -617,7 +663,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
         float r[KSTEPS];
         unpack_rows(rn, r);
         if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
-        rq_tile<KSTEPS, MODE, FULLD, NT, false>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
+        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
         RQ_TRACE(trace_slot);
         ++trace_slot;
     }
@@ -630,7 +676,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
             float raw[KSTEPS], r[KSTEPS];
             load_rows(tile, raw);
             unpack_rows(raw, r);
-            rq_tile<KSTEPS, MODE, FULLD, NT, true>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
+            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
             phase += L;
             RQ_TRACE(trace_slot);
             ++trace_slot;
@@ -679,17 +725,18 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
     // full-width kernels move rows as float4s: every row pointer must be 16-byte aligned (rows are 8*KSTEPS bytes)
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool full = p.D == 2 * KSTEPS && al16(p.res0) && al16(p.embs) && al16(p.residuals) && al16(p.emb_sum);
+    const bool margin = p.tie_margin != nullptr;
+#define RQ_GO(MODE_)                                                                                              \
+    return margin ? (full ? go(rq_forward_kernel<KSTEPS, MODE_, true, NT, true>)                                  \
+                          : go(rq_forward_kernel<KSTEPS, MODE_, false, NT, true>))                                \
+                  : (full ? go(rq_forward_kernel<KSTEPS, MODE_, true, NT, false>)                                 \
+                          : go(rq_forward_kernel<KSTEPS, MODE_, false, NT, false>))
     switch (mode) {
-        case RQHIP_MODE_EVAL:
-            return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_EVAL, true, NT>)
-                        : go(rq_forward_kernel<KSTEPS, RQHIP_MODE_EVAL, false, NT>);
-        case RQHIP_MODE_STE:
-            return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_STE, true, NT>)
-                        : go(rq_forward_kernel<KSTEPS, RQHIP_MODE_STE, false, NT>);
-        case RQHIP_MODE_ROTATION:
-            return full ? go(rq_forward_kernel<KSTEPS, RQHIP_MODE_ROTATION, true, NT>)
-                        : go(rq_forward_kernel<KSTEPS, RQHIP_MODE_ROTATION, false, NT>);
+        case RQHIP_MODE_EVAL: RQ_GO(RQHIP_MODE_EVAL);
+        case RQHIP_MODE_STE: RQ_GO(RQHIP_MODE_STE);
+        case RQHIP_MODE_ROTATION: RQ_GO(RQHIP_MODE_ROTATION);
     }
+#undef RQ_GO
     set_error("rq_forward: unsupported mode %d", mode);
     return RQHIP_EARG;
 }
@@ -711,7 +758,7 @@ extern "C" size_t rqhip_rq_forward_workspace_bytes(int L, int K) {
 
 extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                                 int mode, float beta, int64_t *ids, float *embs, float *residuals,
-                                float *emb_sum, float *loss, float *embs_norm, void *workspace,
+                                float *emb_sum, float *loss, float *embs_norm, float *tie_margin, void *workspace,
                                 size_t workspace_bytes, rqhip_stream_t stream) {
     if (B < 0 || !codebooks || (B > 0 && (!res0 || !ids))) {
         set_error("rq_forward: null pointer or negative B");
@@ -743,7 +790,7 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     RqFwdParams p;
     p.res0 = res0; p.cb = codebooks; p.csq = csq; p.csqmax = csqmax;
     p.ids = ids; p.embs = embs; p.residuals = residuals; p.emb_sum = emb_sum; p.loss = loss;
-    p.embs_norm = embs_norm;
+    p.embs_norm = embs_norm; p.tie_margin = tie_margin;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
     const size_t level_bytes = (size_t)Kp * (Dp + 1) * sizeof(float);
     if (level_bytes * L + 64 + kCoopLdsFloats * sizeof(float) <= (size_t)kLdsBudget) {

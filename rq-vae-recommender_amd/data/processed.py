@@ -10,9 +10,10 @@ that gin configs name as `%data.processed.RecDataset.AMAZON`.
 Source of the matrix, in order:
   1. `<root>/item_features.pt` -- a dict {"x": float32 [N, >=768], "is_train": bool [N] (optional)} that a
      user exports once from the reference's processed HeteroData (`data["item"].x`, `["is_train"]`);
-  2. otherwise a deterministic synthetic corpus: N unit-norm 768-d rows (seed 1234; N from
-     $RQ_SYNTH_ITEMS, default 12101 ~ Amazon Beauty) with the reference's 95/5 split (seed 42,
-     data/amazon.py:154-156).
+  2. ONLY when $RQ_SYNTH_ITEMS=<N> is set (explicit opt-in, loud warning, `ds.synthetic` is True): a
+     deterministic synthetic corpus of N unit-norm 768-d rows (seed 1234) with the reference's 95/5 split
+     (seed 42, data/amazon.py:154-156).  Otherwise a missing file raises FileNotFoundError -- the reference
+     would download the data or fail here, never train on noise.
 MI355X-first: the matrix is moved to the GPU once (`to_device`) and batches are gathered there -- 10 M x 768
 fp32 = 30.7 GB fits one 288 GB HBM stack many times over -- so no PCIe copy sits in the training loop.
 """
@@ -57,14 +58,24 @@ class ItemData(Dataset):
                  is_train: Optional[Tensor] = None, **kwargs) -> None:
         del args, kwargs, force_process  # accepted for signature compatibility (split=..., etc.)
         self.dataset = dataset
+        self.synthetic = False
         if item_matrix is None:
             path = os.path.join(root, "item_features.pt")
             if os.path.exists(path):
                 blob = torch.load(path, map_location="cpu", weights_only=True)
                 item_matrix, is_train = blob["x"].to(torch.float32), blob.get("is_train", is_train)
-            else:
-                n = int(os.environ.get("RQ_SYNTH_ITEMS", "12101"))
+            elif os.environ.get("RQ_SYNTH_ITEMS"):
+                # explicit opt-in only: a run on noise must never look like a run on the dataset
+                n = int(os.environ["RQ_SYNTH_ITEMS"])
+                print(f"[ItemData] WARNING: {path} not found -- using {n} SYNTHETIC unit-norm items "
+                      f"(RQ_SYNTH_ITEMS={n}); results say nothing about the real corpus", flush=True)
                 item_matrix = synthetic_item_matrix(n)
+                self.synthetic = True
+            else:
+                raise FileNotFoundError(
+                    f"{path} not found.  Export the item features first (INTEGRATION.md, 'Item features': "
+                    "torch.save({'x': item_matrix_fp32[N, >=768], 'is_train': mask}, '<dataset_folder>/item_features.pt')) "
+                    "or opt in to synthetic items explicitly with RQ_SYNTH_ITEMS=<n>.")
         if is_train is None:
             is_train = synthetic_train_mask(item_matrix.shape[0])
         if train_test_split == "train":

@@ -5,7 +5,7 @@ modules/tokenizer/semids.py.
 compares every batch with everything seen so far (semids.py:92-105, O(N^2 L)).  Here the corpus is
 tokenised in large row blocks by the fused HIP kernel and the dedup column -- "how many earlier items have
 the same tuple" -- comes from one hash + stable radix-sort pass on the device (csrc/ids.hip), O(N).
-With torch.distributed initialised the rows are sharded across ranks and the id table is all-gathered.
+`precompute_corpus_ids(ds, sharded=True)` shards the rows across ranks and all-gathers the id table.
 """
 from typing import List, Optional
 
@@ -54,11 +54,17 @@ class SemanticIdTokenizer(nn.Module):
 
     @torch.no_grad()
     @eval_mode
-    def precompute_corpus_ids(self, movie_dataset) -> Tensor:
-        """[N, n_layers + 1] int64: semantic ids of every item followed by the dedup counter."""
+    def precompute_corpus_ids(self, movie_dataset, sharded: bool = False) -> Tensor:
+        """[N, n_layers + 1] int64: semantic ids of every item followed by the dedup counter.
+
+        Local by default, like the reference, whose callers run it on the main process only
+        (train_rqvae.py:272-275): a rank-0-only call must not enter a collective.  `sharded=True` is the explicit
+        multi-GPU form -- EVERY rank must call it: rows are split across ranks, tokenised, and the id table is
+        all-gathered (ids are a function of each row alone, except that a different GEMM row count can flip a
+        near-tie; rqhip/parity.py describes the tie policy)."""
         device = self.rq_vae.device
         n = len(movie_dataset)
-        lo, hi = rqdist.shard_bounds(n)
+        lo, hi = rqdist.shard_bounds(n) if sharded else (0, n)
         blocks = []
         for start in range(lo, hi, CORPUS_BLOCK_ROWS):
             rows = torch.arange(start, min(hi, start + CORPUS_BLOCK_ROWS))
@@ -66,32 +72,45 @@ class SemanticIdTokenizer(nn.Module):
             blocks.append(self.rq_vae.get_semantic_ids(x).sem_ids)        # [b, L] view of [L, b]
         local = torch.cat(blocks, dim=0) if blocks else torch.empty((0, self.n_layers), dtype=torch.int64,
                                                                      device=device)
-        ids = rqdist.allgather_rows(local.contiguous())                    # [N, L] on every rank
+        ids = rqdist.allgather_rows(local.contiguous()) if sharded else local.contiguous()   # [N, L]
         rank, _ = ops.dedup_rank(ids.t().contiguous(), self.codebook_size)
         self.cached_ids = torch.cat([ids, rank.unsqueeze(1)], dim=1)
         return self.cached_ids
 
-    def _tokenize_seq_batch_from_cached(self, ids: Tensor) -> Tensor:
-        b, n = ids.shape
-        return self.cached_ids[ids.flatten(), :].reshape(b, n * self.cached_ids.shape[1])
+    # ---- sequences of items -> sequences of id tokens ------------------------------------------------------
+    def _lookup(self, item_ids: Tensor) -> Tensor:
+        """[b, n] item numbers -> [b, n * width] tokens: each item becomes the `width` cached ids of its row."""
+        table = self.cached_ids
+        return table.index_select(0, item_ids.reshape(-1)).view(item_ids.shape[0], -1)
+
+    def _tokenize_seq_batch_from_cached(self, ids: Tensor) -> Tensor:   # the reference's name for `_lookup`
+        return self._lookup(ids)
+
+    @staticmethod
+    def _positions(width: int, rows: int, items: int, device) -> Tensor:
+        """token_type_ids: position of every token inside its item's tuple, 0..width-1 repeated `items` times."""
+        return torch.arange(width, device=device).repeat(rows, items)
 
     @torch.no_grad()
     @eval_mode
     def forward(self, batch: SeqBatch) -> TokenizedSeqBatch:
-        if self.cached_ids is None or batch.ids.max() >= self.cached_ids.shape[0]:
-            B, N = batch.ids.shape
-            sem_ids = self.rq_vae.get_semantic_ids(batch.x).sem_ids
-            D = sem_ids.shape[-1]
-            seq_mask, sem_ids_fut = None, None
+        """Two regimes, as in the reference (semids.py:117-146).  Without a usable cache (none yet, or an item number
+        beyond it) the batch's own features are quantised and the plain n_layers-wide tuples come back, no masks;
+        with one, history and target item numbers are replaced by their cached (n_layers + 1)-wide rows and padded
+        history positions are overwritten with -1."""
+        n_rows, n_items = batch.ids.shape
+        cache = self.cached_ids
+        use_cache = cache is not None and not bool(batch.ids.max() >= cache.shape[0])
+        if use_cache:
+            width = cache.shape[1]
+            valid = batch.seq_mask.repeat_interleave(width, dim=1)
+            history = self._lookup(batch.ids).masked_fill(~valid, -1)
+            target = self._lookup(batch.ids_fut)
         else:
-            B, N = batch.ids.shape
-            _, D = self.cached_ids.shape
-            sem_ids = self._tokenize_seq_batch_from_cached(batch.ids)
-            seq_mask = batch.seq_mask.repeat_interleave(D, dim=1)
-            sem_ids[~seq_mask] = -1
-            sem_ids_fut = self._tokenize_seq_batch_from_cached(batch.ids_fut)
-        token_type_ids = torch.arange(D, device=sem_ids.device).repeat(B, N)
-        token_type_ids_fut = torch.arange(D, device=sem_ids.device).repeat(B, 1)
-        return TokenizedSeqBatch(user_ids=batch.user_ids, sem_ids=sem_ids, sem_ids_fut=sem_ids_fut,
-                                 seq_mask=seq_mask, token_type_ids=token_type_ids,
-                                 token_type_ids_fut=token_type_ids_fut)
+            history = self.rq_vae.get_semantic_ids(batch.x).sem_ids
+            width = history.shape[-1]
+            valid = target = None
+        dev = history.device
+        return TokenizedSeqBatch(user_ids=batch.user_ids, sem_ids=history, sem_ids_fut=target, seq_mask=valid,
+                                 token_type_ids=self._positions(width, n_rows, n_items, dev),
+                                 token_type_ids_fut=self._positions(width, n_rows, 1, dev))

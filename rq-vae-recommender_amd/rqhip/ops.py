@@ -54,11 +54,15 @@ class RqForwardOut(NamedTuple):
     emb_sum: Optional[Tensor]    # [B,D]
     loss: Optional[Tensor]       # [B]
     embs_norm: Optional[Tensor]  # [B,L]
+    tie_margin: Optional[Tensor] = None  # [L,B] relative top-2 distance margin of each level's argmin
+
+
+TIE_TAU = 1e-6  # rows with tie_margin below this are near-ties: another correct fp32 evaluation may pick the other code
 
 
 def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_embs: bool = True,
                want_residuals: bool = True, want_emb_sum: bool = True, want_loss: bool = True,
-               want_norm: bool = True) -> RqForwardOut:
+               want_norm: bool = True, want_margin: bool = False) -> RqForwardOut:
     """L fused quantisation levels (rqhip_rq_forward).  res0 [B,D], codebooks [L,K,D]."""
     _need_gpu(res0, codebooks)
     res0, codebooks = _f32c(res0, "res0"), _f32c(codebooks, "codebooks")
@@ -76,12 +80,14 @@ def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_
         emb_sum = f(B, D) if want_emb_sum else None
         loss = f(B) if want_loss else None
         norm = f(B, L) if want_norm else None
+        margin = f(L, B) if want_margin else None
         wsb = l.rqhip_rq_forward_workspace_bytes(L, K)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         rc = l.rqhip_rq_forward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(embs),
-                                _ptr(residuals), _ptr(emb_sum), _ptr(loss), _ptr(norm), _ptr(ws), wsb, _stream())
+                                _ptr(residuals), _ptr(emb_sum), _ptr(loss), _ptr(norm), _ptr(margin), _ptr(ws), wsb,
+                                _stream())
         check(rc, "rqhip_rq_forward")
-    return RqForwardOut(ids, embs, residuals, emb_sum, loss, norm)
+    return RqForwardOut(ids, embs, residuals, emb_sum, loss, norm, margin)
 
 
 def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Tensor, *,

@@ -1,0 +1,125 @@
+"""Parity gate against reference-generated semantic ids (tests/golden/parity_*.npz).
+
+The fixtures are produced by oracle/gen_parity_fixtures.py, which runs the reference itself
+(/root/reference, CPU) at the BASELINE.json shapes.  This module holds what both the tests and
+bench.py's untimed parity gate need: regenerating the fixture's inputs bit for bit, comparing id tuples,
+and the tie policy -- a row may differ from the reference only where the kernel's own `tie_margin` output
+(include/rqhip.h) flags the level of first divergence as a near-tie; such rows are adjudicated in fp64.
+
+Nothing here touches oracle/: it compares HIP outputs with committed reference outputs.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+INPUT_DIM, HIDDEN, EMBED = 768, [512, 256, 128], 32
+TAU_KERNEL = 1e-6   # identical inputs: only the summation order of quantize.py:113-117 differs (few ulp)
+TAU_E2E = 2e-5      # inputs differ too: the encoder GEMMs (hipBLASLt vs MKL) perturb res0 by ~1e-6 relative
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests",
+                          "golden")
+
+
+def sha(a) -> str:
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.view(np.uint8).reshape(-1)).hexdigest()
+
+
+def load_fixture(tag: str) -> Dict[str, np.ndarray]:
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"parity_{tag}.npz")))
+
+
+def synthetic_items(n: int, seed: int = 1234) -> torch.Tensor:
+    """X = normalize(randn(n, 768)) from a seeded CPU generator."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.nn.functional.normalize(torch.randn(n, INPUT_DIM, generator=g), dim=-1)
+
+
+def regenerable_latents(n: int, scale: float, seed: int = 4321) -> np.ndarray:
+    z = np.random.Generator(np.random.PCG64(seed)).standard_normal((n, EMBED))
+    return (z * scale).astype(np.float32)
+
+
+def weights_sha(model) -> str:
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        if "embedding" in k:
+            continue
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().cpu().numpy()).view(np.uint8).reshape(-1))
+    return h.hexdigest()
+
+
+def build_fixture_model(fx: Dict[str, np.ndarray], device="cpu"):
+    """The fixture's model: `torch.manual_seed(0)` construction (same parameter order as the reference's
+    RqVae.__init__) with the fixture's codebooks; verified against the fixture's weight hash."""
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    K, L = int(fx["K"]), int(fx["L"])
+    torch.manual_seed(0)
+    model = RqVae(input_dim=INPUT_DIM, embed_dim=EMBED, hidden_dims=HIDDEN, codebook_size=K, n_layers=L,
+                  n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.STE,
+                  commitment_weight=float(fx["beta"]))
+    got = weights_sha(model)
+    if got != str(fx["weights_sha256"]):
+        raise RuntimeError("seed-0 construction does not reproduce the fixture's MLP weights "
+                           f"({got[:12]} vs {str(fx['weights_sha256'])[:12]})")
+    with torch.no_grad():
+        for l, layer in enumerate(model.layers):
+            layer.embedding.weight.copy_(torch.from_numpy(fx["codebooks"][l]))
+    return model.to(device)
+
+
+def reference_ids(fx: Dict[str, np.ndarray], training: bool) -> np.ndarray:
+    """[N,L] int64 ids the reference produced (eval mode, or STE training mode)."""
+    ids = fx["ids_eval"].astype(np.int64)
+    if training and len(fx["ids_train_diff_rows"]):
+        ids[fx["ids_train_diff_rows"]] = fx["ids_train_diff_vals"].astype(np.int64)
+    return ids
+
+
+def compare_ids(got: np.ndarray, ref: np.ndarray, tie_margin: np.ndarray, tau: float) -> Dict[str, object]:
+    """got, ref: [N,L] id tuples; tie_margin: [L,N] from the run that produced `got`.
+    A mismatching row is "flagged" when the margin at its FIRST differing level is below tau (later levels
+    differ as a consequence: the residual changed)."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    diff = got != ref
+    rows = np.nonzero(diff.any(axis=1))[0]
+    lev = diff[rows].argmax(axis=1)
+    marg = np.asarray(tie_margin)[lev, rows] if len(rows) else np.zeros((0,), np.float32)
+    n = got.shape[0]
+    return {
+        "rows_total": int(n), "mismatches": int(len(rows)),
+        "ids_exact_rate": float(1.0 - len(rows) / max(n, 1)),
+        "all_mismatches_flagged": bool((marg < tau).all()),
+        "rows_flagged": int((np.asarray(tie_margin).min(axis=0) < tau).sum()), "tau": float(tau),
+        "mismatch_rows": rows, "mismatch_level": lev, "mismatch_margin": marg,
+    }
+
+
+def adjudicate_fp64(residuals: np.ndarray, codebooks: np.ndarray, rows, levels, got: np.ndarray,
+                    ref: np.ndarray) -> np.ndarray:
+    """(d_got - d_ref) / d_min in float64 at each mismatching row's first differing level; residuals [L,N,D].
+    Negative: the code this run chose is the closer one in exact arithmetic."""
+    out = []
+    for i, l in zip(rows, levels):
+        x = residuals[l, i].astype(np.float64)
+        da = ((x - codebooks[l, got[i, l]].astype(np.float64)) ** 2).sum()
+        db = ((x - codebooks[l, ref[i, l]].astype(np.float64)) ** 2).sum()
+        out.append((da - db) / max(min(da, db), 1e-300))
+    return np.asarray(out, dtype=np.float64)
+
+
+def summary(cmp: Dict[str, object], extra: Optional[dict] = None) -> dict:
+    """JSON-friendly subset of compare_ids' result (bench line)."""
+    keep = ("rows_total", "mismatches", "ids_exact_rate", "all_mismatches_flagged", "rows_flagged", "tau")
+    d = {k: cmp[k] for k in keep}
+    d["mismatch_margins"] = [float(f"{m:.3e}") for m in cmp["mismatch_margin"][:8]]
+    if extra:
+        d.update(extra)
+    return d

@@ -83,7 +83,8 @@ class _DeviceBatcher:
 def _id_diversity(tokenizer: SemanticIdTokenizer, index_dataset: ItemData, n_layers: int, codebook_size: int) -> dict:
     """Entropy / codebook usage / duplicate statistics of train_rqvae.py:272-292."""
     tokenizer.reset()
-    corpus_ids = tokenizer.precompute_corpus_ids(index_dataset)
+    # every rank calls this (see the training loop), so the explicit sharded form is safe here
+    corpus_ids = tokenizer.precompute_corpus_ids(index_dataset, sharded=rqdist.world_size() > 1)
     n = corpus_ids.shape[0]
     log = {"max_id_duplicates": (corpus_ids[:, -1].max() / n).item()}
     _, counts = torch.unique(corpus_ids[:, :-1], dim=0, return_counts=True)
@@ -323,8 +324,11 @@ def train(
 
         if is_main and ((it + 1) % save_model_every == 0 or last):
             os.makedirs(save_dir_root, exist_ok=True)
-            torch.save({"iter": it, "model": model.state_dict(), "model_config": model.config,
-                        "optimizer": optimizer.state_dict()}, save_dir_root + f"checkpoint_{it}.pt")
+            state = {"iter": it, "model": model.state_dict(), "model_config": model.config,
+                     "optimizer": optimizer.state_dict()}
+            if getattr(train_dataset, "synthetic", False):
+                state["data"] = "synthetic"   # extra key: a checkpoint trained on noise says so
+            torch.save(state, save_dir_root + f"checkpoint_{it}.pt")
 
         if graphed is not None and ((do_eval and ((it + 1) % eval_every == 0 or last)) or (it + 1) % eval_every == 0
                                     or last or (it + 1) % save_model_every == 0):

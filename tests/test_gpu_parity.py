@@ -23,9 +23,9 @@ def _gpu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _run_forward(x, cbs, mode, beta=0.25):
+def _run_forward(x, cbs, mode, beta=0.25, want_margin=False):
     from rqhip import ops
-    out = ops.rq_forward(_gpu(x), _gpu(cbs), mode, beta)
+    out = ops.rq_forward(_gpu(x), _gpu(cbs), mode, beta, want_margin=want_margin)
     torch.cuda.synchronize()
     return {k: (None if v is None else v.cpu().numpy()) for k, v in out._asdict().items()}
 
@@ -40,10 +40,13 @@ def _assert_bitexact(got, ref, what):
 
 
 def _check_forward(x, cbs, mode, beta=0.25):
-    ref = o.rq_forward(x, cbs, mode, beta)
-    got = _run_forward(x, cbs, mode, beta)
-    for k in ("ids", "embs", "residuals", "emb_sum", "loss", "embs_norm"):
-        _assert_bitexact(got[k], ref[k], f"{k} (mode {mode}, B={x.shape[0]}, cb={cbs.shape})")
+    """Both kernel variants (plain, and the one that also tracks the runner-up distance for tie_margin) against
+    the oracle, every output bit for bit."""
+    ref = o.rq_forward(x, cbs, mode, beta, want_margin=True)
+    for want_margin in (False, True):
+        got = _run_forward(x, cbs, mode, beta, want_margin)
+        for k in ("ids", "embs", "residuals", "emb_sum", "loss", "embs_norm") + (("tie_margin",) if want_margin else ()):
+            _assert_bitexact(got[k], ref[k], f"{k} (mode {mode}, B={x.shape[0]}, cb={cbs.shape}, margin={want_margin})")
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -129,13 +132,13 @@ def test_forward_vs_reference_golden(name):
                                           (262_144, 32, 1024, 4, 0), (131_072, 64, 256, 3, 2)])
 def test_forward_full_size_properties(B, D, K, L, mode):
     """BASELINE config 2 (100k rows, 3 x 256), a config-4 shard (4 x 1024, LDS streaming mode) and the ml32m width
-    at full size: properties that do not need the oracle on every row -- ids in range, decode(ids) reproduces the
-    codewords, the residual chain closes, emb_sum is the level sum -- plus the oracle on a random 2k-row subsample."""
+    at full size: size-independent properties -- ids in range, decode(ids) reproduces the codewords, the residual
+    chain closes, emb_sum is the level sum -- and the oracle on EVERY row (ids, loss, norms, tie margins)."""
     from rqhip import ops
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, D, generator=g) * 0.5
     cbs = torch.randn(L, K, D, generator=g) * torch.tensor([0.5 / (l + 1) for l in range(L)])[:, None, None]
-    out = ops.rq_forward(x.cuda(), cbs.cuda(), mode, 0.25)
+    out = ops.rq_forward(x.cuda(), cbs.cuda(), mode, 0.25, want_margin=True)
     ids = out.ids.cpu()
     assert ids.min() >= 0 and ids.max() < K
     embs, res = out.embs.cpu(), out.residuals.cpu()
@@ -149,11 +152,13 @@ def test_forward_full_size_properties(B, D, K, L, mode):
     for l in range(1, L):
         acc = acc + embs[l]
     assert torch.equal(acc, out.emb_sum.cpu())
-    sel = torch.randperm(B, generator=g)[:2000]
-    ref = o.rq_forward(x[sel].numpy(), cbs.numpy(), mode, 0.25)
-    assert np.array_equal(ref["ids"], ids[:, sel].numpy())
-    _assert_bitexact(out.loss.cpu().numpy()[sel.numpy()], ref["loss"], "loss subsample")
-    _assert_bitexact(out.embs_norm.cpu().numpy()[sel.numpy()], ref["embs_norm"], "norm subsample")
+    ref = o.rq_forward(x.numpy(), cbs.numpy(), mode, 0.25, want_margin=True)
+    assert np.array_equal(ref["ids"], ids.numpy())
+    _assert_bitexact(out.loss.cpu().numpy(), ref["loss"], "loss")
+    _assert_bitexact(out.embs_norm.cpu().numpy(), ref["embs_norm"], "norm")
+    _assert_bitexact(out.tie_margin.cpu().numpy(), ref["tie_margin"], "tie_margin")
+    plain = ops.rq_forward(x.cuda(), cbs.cuda(), mode, 0.25, want_embs=False, want_residuals=False)
+    assert torch.equal(plain.ids.cpu(), ids) and torch.equal(plain.loss.cpu(), out.loss.cpu())
 
 
 # ---------------------------------------------------------------- backward ---------------------------

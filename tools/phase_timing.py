@@ -39,7 +39,7 @@ vp = C.c_void_p
 for _ in range(3):
     rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, 0, C.c_float(0.25),
                               vp(ids.data_ptr()), None, None, vp(es.data_ptr()), vp(loss.data_ptr()),
-                              vp(norm.data_ptr()), vp(ws.data_ptr()), C.c_size_t(wsb), None)
+                              vp(norm.data_ptr()), None, vp(ws.data_ptr()), C.c_size_t(wsb), None)
     assert rc == 0, rc
     torch.cuda.synchronize()
 buf = (C.c_ulonglong * 256)()
@@ -62,7 +62,7 @@ lib.rqhip_debug_trace(None, 1)
 torch.cuda.synchronize()
 rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, 0, C.c_float(0.25),
                           vp(ids.data_ptr()), None, None, vp(es.data_ptr()), vp(loss.data_ptr()),
-                          vp(norm.data_ptr()), vp(ws.data_ptr()), C.c_size_t(wsb), None)
+                          vp(norm.data_ptr()), None, vp(ws.data_ptr()), C.c_size_t(wsb), None)
 torch.cuda.synchronize()
 tr = np.zeros((4096, 16, 8), np.uint64)
 assert lib.rqhip_debug_trace(tr.ctypes.data_as(C.c_void_p), 0) == 0
