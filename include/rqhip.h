@@ -191,6 +191,24 @@ int rqhip_recon_loss_backward(const float *x_hat, int64_t ld_hat, const float *x
                               rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weight gradient of a bias-free Linear(+ReLU) layer with the ReLU backward fused in (SURVEY.md section 8 row f2;
+ * reference modules/encoder.py:25-38, autograd of `relu(x @ W.T)`).
+ *   g [M,N] gradient wrt the layer output, y [M,N] the layer's (ReLU) output or NULL (no ReLU), x [M,K] its input;
+ *   all dense row-major fp32, 16-byte aligned.
+ *   dW [N,K] = g_pre^T x  with  g_pre = g where y > 0 else 0  (g itself when y is NULL)      -- overwritten
+ *   g_masked [M,N] or NULL: receives g_pre for the data-gradient GEMM that follows; may alias g.
+ * The batch rows are split into ranges reduced in a fixed order (workspace holds the partial blocks): the result is
+ * bit-reproducible.  Layer shapes: rqhip_linear_wgrad_supported(N, K) (N, K multiples of the 32..256 tile shapes
+ * listed in csrc/wgrad.hip; every layer of the shipped 768-512-256-128-32 MLPs); others return RQHIP_EUNSUPPORTED
+ * and the caller keeps the library GEMM.
+ */
+int rqhip_linear_wgrad_supported(int N, int K);
+size_t rqhip_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
+int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K,
+                       float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
+                       rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every
  * rqhip_rq_forward call brackets its MAIN kernel (not the codebook-norm prologue) with a hipEvent pair
  * recorded on the call's stream.  rqhip_profile_read synchronises the recorded events and returns the

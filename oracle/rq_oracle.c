@@ -578,3 +578,33 @@ int rqo_topk_first_match(const int64_t *actual, const int64_t *top_k, int64_t B,
     }
     return RQO_OK;
 }
+
+/* ---- weight gradient of a bias-free Linear(+ReLU) layer (reference modules/encoder.py:25-38 under autograd) -----
+ * dW[n,k] = sum_m g_pre[m,n] x[m,k],  g_pre = g where y > 0 else 0 (aten threshold_backward; g itself when y == NULL).
+ * Restates csrc/wgrad.hip's FIXED summation order: the rows are cut into 32-row chunks, the chunks into `msplit`
+ * contiguous ranges (range s = chunks [C s / msplit, C (s+1) / msplit)); inside a range one fp32 FMA chain over the
+ * rows in ascending order (what the MFMA accumulates), then the ranges' partial sums are added in ascending order.
+ * g_masked [M,N] (optional) receives g_pre. */
+int rqo_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K, int msplit,
+                     float *g_masked, float *dW) {
+    if (M < 0 || N <= 0 || K <= 0 || msplit <= 0 || !g || !x || !dW) return RQO_EARG;
+    const int64_t C = (M + 31) / 32;
+    float *gp = (float *)malloc(sizeof(float) * (size_t)(M > 0 ? M : 1) * N);
+    if (!gp) return RQO_ENOMEM;
+    for (int64_t i = 0; i < M * N; ++i) gp[i] = (y && y[i] <= 0.0f) ? 0.0f : g[i];
+    if (g_masked) memcpy(g_masked, gp, sizeof(float) * (size_t)M * N);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            float total = 0.0f;
+            for (int s = 0; s < msplit; ++s) {
+                int64_t r0 = (C * s / msplit) * 32, r1 = (C * (s + 1) / msplit) * 32;
+                if (r1 > M) r1 = M;
+                float acc = 0.0f;
+                for (int64_t m = r0; m < r1; ++m) acc = fmaf(gp[(size_t)m * N + n], x[(size_t)m * K + k], acc);
+                total = (s == 0) ? acc : total + acc;
+            }
+            dW[(size_t)n * K + k] = total;
+        }
+    free(gp);
+    return RQO_OK;
+}

@@ -235,3 +235,17 @@ def recon_loss(x_hat, x) -> np.ndarray:
     out = np.empty((B,), np.float32)
     _chk(lib().rqo_recon_loss(_p(x_hat), _p(x), C.c_int64(B), C.c_int(N), _p(out)), "recon_loss")
     return out
+
+
+def linear_wgrad(g, y, x, msplit: int):
+    """dW = (g * (y > 0))^T x in csrc/wgrad.hip's summation order (see rq_oracle.c).  Returns (dW [N,K], g_pre [M,N])."""
+    g, x = _f(g), _f(x)
+    y = None if y is None else _f(y)
+    M, N = g.shape
+    K = x.shape[1]
+    dw = np.empty((N, K), np.float32)
+    gm = np.empty((M, N), np.float32)
+    rc = lib().rqo_linear_wgrad(_p(g), _p(y), _p(x), C.c_int64(M), C.c_int(N), C.c_int(K), C.c_int(msplit), _p(gm),
+                                _p(dw))
+    _chk(rc, "linear_wgrad")
+    return dw, gm

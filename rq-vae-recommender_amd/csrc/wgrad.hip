@@ -1,0 +1,317 @@
+// wgrad.hip -- weight gradient of a bias-free Linear(+ReLU) layer with the ReLU backward fused in (gfx950).
+//
+// SURVEY.md section 8 row f2 (reference modules/encoder.py:7-38: the encoder/decoder MLPs around the quantiser).
+// For y = relu(x W^T) autograd runs, per layer,   g_pre = gy * (y > 0)   (one elementwise pass over [M, N]),
+//   dW = g_pre^T x   (a GEMM whose reduction runs over the M = 100 000 batch rows)   and   gx = g_pre W.
+// The library does the dW shapes of this MLP badly -- tiny outputs (128 x 256 ... 512 x 768) with a huge reduction
+// dimension: 46-97 TFLOP/s on the small layers -- and the mask passes cost 0.32 ms of a 5.9 ms step.  This kernel
+// computes dW with the mask applied while the gradient rows are staged, and writes g_pre back once for the gx GEMM
+// that follows, so the separate pass disappears.
+//
+// Mapping
+//   * dW[n,k] = sum_m g_pre[m,n] x[m,k]:  v_mfma_f32_32x32x2_f32 with A = g_pre^T (32 n x 2 m), B = x (2 m x 32 k):
+//     the reduction index m is the ROW index of both operands, so both are consumed exactly as they lie in memory;
+//     no transposition anywhere.
+//   * a workgroup owns an Nt x Kt block of dW ("slab") and a contiguous range of rows; it streams 32-row chunks of
+//     gy / y / x through a double-buffered LDS stage (global_load_dwordx4 -> mask in registers -> ds_write_b128;
+//     the loads of chunk c+1 are in flight while chunk c is multiplied).
+//   * a wave owns (32 TA) x (32 TB) of the block.  Tile t of its TA n-tiles takes the features n0 + TA*i + t
+//     (i = lane & 31), so ONE ds_read_b128 / b64 / b32 of TA consecutive floats is the A operand of all TA tiles;
+//     likewise for k.  Per pair of rows: one A read, one B read, TA*TB MFMAs.  All LDS accesses are conflict free.
+//   * row ranges are reduced in a fixed order: every workgroup writes its partial block to the workspace and a second
+//     kernel sums the partials in ascending row-range order -- bit-reproducible, no atomics.
+//   * consecutive workgroups are different slabs of the SAME row range, so the gy / x strips they share are fetched
+//     from HBM once and hit in L2 / MALL for the others.
+#include "rqhip_common.h"
+
+namespace rqhip {
+
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWgChunk = 32;  // rows per LDS stage
+
+struct WgradParams {
+    const float *g;   // [M,N] upstream gradient wrt the layer output
+    const float *y;   // [M,N] layer output (ReLU applied) or nullptr: no mask
+    const float *x;   // [M,K] layer input
+    float *gm;        // [M,N] masked gradient written back (may alias g) or nullptr
+    float *out;       // partial blocks [msplit][N][K] (or dW itself when msplit == 1)
+    long long M;
+    int N, K;
+    int nslab_n, nslab_k, msplit;
+    long long n_chunks;  // ceil(M / 32)
+};
+
+template <int V>
+struct VecOf;
+template <>
+struct VecOf<1> { typedef float type; };
+template <>
+struct VecOf<2> { typedef wg_f32x2 type; };
+template <>
+struct VecOf<4> { typedef wg_f32x4 type; };
+
+template <int V>
+__device__ __forceinline__ float vec_get(const typename VecOf<V>::type &v, int i) {
+    if constexpr (V == 1) return v;
+    else return v[i];
+}
+
+// TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given
+template <int TA, int TB, int WA, int WB, bool MASK>
+__global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p) {
+    constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB, NT = 64 * WA * WB;
+    constexpr int MC = kWgChunk;
+    constexpr int G4 = MC * Nt / 4, X4 = MC * Kt / 4;           // float4s per stage
+    constexpr int GQ = (G4 + NT - 1) / NT, XQ = (X4 + NT - 1) / NT;  // per thread
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    float *sG = reinterpret_cast<float *>(wg_smem);            // [2][MC][Nt]
+    float *sX = sG + 2 * MC * Nt;                              // [2][MC][Kt]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    const int wa = wave / WB, wb = wave % WB;
+    const int nslabs = p.nslab_n * p.nslab_k;
+    const int slab = blockIdx.x % nslabs, split = blockIdx.x / nslabs;
+    const int slab_n = slab / p.nslab_k, slab_k = slab % p.nslab_k;
+    const int n0 = slab_n * Nt, k0 = slab_k * Kt;
+    const long long c_begin = p.n_chunks * split / p.msplit, c_end = p.n_chunks * (split + 1) / p.msplit;
+    const bool write_back = MASK && p.gm != nullptr && slab_k == 0;
+
+    wg_f32x16 acc[TA][TB];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    wg_f32x4 rg[GQ], ry[MASK ? GQ : 1], rx[XQ];
+    auto fetch = [&](long long chunk) {
+        const long long row0 = chunk * MC;
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int f = tid + q * NT;
+            const int r = f / (Nt / 4), c4 = f % (Nt / 4);
+            const long long row = row0 + r;
+            const bool ok = (G4 % NT == 0 || f < G4) && row < p.M;
+            const size_t off = (size_t)(ok ? row : 0) * p.N + n0 + 4 * c4;
+            rg[q] = ok ? *reinterpret_cast<const wg_f32x4 *>(p.g + off) : wg_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (MASK) ry[q] = ok ? *reinterpret_cast<const wg_f32x4 *>(p.y + off) : wg_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f = tid + q * NT;
+            const int r = f / (Kt / 4), c4 = f % (Kt / 4);
+            const long long row = row0 + r;
+            const bool ok = (X4 % NT == 0 || f < X4) && row < p.M;
+            rx[q] = ok ? *reinterpret_cast<const wg_f32x4 *>(p.x + (size_t)row * p.K + k0 + 4 * c4)
+                       : wg_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](long long chunk, int buf) {
+        const long long row0 = chunk * MC;
+        float *dG = sG + buf * MC * Nt, *dX = sX + buf * MC * Kt;
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int f = tid + q * NT;
+            if (G4 % NT != 0 && f >= G4) continue;
+            wg_f32x4 v = rg[q];
+            if (MASK) {  // threshold_backward(gy, y, 0): 0 where y <= 0
+                v.x = ry[q].x <= 0.0f ? 0.0f : v.x;
+                v.y = ry[q].y <= 0.0f ? 0.0f : v.y;
+                v.z = ry[q].z <= 0.0f ? 0.0f : v.z;
+                v.w = ry[q].w <= 0.0f ? 0.0f : v.w;
+            }
+            *reinterpret_cast<wg_f32x4 *>(dG + 4 * f) = v;
+            if (write_back) {
+                const int r = f / (Nt / 4), c4 = f % (Nt / 4);
+                const long long row = row0 + r;
+                if (row < p.M) *reinterpret_cast<wg_f32x4 *>(p.gm + (size_t)row * p.N + n0 + 4 * c4) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f = tid + q * NT;
+            if (X4 % NT != 0 && f >= X4) continue;
+            *reinterpret_cast<wg_f32x4 *>(dX + 4 * f) = rx[q];
+        }
+    };
+
+    if (c_begin < c_end) {
+        fetch(c_begin);
+        stash(c_begin, 0);
+    }
+    __syncthreads();
+    for (long long c = c_begin; c < c_end; ++c) {
+        const int buf = (int)((c - c_begin) & 1);
+        const bool more = c + 1 < c_end;
+        if (more) fetch(c + 1);
+        const float *gA = sG + buf * MC * Nt + wa * 32 * TA + TA * il;
+        const float *xB = sX + buf * MC * Kt + wb * 32 * TB + TB * il;
+        typename VecOf<TA>::type a_cur = *reinterpret_cast<const typename VecOf<TA>::type *>(gA + h * Nt);
+        typename VecOf<TB>::type b_cur = *reinterpret_cast<const typename VecOf<TB>::type *>(xB + h * Kt);
+#pragma unroll
+        for (int s = 0; s < MC / 2; ++s) {
+            typename VecOf<TA>::type a_nxt = a_cur;
+            typename VecOf<TB>::type b_nxt = b_cur;
+            if (s + 1 < MC / 2) {
+                a_nxt = *reinterpret_cast<const typename VecOf<TA>::type *>(gA + (2 * (s + 1) + h) * Nt);
+                b_nxt = *reinterpret_cast<const typename VecOf<TB>::type *>(xB + (2 * (s + 1) + h) * Kt);
+            }
+#pragma unroll
+            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                for (int u = 0; u < TB; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(vec_get<TA>(a_cur, t), vec_get<TB>(b_cur, u),
+                                                                     acc[t][u], 0, 0, 0);
+            a_cur = a_nxt;
+            b_cur = b_nxt;
+        }
+        if (more) stash(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r]: n = n0 + wave's
+    // 32 TA base + TA * (8 (r >> 2) + 4 h + (r & 3)) + t,  k = k0 + wave's 32 TB base + TB * il + u
+    float *dst = p.out + (size_t)split * p.N * p.K;
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wa * 32 * TA + TA * (8 * (r >> 2) + 4 * h + (r & 3)) + t;
+            float *row = dst + (size_t)n * p.K + k0 + wb * 32 * TB + TB * il;
+            if constexpr (TB == 1) {
+                row[0] = acc[t][0][r];
+            } else if constexpr (TB == 2) {
+                *reinterpret_cast<wg_f32x2 *>(row) = wg_f32x2{acc[t][0][r], acc[t][1][r]};
+            } else {
+                *reinterpret_cast<wg_f32x4 *>(row) = wg_f32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+            }
+        }
+}
+
+// dW = sum over row ranges, ascending (fixed order); one float4 per thread
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, size_t nk4, float *__restrict__ dw) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nk4) return;
+    const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(part) + i;
+    wg_f32x4 s = src[0];
+    for (int k = 1; k < msplit; ++k) {
+        const wg_f32x4 v = src[(size_t)k * nk4];
+        s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+    }
+    reinterpret_cast<wg_f32x4 *>(dw)[i] = s;
+}
+
+struct WgradPlan {
+    int cfg;            // 0: 256x256, 1: 128x256, 2: 256x128, 3: 32x128, 4: 128x32; -1: unsupported
+    int Nt, Kt;
+    int nslab_n, nslab_k, msplit;
+    size_t lds;
+};
+
+static WgradPlan wgrad_plan(long long M, int N, int K) {
+    WgradPlan pl;
+    pl.cfg = -1;
+    if (N % 256 == 0 && K % 256 == 0) { pl.cfg = 0; pl.Nt = 256; pl.Kt = 256; }
+    else if (N % 128 == 0 && K % 256 == 0) { pl.cfg = 1; pl.Nt = 128; pl.Kt = 256; }
+    else if (N % 256 == 0 && K % 128 == 0) { pl.cfg = 2; pl.Nt = 256; pl.Kt = 128; }
+    else if (N % 32 == 0 && K % 128 == 0) { pl.cfg = 3; pl.Nt = 32; pl.Kt = 128; }
+    else if (N % 128 == 0 && K % 32 == 0) { pl.cfg = 4; pl.Nt = 128; pl.Kt = 32; }
+    if (pl.cfg < 0) return pl;
+    pl.nslab_n = N / pl.Nt;
+    pl.nslab_k = K / pl.Kt;
+    const long long chunks = (M + kWgChunk - 1) / kWgChunk;
+    const int slabs = pl.nslab_n * pl.nslab_k;
+    long long ms = cu_count() / slabs;      // one workgroup per CU (the LDS stage is 40-128 KiB)
+    if (ms < 1) ms = 1;
+    if (ms > chunks) ms = chunks > 0 ? chunks : 1;
+    pl.msplit = (int)ms;
+    pl.lds = (size_t)2 * kWgChunk * (pl.Nt + pl.Kt) * sizeof(float);
+    return pl;
+}
+
+}  // namespace rqhip
+
+using namespace rqhip;
+
+extern "C" size_t rqhip_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const WgradPlan pl = wgrad_plan(M, N, K);
+    if (pl.cfg < 0 || pl.msplit <= 1) return 16;
+    return (size_t)pl.msplit * N * K * sizeof(float);
+}
+
+extern "C" int rqhip_linear_wgrad_supported(int N, int K) { return wgrad_plan(1 << 20, N, K).cfg >= 0 ? 1 : 0; }
+
+template <int TA, int TB, int WA, int WB>
+static int wgrad_launch(const WgradParams &p, const WgradPlan &pl, bool mask, hipStream_t s) {
+    auto go = [&](auto kern) -> int {
+        static bool attr_set[16] = {};
+        int dev = 0;
+        RQ_RETURN_IF_HIP(hipGetDevice(&dev));
+        if (dev < 16 && !attr_set[dev]) {
+            RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(pl.nslab_n * pl.nslab_k * pl.msplit), dim3(64 * WA * WB), pl.lds, s, p);
+        RQ_CHECK_LAUNCH("wgrad_kernel");
+        return 0;
+    };
+    return mask ? go(wgrad_kernel<TA, TB, WA, WB, true>) : go(wgrad_kernel<TA, TB, WA, WB, false>);
+}
+
+extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K,
+                                  float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
+                                  rqhip_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0 || !dW || (M > 0 && (!g || !x))) {
+        set_error("linear_wgrad: null pointer or bad size");
+        return RQHIP_EARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M == 0) {
+        RQ_RETURN_IF_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), s));
+        return RQHIP_OK;
+    }
+    const WgradPlan pl = wgrad_plan(M, N, K);
+    if (pl.cfg < 0) {
+        set_error("linear_wgrad: unsupported layer shape N=%d K=%d (see rqhip_linear_wgrad_supported)", N, K);
+        return RQHIP_EUNSUPPORTED;
+    }
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (!al16(g) || !al16(y) || !al16(x) || !al16(g_masked) || !al16(dW) || !al16(workspace)) {
+        set_error("linear_wgrad: pointers must be 16-byte aligned");
+        return RQHIP_EARG;
+    }
+    if (pl.msplit > 1 && (!workspace || workspace_bytes < rqhip_linear_wgrad_workspace_bytes(M, N, K))) {
+        set_error("linear_wgrad: workspace too small");
+        return RQHIP_EWORKSPACE;
+    }
+    WgradParams p;
+    p.g = g; p.y = y; p.x = x; p.gm = g_masked;
+    p.out = pl.msplit > 1 ? reinterpret_cast<float *>(workspace) : dW;
+    p.M = M; p.N = N; p.K = K;
+    p.nslab_n = pl.nslab_n; p.nslab_k = pl.nslab_k; p.msplit = pl.msplit;
+    p.n_chunks = (M + kWgChunk - 1) / kWgChunk;
+    const bool mask = y != nullptr;
+    int rc = 0;
+    switch (pl.cfg) {
+        case 0: rc = wgrad_launch<4, 2, 2, 4>(p, pl, mask, s); break;
+        case 1: rc = wgrad_launch<4, 1, 1, 8>(p, pl, mask, s); break;
+        case 2: rc = wgrad_launch<2, 2, 4, 2>(p, pl, mask, s); break;
+        case 3: rc = wgrad_launch<1, 1, 1, 4>(p, pl, mask, s); break;
+        default: rc = wgrad_launch<1, 1, 4, 1>(p, pl, mask, s); break;
+    }
+    if (rc) return rc;
+    if (pl.msplit > 1) {
+        const size_t nk4 = (size_t)N * K / 4;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float *>(workspace), pl.msplit, nk4, dW);
+        RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
+    }
+    return RQHIP_OK;
+}

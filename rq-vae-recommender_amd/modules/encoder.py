@@ -4,8 +4,8 @@ The encoder/decoder GEMMs stay library GEMMs on PyTorch-ROCm (fp32, `rqhip/tunin
 GPU every Linear that is followed by a ReLU runs as ONE hipBLASLt call with the ReLU in the GEMM epilogue
 (`torch._addmm_activation` with a zero bias) instead of a GEMM plus an elementwise pass over the activations:
 -0.29 ms of a 6.1 ms step at 100 000 rows (`tools/relu_epilogue_probe.py`).  The op has no autograd formula, so
-`_LinearReLU` supplies the two backward GEMMs and the ReLU mask itself -- the same three kernels autograd runs
-for linear + relu.  Parameter names are `mlp.{0,2,4,...}.weight`, as in the reference, so checkpoints load in both
+`_LinearReLU` supplies the backward itself: the weight gradient WITH the ReLU mask fused is one hand-written kernel
+(`csrc/wgrad.hip`), the input gradient a library GEMM on the masked gradient it hands over.  Parameter names are `mlp.{0,2,4,...}.weight`, as in the reference, so checkpoints load in both
 directions."""
 from typing import List
 
@@ -13,10 +13,19 @@ import torch
 from torch import Tensor, nn
 
 from modules.normalize import L2NormalizationLayer
+from rqhip import ops
+
+
+def _hip_wgrad_ok(g: Tensor, w: Tensor) -> bool:
+    return (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[0] > 0
+            and ops.linear_wgrad_supported(w.shape[0], w.shape[1]))
 
 
 class _LinearReLU(torch.autograd.Function):
-    """relu(x @ w.T) for 2-D fp32 ROCm tensors, ReLU fused into the GEMM epilogue."""
+    """relu(x @ w.T) for 2-D fp32 ROCm tensors, ReLU fused into the GEMM epilogue.  Backward: the weight gradient and
+    the ReLU mask are ONE hand-written kernel (csrc/wgrad.hip), which also hands the masked gradient to the library
+    GEMM that forms the input gradient; shapes the kernel does not tile keep the three library kernels autograd
+    would run (mask, two GEMMs)."""
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, zero_bias: Tensor) -> Tensor:
@@ -27,10 +36,33 @@ class _LinearReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy: Tensor):
         x, w, y = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
-        gx = g.mm(w) if ctx.needs_input_grad[0] else None      # and the two GEMMs it does for linear
-        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_w and _hip_wgrad_ok(gy, w):
+            gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x)
+        else:
+            g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
+            gw = g.t().mm(x) if need_w else None
+        gx = g.mm(w) if need_x else None
         return gx, gw, None
+
+
+class _LinearPlain(torch.autograd.Function):
+    """x @ w.T (the last layer of each MLP: no ReLU), weight gradient by csrc/wgrad.hip."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor) -> Tensor:
+        ctx.save_for_backward(x, w)
+        return x.mm(w.t())
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, w = ctx.saved_tensors
+        need_x, need_w = ctx.needs_input_grad
+        gw = None
+        if need_w:
+            gw = ops.linear_wgrad(gy, None, x)[0] if _hip_wgrad_ok(gy, w) else gy.t().mm(x)
+        gx = gy.mm(w) if need_x else None
+        return gx, gw
 
 
 class MLP(nn.Module):
@@ -71,6 +103,9 @@ class MLP(nn.Module):
                     and isinstance(layers[i + 1], nn.ReLU)):
                 x = _LinearReLU.apply(x, layer.weight, self._zero_bias(layer.out_features, x))
                 i += 2
+            elif isinstance(layer, nn.Linear) and layer.bias is None:
+                x = _LinearPlain.apply(x, layer.weight)
+                i += 1
             else:
                 x = layer(x)
                 i += 1

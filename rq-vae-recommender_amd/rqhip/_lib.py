@@ -44,6 +44,9 @@ SIGNATURES = {
     "rqhip_topk_first_match": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
     "rqhip_recon_loss_forward": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _vp, _vp]),
     "rqhip_recon_loss_backward": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+    "rqhip_linear_wgrad_supported": (_int, [_int, _int]),
+    "rqhip_linear_wgrad_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "rqhip_linear_wgrad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),
 }

@@ -330,3 +330,30 @@ def recon_loss_backward(x_hat: Tensor, x: Tensor, g_out: Tensor, need_hat: bool 
                                                   _ptr(g_hat), _ptr(g_x), _stream())
         check(rc, "rqhip_recon_loss_backward")
     return g_hat, g_x
+
+
+def linear_wgrad_supported(n_out: int, n_in: int) -> bool:
+    return bool(_lib.lib().rqhip_linear_wgrad_supported(int(n_out), int(n_in)))
+
+
+def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool = True):
+    """dW [N,K] = (g * (y > 0))^T x with the ReLU backward fused (rqhip_linear_wgrad); y None = layer without ReLU.
+    Returns (dW, g_pre): g_pre = the masked gradient in a fresh tensor when `want_masked` and y is given (the input
+    of the data-gradient GEMM that follows), g itself when there is no mask, None when not wanted."""
+    _need_gpu(g, y, x)
+    g, x = _f32c(g, "g"), _f32c(x, "x")
+    y = _f32c(y, "y")
+    if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0] or (y is not None and y.shape != g.shape):
+        raise RqHipError(f"linear_wgrad: shapes g {tuple(g.shape)}, x {tuple(x.shape)}")
+    M, N = g.shape
+    K = x.shape[1]
+    dev = g.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        wsb = l.rqhip_linear_wgrad_workspace_bytes(M, N, K)
+        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+        gm = torch.empty_like(g) if (want_masked and y is not None) else None
+        rc = l.rqhip_linear_wgrad(_ptr(g), _ptr(y), _ptr(x), M, N, K, _ptr(gm), _ptr(dw), _ptr(ws), wsb, _stream())
+        check(rc, "rqhip_linear_wgrad")
+    return dw, (g if y is None else gm)

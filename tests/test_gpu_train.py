@@ -39,7 +39,9 @@ def test_train_amazon_config_short_run_checkpoint_and_resume(tmp_path, monkeypat
     ckpt = os.path.join(out_dir, "checkpoint_11.pt")
     assert os.path.exists(ckpt)
     state = torch.load(ckpt, map_location="cpu", weights_only=False)
-    assert set(state) == {"iter", "model", "model_config", "optimizer"} and state["iter"] == 11
+    # the reference's four keys; a run on the opt-in synthetic corpus (RQ_SYNTH_ITEMS, as here) adds the marker "data"
+    assert set(state) == {"iter", "model", "model_config", "optimizer", "data"} and state["iter"] == 11
+    assert state["data"] == "synthetic"
     assert {"layers.0.embedding.weight", "encoder.mlp.0.weight", "decoder.mlp.6.weight"} <= set(state["model"])
     assert state["model"]["layers.0.embedding.weight"].shape == (256, 32)
     # resume: start_iter = iter + 1, optimizer state restored, k-means init skipped
