@@ -190,6 +190,18 @@ int rqhip_recon_loss_backward(const float *x_hat, int64_t ld_hat, const float *x
                               const float *g_out, int64_t B, int N, float *g_x_hat, float *g_x,
                               rqhip_stream_t stream);
 
+/* Speculative form of the pair above for the training step: the forward also writes the gradient it expects to be
+ * asked for, g_spec[b,:] = (2 (x_hat - x)) * row_scale -- `(reconstruction + quantize_loss).mean().backward()`
+ * (modules/rqvae.py:152-154) sends row_scale = 1/B to every row -- and the backward only re-does rows whose upstream
+ * gradient g_out[b] is NOT bit-identical to row_scale (exactly what rqhip_recon_loss_backward would write).  Same
+ * results as the plain pair in every case; one HBM pass instead of two when the expectation holds.
+ * Needs N and the strides multiples of 4 and 16-byte aligned pointers (else RQHIP_EUNSUPPORTED: use the plain pair). */
+int rqhip_recon_loss_forward_spec(const float *x_hat, int64_t ld_hat, const float *x, int64_t ld_x, int64_t B, int N,
+                                  float row_scale, float *out, float *g_spec, rqhip_stream_t stream);
+int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat, const float *x, int64_t ld_x,
+                                   const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
+                                   rqhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of a bias-free Linear(+ReLU) layer with the ReLU backward fused in (SURVEY.md section 8 row f2;
  * reference modules/encoder.py:25-38, autograd of `relu(x @ W.T)`).
@@ -203,6 +215,9 @@ int rqhip_recon_loss_backward(const float *x_hat, int64_t ld_hat, const float *x
  * and the caller keeps the library GEMM.
  */
 int rqhip_linear_wgrad_supported(int N, int K);
+/* returns the tile configuration (>= 0) or -1, and the number of row ranges the kernel will reduce over (tests restate
+ * the summation order with it) */
+int rqhip_linear_wgrad_plan(int64_t M, int N, int K, int *msplit);
 size_t rqhip_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                        float *g_masked, float *dW, void *workspace, size_t workspace_bytes,

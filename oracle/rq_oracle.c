@@ -581,30 +581,37 @@ int rqo_topk_first_match(const int64_t *actual, const int64_t *top_k, int64_t B,
 
 /* ---- weight gradient of a bias-free Linear(+ReLU) layer (reference modules/encoder.py:25-38 under autograd) -----
  * dW[n,k] = sum_m g_pre[m,n] x[m,k],  g_pre = g where y > 0 else 0 (aten threshold_backward; g itself when y == NULL).
- * Restates csrc/wgrad.hip's FIXED summation order: the rows are cut into 32-row chunks, the chunks into `msplit`
- * contiguous ranges (range s = chunks [C s / msplit, C (s+1) / msplit)); inside a range one fp32 FMA chain over the
- * rows in ascending order (what the MFMA accumulates), then the ranges' partial sums are added in ascending order.
+ * Restates csrc/wgrad.hip's FIXED summation order: the rows are cut into 32-row granules, the granules into `msplit`
+ * contiguous ranges (range s = granules [C s / msplit, C (s+1) / msplit)); inside a range one fp32 FMA chain over the
+ * rows in ascending order (what the MFMA accumulates); the ranges' sums are then added as a balanced binary tree:
+ * padded with zeros to a power of two, a[j] += a[j+s] for j a multiple of 2s, s = 1, 2, 4, ...
  * g_masked [M,N] (optional) receives g_pre. */
 int rqo_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K, int msplit,
                      float *g_masked, float *dW) {
     if (M < 0 || N <= 0 || K <= 0 || msplit <= 0 || !g || !x || !dW) return RQO_EARG;
     const int64_t C = (M + 31) / 32;
+    int P = 1;
+    while (P < msplit) P <<= 1;
     float *gp = (float *)malloc(sizeof(float) * (size_t)(M > 0 ? M : 1) * N);
-    if (!gp) return RQO_ENOMEM;
+    float *leaf = (float *)malloc(sizeof(float) * (size_t)P);
+    if (!gp || !leaf) { free(gp); free(leaf); return RQO_ENOMEM; }
     for (int64_t i = 0; i < M * N; ++i) gp[i] = (y && y[i] <= 0.0f) ? 0.0f : g[i];
     if (g_masked) memcpy(g_masked, gp, sizeof(float) * (size_t)M * N);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
-            float total = 0.0f;
-            for (int s = 0; s < msplit; ++s) {
-                int64_t r0 = (C * s / msplit) * 32, r1 = (C * (s + 1) / msplit) * 32;
-                if (r1 > M) r1 = M;
+            for (int s = 0; s < P; ++s) {
                 float acc = 0.0f;
-                for (int64_t m = r0; m < r1; ++m) acc = fmaf(gp[(size_t)m * N + n], x[(size_t)m * K + k], acc);
-                total = (s == 0) ? acc : total + acc;
+                if (s < msplit) {
+                    int64_t r0 = (C * s / msplit) * 32, r1 = (C * (s + 1) / msplit) * 32;
+                    if (r1 > M) r1 = M;
+                    for (int64_t m = r0; m < r1; ++m) acc = fmaf(gp[(size_t)m * N + n], x[(size_t)m * K + k], acc);
+                }
+                leaf[s] = acc;
             }
-            dW[(size_t)n * K + k] = total;
+            for (int s = 1; s < P; s <<= 1)
+                for (int j = 0; j < P; j += 2 * s) leaf[j] = leaf[j] + leaf[j + s];
+            dW[(size_t)n * K + k] = leaf[0];
         }
-    free(gp);
+    free(gp); free(leaf);
     return RQO_OK;
 }

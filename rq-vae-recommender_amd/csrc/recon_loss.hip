@@ -81,6 +81,59 @@ __global__ __launch_bounds__(256) void recon_bwd_kernel(const float *__restrict_
     }
 }
 
+// Forward that also writes the gradient it EXPECTS to be asked for: g_spec[b,:] = (2 (x_hat - x)) * row_scale, the
+// value recon_bwd_kernel produces when the upstream gradient of row b equals row_scale -- which is what
+// `(reconstruction + quantize_loss).mean().backward()` (rqvae.py:152-154) sends: 1/B for every row.  One pass
+// (read x_hat, x; write g_spec) replaces the forward pass plus most of the backward pass.
+__global__ __launch_bounds__(256) void recon_fwd_spec_kernel(const float *__restrict__ xh, long long ldh,
+                                                             const float *__restrict__ x, long long ldx, long long B,
+                                                             int N, float row_scale, float *__restrict__ out,
+                                                             float *__restrict__ gs) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long row = gw; row < B; row += waves) {   // (caller guarantees the float4 layout)
+        const float *a = xh + row * ldh, *b = x + row * ldx;
+        float s = 0.0f;
+        for (int i = lane; i < N / 4; i += 64) {
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(a + 4 * i);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(b + 4 * i);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = u[j] - v[j];
+                s = s + d * d;
+                o[j] = (2.0f * d) * row_scale;
+            }
+            *reinterpret_cast<f32x4 *>(gs + row * (long long)N + 4 * i) = o;
+        }
+        s = butterfly_sum(s);
+        if (lane == 0) out[row] = s;
+    }
+}
+
+// Backward of the above: rows whose upstream gradient IS row_scale (bit for bit) are already right and are not
+// touched; any other row is recomputed exactly as recon_bwd_kernel would.  In a training step this reads B floats.
+__global__ __launch_bounds__(256) void recon_bwd_spec_kernel(const float *__restrict__ xh, long long ldh,
+                                                             const float *__restrict__ x, long long ldx,
+                                                             const float *__restrict__ g, long long B, int N,
+                                                             float row_scale, float *__restrict__ gs) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long row = gw; row < B; row += waves) {
+        const float gr = g[row];
+        if (__float_as_uint(gr) == __float_as_uint(row_scale)) continue;
+        const float *a = xh + row * ldh, *b = x + row * ldx;
+        for (int i = lane; i < N / 4; i += 64) {
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(a + 4 * i);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(b + 4 * i);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (2.0f * (u[j] - v[j])) * gr;
+            *reinterpret_cast<f32x4 *>(gs + row * (long long)N + 4 * i) = o;
+        }
+    }
+}
+
 static int row_grid(long long B) {
     long long want = (B + 3) / 4, cap = (long long)cu_count() * 8;
     if (want < 1) want = 1;
@@ -116,5 +169,46 @@ extern "C" int rqhip_recon_loss_backward(const float *x_hat, int64_t ld_hat, con
     hipLaunchKernelGGL(recon_bwd_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x_hat,
                        (long long)ld_hat, x, (long long)ld_x, g_out, (long long)B, N, g_x_hat, g_x);
     RQ_CHECK_LAUNCH("recon_bwd_kernel");
+    return RQHIP_OK;
+}
+
+static bool recon_vec_ok(const void *a, const void *b, const void *c, int64_t ld_hat, int64_t ld_x, int N) {
+    return (N & 3) == 0 && (ld_hat & 3) == 0 && (ld_x & 3) == 0 &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+extern "C" int rqhip_recon_loss_forward_spec(const float *x_hat, int64_t ld_hat, const float *x, int64_t ld_x,
+                                             int64_t B, int N, float row_scale, float *out, float *g_spec,
+                                             rqhip_stream_t stream) {
+    if (B < 0 || N < 1 || ld_hat < N || ld_x < N || (B > 0 && (!x_hat || !x || !out || !g_spec))) {
+        set_error("recon_loss_forward_spec: bad arguments");
+        return RQHIP_EARG;
+    }
+    if (!recon_vec_ok(x_hat, x, g_spec, ld_hat, ld_x, N)) {
+        set_error("recon_loss_forward_spec: needs N, strides multiples of 4 and 16-byte aligned pointers");
+        return RQHIP_EUNSUPPORTED;
+    }
+    if (B == 0) return RQHIP_OK;
+    hipLaunchKernelGGL(recon_fwd_spec_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x_hat, (long long)ld_hat, x, (long long)ld_x, (long long)B, N, row_scale, out, g_spec);
+    RQ_CHECK_LAUNCH("recon_fwd_spec_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat, const float *x, int64_t ld_x,
+                                              const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
+                                              rqhip_stream_t stream) {
+    if (B < 0 || N < 1 || ld_hat < N || ld_x < N || (B > 0 && (!x_hat || !x || !g_out || !g_spec))) {
+        set_error("recon_loss_backward_spec: bad arguments");
+        return RQHIP_EARG;
+    }
+    if (!recon_vec_ok(x_hat, x, g_spec, ld_hat, ld_x, N)) {
+        set_error("recon_loss_backward_spec: needs N, strides multiples of 4 and 16-byte aligned pointers");
+        return RQHIP_EUNSUPPORTED;
+    }
+    if (B == 0) return RQHIP_OK;
+    hipLaunchKernelGGL(recon_bwd_spec_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x_hat, (long long)ld_hat, x, (long long)ld_x, g_out, (long long)B, N, row_scale, g_spec);
+    RQ_CHECK_LAUNCH("recon_bwd_spec_kernel");
     return RQHIP_OK;
 }

@@ -19,7 +19,11 @@
 //     (i = lane & 31), so ONE ds_read_b128 / b64 / b32 of TA consecutive floats is the A operand of all TA tiles;
 //     likewise for k.  Per pair of rows: one A read, one B read, TA*TB MFMAs.  All LDS accesses are conflict free.
 //   * row ranges are reduced in a fixed order: every workgroup writes its partial block to the workspace and a second
-//     kernel sums the partials in ascending row-range order -- bit-reproducible, no atomics.
+//     kernel adds the partials as a balanced binary tree over the range index (adjacent pairs first) -- bit-reproducible,
+//     no atomics, and parallel: a first version summed the 42..256 partials of an element sequentially in one thread
+//     and that chain of dependent loads, not the GEMM, was most of the small layers' time.
+//   * measured dead end: an LDS-free variant in which every lane loads its own operands straight into a register
+//     ring (16 row pairs ahead) is 30 % SLOWER on the big layers (each strip is fetched by 4 / 2 waves through L1).
 //   * consecutive workgroups are different slabs of the SAME row range, so the gy / x strips they share are fetched
 //     from HBM once and hit in L2 / MALL for the others.
 #include "rqhip_common.h"
@@ -30,7 +34,7 @@ typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kWgChunk = 32;  // rows per LDS stage
+constexpr int kWgChunk = 32;  // granularity of the row ranges (part of the summation-order contract, see the oracle)
 
 struct WgradParams {
     const float *g;   // [M,N] upstream gradient wrt the layer output
@@ -42,6 +46,7 @@ struct WgradParams {
     int N, K;
     int nslab_n, nslab_k, msplit;
     long long n_chunks;  // ceil(M / 32)
+    int pow2;            // msplit rounded up to a power of two (reduction tree)
 };
 
 template <int V>
@@ -59,11 +64,10 @@ __device__ __forceinline__ float vec_get(const typename VecOf<V>::type &v, int i
     else return v[i];
 }
 
-// TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given
-template <int TA, int TB, int WA, int WB, bool MASK>
+// TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given; MC: rows per LDS stage
+template <int TA, int TB, int WA, int WB, bool MASK, int MC>
 __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p) {
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB, NT = 64 * WA * WB;
-    constexpr int MC = kWgChunk;
     constexpr int G4 = MC * Nt / 4, X4 = MC * Kt / 4;           // float4s per stage
     constexpr int GQ = (G4 + NT - 1) / NT, XQ = (X4 + NT - 1) / NT;  // per thread
     extern __shared__ __attribute__((aligned(16))) char wg_smem[];
@@ -77,7 +81,11 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
     const int slab = blockIdx.x % nslabs, split = blockIdx.x / nslabs;
     const int slab_n = slab / p.nslab_k, slab_k = slab % p.nslab_k;
     const int n0 = slab_n * Nt, k0 = slab_k * Kt;
-    const long long c_begin = p.n_chunks * split / p.msplit, c_end = p.n_chunks * (split + 1) / p.msplit;
+    // row range of this workgroup: granules [G s / msplit, G (s+1) / msplit) of 32 rows; walked in stages of MC rows
+    const long long r_begin = (p.n_chunks * split / p.msplit) * kWgChunk;
+    long long r_end = (p.n_chunks * (split + 1) / p.msplit) * kWgChunk;
+    if (r_end > p.M) r_end = p.M;
+    const long long c_begin = 0, c_end = (r_end - r_begin + MC - 1) / MC;   // stages
     const bool write_back = MASK && p.gm != nullptr && slab_k == 0;
 
     wg_f32x16 acc[TA][TB];
@@ -90,13 +98,13 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
 
     wg_f32x4 rg[GQ], ry[MASK ? GQ : 1], rx[XQ];
     auto fetch = [&](long long chunk) {
-        const long long row0 = chunk * MC;
+        const long long row0 = r_begin + chunk * MC;
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
             const int f = tid + q * NT;
             const int r = f / (Nt / 4), c4 = f % (Nt / 4);
             const long long row = row0 + r;
-            const bool ok = (G4 % NT == 0 || f < G4) && row < p.M;
+            const bool ok = (G4 % NT == 0 || f < G4) && row < r_end;
             const size_t off = (size_t)(ok ? row : 0) * p.N + n0 + 4 * c4;
             rg[q] = ok ? *reinterpret_cast<const wg_f32x4 *>(p.g + off) : wg_f32x4{0.f, 0.f, 0.f, 0.f};
             if (MASK) ry[q] = ok ? *reinterpret_cast<const wg_f32x4 *>(p.y + off) : wg_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -106,13 +114,13 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
             const int f = tid + q * NT;
             const int r = f / (Kt / 4), c4 = f % (Kt / 4);
             const long long row = row0 + r;
-            const bool ok = (X4 % NT == 0 || f < X4) && row < p.M;
+            const bool ok = (X4 % NT == 0 || f < X4) && row < r_end;
             rx[q] = ok ? *reinterpret_cast<const wg_f32x4 *>(p.x + (size_t)row * p.K + k0 + 4 * c4)
                        : wg_f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stash = [&](long long chunk, int buf) {
-        const long long row0 = chunk * MC;
+        const long long row0 = r_begin + chunk * MC;
         float *dG = sG + buf * MC * Nt, *dX = sX + buf * MC * Kt;
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
             if (write_back) {
                 const int r = f / (Nt / 4), c4 = f % (Nt / 4);
                 const long long row = row0 + r;
-                if (row < p.M) *reinterpret_cast<wg_f32x4 *>(p.gm + (size_t)row * p.N + n0 + 4 * c4) = v;
+                if (row < r_end) *reinterpret_cast<wg_f32x4 *>(p.gm + (size_t)row * p.N + n0 + 4 * c4) = v;
             }
         }
 #pragma unroll
@@ -193,34 +201,51 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
         }
 }
 
-// dW = sum over row ranges, ascending (fixed order); one float4 per thread
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, size_t nk4, float *__restrict__ dw) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nk4) return;
-    const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(part) + i;
-    wg_f32x4 s = src[0];
-    for (int k = 1; k < msplit; ++k) {
-        const wg_f32x4 v = src[(size_t)k * nk4];
-        s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+// dW = balanced-tree sum of the row ranges' partial blocks: leaves padded with zeros to a power of two P, then
+// a[j] += a[j + s] for every j that is a multiple of 2s, s = 1, 2, 4, ... (adjacent pairs first; fixed order).
+// A workgroup owns kRedElems float4 elements of dW, stages all their partials in LDS and walks the tree there.
+constexpr int kRedElems = 4;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, int pow2,
+                                                           size_t nk4, float *__restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) char red_smem[];
+    wg_f32x4 *a = reinterpret_cast<wg_f32x4 *>(red_smem);   // [pow2][kRedElems]
+    const size_t base = (size_t)blockIdx.x * kRedElems;
+    const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(part);
+    for (int i = threadIdx.x; i < pow2 * kRedElems; i += 256) {
+        const int k = i / kRedElems, e = i % kRedElems;
+        a[i] = (k < msplit && base + e < nk4) ? src[(size_t)k * nk4 + base + e] : wg_f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    reinterpret_cast<wg_f32x4 *>(dw)[i] = s;
+    __syncthreads();
+    for (int s = 1; s < pow2; s <<= 1) {
+        const int pairs = pow2 / (2 * s) * kRedElems;
+        for (int i = threadIdx.x; i < pairs; i += 256) {
+            const int j = (i / kRedElems) * 2 * s, e = i % kRedElems;
+            wg_f32x4 l = a[j * kRedElems + e];
+            const wg_f32x4 r = a[(j + s) * kRedElems + e];
+            l.x = l.x + r.x; l.y = l.y + r.y; l.z = l.z + r.z; l.w = l.w + r.w;
+            a[j * kRedElems + e] = l;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kRedElems && base + threadIdx.x < nk4)
+        reinterpret_cast<wg_f32x4 *>(dw)[base + threadIdx.x] = a[threadIdx.x];
 }
 
 struct WgradPlan {
     int cfg;            // 0: 256x256, 1: 128x256, 2: 256x128, 3: 32x128, 4: 128x32; -1: unsupported
-    int Nt, Kt;
-    int nslab_n, nslab_k, msplit;
+    int Nt, Kt, mc;     // block of dW per workgroup, rows per LDS stage
+    int nslab_n, nslab_k, msplit, pow2;
     size_t lds;
 };
 
 static WgradPlan wgrad_plan(long long M, int N, int K) {
     WgradPlan pl;
     pl.cfg = -1;
-    if (N % 256 == 0 && K % 256 == 0) { pl.cfg = 0; pl.Nt = 256; pl.Kt = 256; }
-    else if (N % 128 == 0 && K % 256 == 0) { pl.cfg = 1; pl.Nt = 128; pl.Kt = 256; }
-    else if (N % 256 == 0 && K % 128 == 0) { pl.cfg = 2; pl.Nt = 256; pl.Kt = 128; }
-    else if (N % 32 == 0 && K % 128 == 0) { pl.cfg = 3; pl.Nt = 32; pl.Kt = 128; }
-    else if (N % 128 == 0 && K % 32 == 0) { pl.cfg = 4; pl.Nt = 128; pl.Kt = 32; }
+    if (N % 256 == 0 && K % 256 == 0) { pl.cfg = 0; pl.Nt = 256; pl.Kt = 256; pl.mc = 32; }
+    else if (N % 128 == 0 && K % 256 == 0) { pl.cfg = 1; pl.Nt = 128; pl.Kt = 256; pl.mc = 32; }
+    else if (N % 256 == 0 && K % 128 == 0) { pl.cfg = 2; pl.Nt = 256; pl.Kt = 128; pl.mc = 32; }
+    else if (N % 32 == 0 && K % 128 == 0) { pl.cfg = 3; pl.Nt = 32; pl.Kt = 128; pl.mc = 64; }
+    else if (N % 128 == 0 && K % 32 == 0) { pl.cfg = 4; pl.Nt = 128; pl.Kt = 32; pl.mc = 64; }
     if (pl.cfg < 0) return pl;
     pl.nslab_n = N / pl.Nt;
     pl.nslab_k = K / pl.Kt;
@@ -230,7 +255,9 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
     if (ms < 1) ms = 1;
     if (ms > chunks) ms = chunks > 0 ? chunks : 1;
     pl.msplit = (int)ms;
-    pl.lds = (size_t)2 * kWgChunk * (pl.Nt + pl.Kt) * sizeof(float);
+    pl.pow2 = 1;
+    while (pl.pow2 < pl.msplit) pl.pow2 <<= 1;
+    pl.lds = (size_t)2 * pl.mc * (pl.Nt + pl.Kt) * sizeof(float);
     return pl;
 }
 
@@ -247,7 +274,13 @@ extern "C" size_t rqhip_linear_wgrad_workspace_bytes(int64_t M, int N, int K) {
 
 extern "C" int rqhip_linear_wgrad_supported(int N, int K) { return wgrad_plan(1 << 20, N, K).cfg >= 0 ? 1 : 0; }
 
-template <int TA, int TB, int WA, int WB>
+extern "C" int rqhip_linear_wgrad_plan(int64_t M, int N, int K, int *msplit) {
+    const WgradPlan pl = wgrad_plan(M, N, K);
+    if (msplit) *msplit = pl.cfg < 0 ? 0 : pl.msplit;
+    return pl.cfg;
+}
+
+template <int TA, int TB, int WA, int WB, int MC>
 static int wgrad_launch(const WgradParams &p, const WgradPlan &pl, bool mask, hipStream_t s) {
     auto go = [&](auto kern) -> int {
         static bool attr_set[16] = {};
@@ -262,7 +295,7 @@ static int wgrad_launch(const WgradParams &p, const WgradPlan &pl, bool mask, hi
         RQ_CHECK_LAUNCH("wgrad_kernel");
         return 0;
     };
-    return mask ? go(wgrad_kernel<TA, TB, WA, WB, true>) : go(wgrad_kernel<TA, TB, WA, WB, false>);
+    return mask ? go(wgrad_kernel<TA, TB, WA, WB, true, MC>) : go(wgrad_kernel<TA, TB, WA, WB, false, MC>);
 }
 
 extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K,
@@ -297,20 +330,22 @@ extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x
     p.M = M; p.N = N; p.K = K;
     p.nslab_n = pl.nslab_n; p.nslab_k = pl.nslab_k; p.msplit = pl.msplit;
     p.n_chunks = (M + kWgChunk - 1) / kWgChunk;
+    p.pow2 = pl.pow2;
     const bool mask = y != nullptr;
     int rc = 0;
     switch (pl.cfg) {
-        case 0: rc = wgrad_launch<4, 2, 2, 4>(p, pl, mask, s); break;
-        case 1: rc = wgrad_launch<4, 1, 1, 8>(p, pl, mask, s); break;
-        case 2: rc = wgrad_launch<2, 2, 4, 2>(p, pl, mask, s); break;
-        case 3: rc = wgrad_launch<1, 1, 1, 4>(p, pl, mask, s); break;
-        default: rc = wgrad_launch<1, 1, 4, 1>(p, pl, mask, s); break;
+        case 0: rc = wgrad_launch<4, 2, 2, 4, 32>(p, pl, mask, s); break;
+        case 1: rc = wgrad_launch<4, 1, 1, 8, 32>(p, pl, mask, s); break;
+        case 2: rc = wgrad_launch<2, 2, 4, 2, 32>(p, pl, mask, s); break;
+        case 3: rc = wgrad_launch<1, 1, 1, 4, 64>(p, pl, mask, s); break;
+        default: rc = wgrad_launch<1, 1, 4, 1, 64>(p, pl, mask, s); break;
     }
     if (rc) return rc;
     if (pl.msplit > 1) {
         const size_t nk4 = (size_t)N * K / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<const float *>(workspace), pl.msplit, nk4, dW);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + kRedElems - 1) / kRedElems)), dim3(256),
+                           (size_t)pl.pow2 * kRedElems * sizeof(wg_f32x4), s, reinterpret_cast<const float *>(workspace),
+                           pl.msplit, pl.pow2, nk4, dW);
         RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
     }
     return RQHIP_OK;

@@ -60,7 +60,10 @@ class _LinearPlain(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad
         gw = None
         if need_w:
-            gw = ops.linear_wgrad(gy, None, x)[0] if _hip_wgrad_ok(gy, w) else gy.t().mm(x)
+            # without a mask to fuse the hand-written kernel only wins on the small layers; the 768 x 512 one stays
+            # with the library (measured 626 vs 600 us at 100 000 rows)
+            small = w.shape[0] * w.shape[1] <= 256 * 256
+            gw = ops.linear_wgrad(gy, None, x)[0] if (small and _hip_wgrad_ok(gy, w)) else gy.t().mm(x)
         gx = gy.mm(w) if need_x else None
         return gx, gw
 

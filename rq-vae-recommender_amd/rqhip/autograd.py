@@ -76,15 +76,30 @@ class GumbelLevelFunction(torch.autograd.Function):
 
 
 class ReconLossFunction(torch.autograd.Function):
-    """Row-wise squared error (reference modules/loss.py:5-10) as one HIP pass forward and one backward."""
+    """Row-wise squared error (reference modules/loss.py:5-10) as one HIP pass forward and one backward.
+
+    When only x_hat needs a gradient (the training step), the forward pass also writes the gradient it expects to be
+    asked for -- 2 (x_hat - x) / B, what `.mean().backward()` of rqvae.py:152-154 sends -- and the backward pass merely
+    verifies the upstream rows on the device, redoing the ones that differ: same results, one pass over the [B, 768]
+    tensors instead of two."""
 
     @staticmethod
     def forward(ctx, x_hat: Tensor, x: Tensor):
+        B = x.shape[0]
+        ctx.spec = B > 0 and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and ops.recon_spec_ok(x_hat, x)
+        if ctx.spec:
+            ctx.row_scale = float(torch.tensor(1.0, dtype=torch.float32) / B)   # fp32 1/B, as autograd's mean computes it
+            out, g_spec = ops.recon_loss_forward_spec(x_hat, x, ctx.row_scale)
+            ctx.save_for_backward(x_hat, x, g_spec)
+            return out
         ctx.save_for_backward(x_hat, x)
         return ops.recon_loss_forward(x_hat, x)
 
     @staticmethod
     def backward(ctx, g_out):
+        if ctx.spec:
+            x_hat, x, g_spec = ctx.saved_tensors
+            return ops.recon_loss_backward_spec(x_hat, x, _dense(g_out), ctx.row_scale, g_spec), None
         x_hat, x = ctx.saved_tensors
         need_hat, need_x = ctx.needs_input_grad
         if not (need_hat or need_x):

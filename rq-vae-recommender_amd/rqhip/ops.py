@@ -332,6 +332,40 @@ def recon_loss_backward(x_hat: Tensor, x: Tensor, g_out: Tensor, need_hat: bool 
     return g_hat, g_x
 
 
+def recon_spec_ok(x_hat: Tensor, x: Tensor) -> bool:
+    """Can the speculative reconstruction-loss pair take these tensors (float4 layout)?"""
+    return (x_hat.dim() == 2 and x_hat.shape == x.shape and x_hat.shape[1] % 4 == 0 and x_hat.stride(1) == 1
+            and x.stride(1) == 1 and x_hat.stride(0) % 4 == 0 and x.stride(0) % 4 == 0
+            and x_hat.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and x_hat.dtype == torch.float32
+            and x.dtype == torch.float32)
+
+
+def recon_loss_forward_spec(x_hat: Tensor, x: Tensor, row_scale: float):
+    """out[b] = sum_d (x_hat - x)^2 and the expected gradient g_spec = 2 (x_hat - x) * row_scale in one pass
+    (rqhip_recon_loss_forward_spec).  Returns (out [B], g_spec [B,N])."""
+    _need_gpu(x_hat, x)
+    B, N = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((B,), dtype=torch.float32, device=x.device)
+        g_spec = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().rqhip_recon_loss_forward_spec(_ptr(x_hat), x_hat.stride(0), _ptr(x), x.stride(0), B, N,
+                                                      row_scale, _ptr(out), _ptr(g_spec), _stream())
+        check(rc, "rqhip_recon_loss_forward_spec")
+    return out, g_spec
+
+
+def recon_loss_backward_spec(x_hat: Tensor, x: Tensor, g_out: Tensor, row_scale: float, g_spec: Tensor) -> Tensor:
+    """Fix up g_spec in place for rows whose upstream gradient differs from row_scale; returns g_spec."""
+    _need_gpu(x_hat, x, g_out, g_spec)
+    g_out = _f32c(g_out, "g_out")
+    B, N = x.shape
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rqhip_recon_loss_backward_spec(_ptr(x_hat), x_hat.stride(0), _ptr(x), x.stride(0), _ptr(g_out),
+                                                       B, N, row_scale, _ptr(g_spec), _stream())
+        check(rc, "rqhip_recon_loss_backward_spec")
+    return g_spec
+
+
 def linear_wgrad_supported(n_out: int, n_in: int) -> bool:
     return bool(_lib.lib().rqhip_linear_wgrad_supported(int(n_out), int(n_in)))
 

@@ -353,6 +353,31 @@ def test_recon_loss_strided_views_and_autograd():
     assert torch.allclose(ReconstructionLoss()(xh.detach(), x), ((xh.detach() - x) ** 2).sum(-1), rtol=1e-5)
 
 
+def test_recon_loss_speculative_gradient_equals_plain_pair():
+    """ReconLossFunction's training form (csrc/recon_loss.hip *_spec): the forward pre-writes 2 (x_hat - x) / B and the
+    backward only redoes rows whose upstream gradient is not 1/B.  Bitwise the same as the plain forward + backward,
+    whether the expectation holds (mean().backward()), fails for every row (sum().backward()) or for a few rows."""
+    from rqhip import ops
+    from rqhip.autograd import ReconLossFunction
+    torch.manual_seed(5)
+    B, N = 3000, 768
+    x = torch.randn(B, N, device="cuda")
+    base = torch.randn(B, N, device="cuda")
+    w = torch.rand(B, device="cuda")
+    w[::7] = 1.0 / B
+    for reduce in (lambda t: t.mean(), lambda t: t.sum(), lambda t: (t * w).sum()):
+        xh = base.clone().requires_grad_(True)
+        out = ReconLossFunction.apply(xh, x)
+        assert torch.equal(out, ops.recon_loss_forward(base, x))
+        g_rows = torch.autograd.grad(reduce(out), out, retain_graph=True)[0]
+        reduce(out).backward()
+        want, _ = ops.recon_loss_backward(base, x, g_rows.contiguous(), True, False)
+        assert torch.equal(xh.grad, want)
+    # inference (no gradient requested) takes the plain kernel
+    with torch.no_grad():
+        assert torch.equal(ReconLossFunction.apply(base, x), ops.recon_loss_forward(base, x))
+
+
 # ---------------------------------------------------------------- property tests ----------------------
 
 def test_forward_property_random_shapes_and_special_values():

@@ -17,18 +17,11 @@ pytestmark = pytest.mark.gpu
 LAYERS = [(512, 768), (256, 512), (128, 256), (32, 128), (128, 32), (256, 128), (512, 256), (768, 512)]
 
 
-def _cus():
+def _msplit(M, N, K):
     from rqhip import _lib
     n = C.c_int(0)
-    assert _lib.lib().rqhip_device_cu_count(C.byref(n)) == 0
+    assert _lib.lib().rqhip_linear_wgrad_plan(M, N, K, C.byref(n)) >= 0
     return n.value
-
-
-def _msplit(M, N, K):
-    tiles = [(256, 256), (128, 256), (256, 128), (32, 128), (128, 32)]
-    nt, kt = next((a, b) for a, b in tiles if N % a == 0 and K % b == 0)
-    slabs = (N // nt) * (K // kt)
-    return max(1, min((M + 31) // 32, _cus() // slabs))
 
 
 def _inputs(M, N, K, seed):
