@@ -92,12 +92,16 @@ int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks
  *   upstream gradients (each may be NULL = zeros):
  *     g_embs [L,B,D] wrt embs, g_embsum [B,D] wrt emb_sum, g_resid [L,B,D] wrt residuals,
  *     g_loss [B] wrt loss
- *   outputs: g_res0 [B,D] (may be NULL; exact per-row arithmetic), g_codebooks [L,K,D] (may be NULL;
- *     OVERWRITTEN; rows are summed in LDS with float atomics, so the summation ORDER is not fixed and the
- *     result is reproducible to fp32 rounding only)
+ *   outputs: g_res0 [B,D] (may be NULL; exact per-row arithmetic), g_codebooks [L,K,D] (may be NULL; OVERWRITTEN).
+ *     For D <= 32, L <= 4 (rqhip_rq_backward_plan returns 1) the rows of a code are summed in a FIXED order -- no
+ *     atomics; bit-reproducible and restated by the oracle.  Other shapes scatter with LDS float atomics: the sum
+ *     order is then not fixed and g_codebooks is reproducible to fp32 rounding only.
  *   workspace: rqhip_rq_backward_workspace_bytes(B,D,L,K) bytes
  */
 size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K);
+/* 1 when the fixed-order fused kernel is used; then *n_wg / *waves_per_wg give its launch geometry (the summation
+ * order is a function of them: oracle/rq_oracle.c:rqo_rq_backward_ordered) */
+int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int *n_wg, int *waves_per_wg);
 int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                       int mode, float beta, const int64_t *ids, const float *g_embs,
                       const float *g_embsum, const float *g_resid, const float *g_loss,

@@ -233,10 +233,70 @@ int rqo_rq_forward_ex(const float *res0, int64_t B, int D, const float *codebook
  *   STE  : G_l = g_resid_l + G_{l+1} + A_l + 2b(res-emb)gl ;      dE[id] += 2(emb-res)gl
  *   ROT  : G_l = g_resid_l + G_{l+1} + s(A_l - 2(A_l.w)w + 2(A_l.q)u) + 2b(res-emb)gl ; dE as STE
  */
+static int rq_backward_core(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                            int mode, float beta, const int64_t *ids, const float *g_embs,
+                            const float *g_embsum, const float *g_resid, const float *g_loss,
+                            float *g_res0, float *g_codebooks, float *Vrows);
+
 int rqo_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                     int mode, float beta, const int64_t *ids, const float *g_embs,
                     const float *g_embsum, const float *g_resid, const float *g_loss,
                     float *g_res0, float *g_codebooks) {
+    return rq_backward_core(res0, B, D, codebooks, L, K, mode, beta, ids, g_embs, g_embsum, g_resid, g_loss, g_res0,
+                            g_codebooks, 0);
+}
+
+/* Same gradients, but the codebook gradient is accumulated in the FIXED order of csrc/rq_backward.hip's fused
+ * kernel, so that the GPU result can be compared bit for bit (the kernel has no atomics: inside a workgroup every
+ * code is owned by one wave, which adds the rows in order):
+ *   workgroup b of n_wg, wave j of nw, round it  ->  32-row tile  (it * nw + j) * n_wg + b;
+ *   partial_b[l][id] += V_l(row)   for it ascending, j ascending, rows of the tile ascending   (fp32 adds from 0);
+ *   g_codebooks = (s0 + s1) + (s2 + s3),  s_q = 0 + partial_q + partial_{q+4} + ...   (rq_cbgrad_reduce_kernel). */
+int rqo_rq_backward_ordered(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                            int mode, float beta, const int64_t *ids, const float *g_embs,
+                            const float *g_embsum, const float *g_resid, const float *g_loss,
+                            float *g_res0, float *g_codebooks, int n_wg, int nw) {
+    if (n_wg <= 0 || nw <= 0 || !g_codebooks) return RQO_EARG;
+    const size_t LKD = (size_t)L * K * D;
+    float *V = (float *)malloc(sizeof(float) * (size_t)L * (size_t)(B > 0 ? B : 1) * D);
+    float *part = (float *)calloc((size_t)n_wg * LKD, sizeof(float));
+    if (!V || !part) { free(V); free(part); return RQO_ENOMEM; }
+    int rc = rq_backward_core(res0, B, D, codebooks, L, K, mode, beta, ids, g_embs, g_embsum, g_resid, g_loss, g_res0,
+                              0, V);
+    if (rc) { free(V); free(part); return rc; }
+    const int64_t n_tiles = (B + 31) / 32, waves = (int64_t)n_wg * nw;
+    for (int b = 0; b < n_wg; ++b) {
+        float *pb = part + (size_t)b * LKD;
+        for (int64_t it = 0; it * waves < n_tiles; ++it)
+            for (int j = 0; j < nw; ++j) {
+                int64_t tile = it * waves + (int64_t)j * n_wg + b;
+                if (tile >= n_tiles) continue;
+                for (int64_t i = tile * 32; i < tile * 32 + 32 && i < B; ++i)
+                    for (int l = 0; l < L; ++l) {
+                        float *dE = pb + ((size_t)l * K + ids[(size_t)l * B + i]) * D;
+                        const float *v = V + ((size_t)l * B + i) * D;
+                        for (int d = 0; d < D; ++d) dE[d] = dE[d] + v[d];
+                    }
+            }
+    }
+    for (size_t e = 0; e < LKD; ++e) {
+        float sg[4];
+        for (int q = 0; q < 4; ++q) {
+            float a = 0.0f;
+            for (int g = q; g < n_wg; g += 4) a = a + part[(size_t)g * LKD + e];
+            sg[q] = a;
+        }
+        g_codebooks[e] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    }
+    free(V); free(part);
+    return RQO_OK;
+}
+
+/* Vrows [L,B,D] (optional): receives, per row and level, the vector the embedding backward adds to dE[id]. */
+static int rq_backward_core(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                            int mode, float beta, const int64_t *ids, const float *g_embs,
+                            const float *g_embsum, const float *g_resid, const float *g_loss,
+                            float *g_res0, float *g_codebooks, float *Vrows) {
     if (B < 0 || D <= 0 || L <= 0 || K <= 0 || !res0 || !codebooks || !ids) return RQO_EARG;
     if (mode != RQO_MODE_EVAL && mode != RQO_MODE_STE && mode != RQO_MODE_ROTATION) return RQO_EARG;
     size_t LD = (size_t)L * D;
@@ -285,6 +345,7 @@ int rqo_rq_backward(const float *res0, int64_t B, int D, const float *codebooks,
                     float commit = (2.0f * beta) * (r[d] - emb[d]) * gl;
                     float gnew = ((gr + G[d]) + lin) + commit;
                     if (dE) dE[d] = dE[d] + (2.0f * (emb[d] - r[d])) * gl;
+                    if (Vrows) Vrows[((size_t)l * B + i) * D + d] = (2.0f * (emb[d] - r[d])) * gl;
                     Gn[d] = gnew;
                 }
                 memcpy(G, Gn, sizeof(float) * D);
@@ -297,9 +358,11 @@ int rqo_rq_backward(const float *res0, int64_t B, int D, const float *codebooks,
                     if (mode == RQO_MODE_EVAL) {
                         gnew = (gr + G[d]) + commit;
                         if (dE) dE[d] = dE[d] + (A[d] + embg);
+                        if (Vrows) Vrows[((size_t)l * B + i) * D + d] = A[d] + embg;
                     } else {
                         gnew = ((gr + G[d]) + A[d]) + commit;
                         if (dE) dE[d] = dE[d] + embg;
+                        if (Vrows) Vrows[((size_t)l * B + i) * D + d] = embg;
                     }
                     G[d] = gnew;
                 }

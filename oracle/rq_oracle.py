@@ -79,8 +79,10 @@ def rq_forward(res0, codebooks, mode: int, beta: float = 0.25, want_margin: bool
 
 
 def rq_backward(res0, codebooks, mode: int, beta: float, ids, g_embs=None, g_embsum=None,
-                g_resid=None, g_loss=None):
-    """Closed-form backward of rq_forward.  Returns (g_res0 [B,D], g_codebooks [L,K,D])."""
+                g_resid=None, g_loss=None, order=None):
+    """Closed-form backward of rq_forward.  Returns (g_res0 [B,D], g_codebooks [L,K,D]).
+    order=None: codebook gradients summed over rows in ascending order; order=(n_wg, nw): in the fixed order of the
+    fused HIP kernel launched with n_wg workgroups of nw waves (rqhip_rq_backward_plan), for bit-exact comparison."""
     res0, codebooks = _f(res0), _f(codebooks)
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     B, D = res0.shape
@@ -91,9 +93,12 @@ def rq_backward(res0, codebooks, mode: int, beta: float, ids, g_embs=None, g_emb
     gl = None if g_loss is None else _f(g_loss)
     g_res0 = np.empty((B, D), np.float32)
     g_cb = np.empty((L, K, D), np.float32)
-    rc = lib().rqo_rq_backward(_p(res0), C.c_int64(B), C.c_int(D), _p(codebooks), C.c_int(L), C.c_int(K),
-                               C.c_int(mode), C.c_float(beta), _p(ids), _p(ge), _p(gs), _p(gr), _p(gl),
-                               _p(g_res0), _p(g_cb))
+    args = (_p(res0), C.c_int64(B), C.c_int(D), _p(codebooks), C.c_int(L), C.c_int(K), C.c_int(mode), C.c_float(beta),
+            _p(ids), _p(ge), _p(gs), _p(gr), _p(gl), _p(g_res0), _p(g_cb))
+    if order is None:
+        rc = lib().rqo_rq_backward(*args)
+    else:
+        rc = lib().rqo_rq_backward_ordered(*args, C.c_int(int(order[0])), C.c_int(int(order[1])))
     _chk(rc, "rq_backward")
     return g_res0, g_cb
 

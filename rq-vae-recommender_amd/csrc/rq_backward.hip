@@ -147,34 +147,62 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
 // registers (L * KSTEPS values per lane) and each row's codeword-gradient vectors go straight into the
 // workgroup's LDS tables: no [L,B,D] round trip through HBM.  Per row: reads res0, ids, upstream gradients
 // (12D + 8L bytes), writes g_res0 (4D) -- the algorithmic traffic of SURVEY.md 8d.
-#ifndef RQ_BWD_ATOMICS
-#define RQ_BWD_ATOMICS 1  // developer switch (tools/): 0 removes the LDS scatter to time the rest
-#endif
 constexpr int kFusedMaxL = 4;
 constexpr int kFusedThreads = 512;
+constexpr int kFusedWaves = kFusedThreads / 64;
+
+// Embedding backward inside the fused kernel WITHOUT atomics ("owner computes"): the workgroup keeps one
+// [levels, K, D] table in LDS; after a level's per-row vectors V are known, the waves park them (and the rows' ids) in
+// an LDS stage, and every code is then accumulated by exactly ONE wave -- wave (id mod 8) -- which walks the staged
+// rows in order (ballot of "mine", lowest set bit first) and adds V to its table row with plain LDS read / add / write.
+// One owner per address and in-order LDS execution make the sum order fixed: round, wave, row ascending -- restated by
+// oracle/rq_oracle.c:rqo_rq_backward_ordered, so the codebook gradient is bit-reproducible.  (The first version let
+// all waves ds_add_f32 into the table: 9.6 M LDS float atomics = 45 of the kernel's 76 us, and an unordered sum.)
+// `sg` waves are staged at a time (8, or 4 when a K = 1024 table leaves less LDS).
+__device__ __forceinline__ void cb_accumulate(float *__restrict__ tab_l, const float *__restrict__ stage,
+                                              const int *__restrict__ ids_s, int rows, int D, int wave, int lane) {
+    for (int base = 0; base < rows; base += 64) {
+        const int myid = (base + lane < rows) ? ids_s[base + lane] : -1;
+        const bool mine = myid >= 0 && (myid & (kFusedWaves - 1)) == wave;
+        unsigned long long m = __ballot(mine);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int id = __builtin_amdgcn_readlane(myid, j);
+            if (lane < D) {
+                float *t = tab_l + (size_t)id * D + lane;
+                *t = *t + stage[(size_t)(base + j) * (D + 1) + lane];
+            }
+        }
+    }
+}
 
 // VEC: D == 2*KSTEPS and every row pointer 16-byte aligned -> rows and codewords move as float4 half-rows +
 // v_permlane32_swap (rq_rowmath.h) instead of 4 bytes per lane and instruction.
 template <int KSTEPS, int MODE, bool VEC>
 __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const RqBwdParams p, float *__restrict__ partial,
-                                                                         int LKD_total) {
+                                                                         int LKD_total, int sg) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int D = p.D, L = p.L, K = p.K;
-    const int stride = D + 1;
-    const int tbl = (p.l_end - p.l_begin) * K * stride;
+    const int tbl = (p.l_end - p.l_begin) * K * D;           // [levels of this launch][K][D]
+    float *stage = acc + tbl;                               // [sg * 32][D + 1]
+    int *ids_s = reinterpret_cast<int *>(stage + sg * 32 * (D + 1));  // [sg * 32]
     if (p.g_cb)
         for (int e = threadIdx.x; e < tbl; e += kFusedThreads) acc[e] = 0.0f;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int il = lane & 31, h = lane >> 5;
-    constexpr int kWaves = kFusedThreads / 64;
+    constexpr int kWaves = kFusedWaves;
     const long long waves = (long long)gridDim.x * kWaves;
-    const long long gw = (long long)(threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    const long long gw = (long long)wave * gridDim.x + blockIdx.x;
+    // every wave of the workgroup runs the same number of rounds (the accumulation below has barriers)
+    const long long n_rounds = (p.n_tiles + waves - 1) / waves;
 
-    for (long long tile = gw; tile < p.n_tiles; tile += waves) {
+    for (long long it = 0; it < n_rounds; ++it) {
+        const long long tile = it * waves + gw;
         const long long row = tile * 32 + il;
-        const bool ok = row < p.B;
+        const bool ok = tile < p.n_tiles && row < p.B;
         const long long rc = ok ? row : p.B - 1;
 
         float rl[kFusedMaxL][KSTEPS];
@@ -228,8 +256,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                     if (p.g_embsum) a = a + gs[kk];
                     A[kk] = a - G[kk];
                 }
-                const bool mine = p.g_cb && ok && l >= p.l_begin && l < p.l_end;  // this launch owns level l's table
-                float *tab = acc + (size_t)((l - p.l_begin) * K + idl[l]) * stride + h;
+                float cbv[KSTEPS];  // this row's contribution to dE_l[id] (features of this lane's parity)
                 if (MODE == RQHIP_MODE_ROTATION) {
                     float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
                     const float xsq = pair_sumsq<KSTEPS>(r);
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                         const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
                         const float embg = (2.0f * (e[kk] - r[kk])) * gl;
                         G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
-                        if (RQ_BWD_ATOMICS && mine && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                        cbv[kk] = embg;
                     }
                 } else {
 #pragma unroll
@@ -251,11 +278,26 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
                         if (MODE == RQHIP_MODE_EVAL) {
                             const float contrib = A[kk] + embg;
                             G[kk] = (gr[kk] + G[kk]) + commit;
-                            if (RQ_BWD_ATOMICS && mine && 2 * kk + h < D) atomicAdd(tab + 2 * kk, contrib);
+                            cbv[kk] = contrib;
                         } else {
                             G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
-                            if (RQ_BWD_ATOMICS && mine && 2 * kk + h < D) atomicAdd(tab + 2 * kk, embg);
+                            cbv[kk] = embg;
                         }
+                    }
+                }
+                if (p.g_cb && l >= p.l_begin && l < p.l_end) {  // uniform: this launch owns level l's table
+                    float *tab_l = acc + (size_t)(l - p.l_begin) * K * D;
+                    for (int g0 = 0; g0 < kWaves; g0 += sg) {
+                        if (wave >= g0 && wave < g0 + sg) {
+                            float *st = stage + (size_t)((wave - g0) * 32 + il) * (D + 1) + h;
+#pragma unroll
+                            for (int kk = 0; kk < KSTEPS; ++kk)
+                                if (2 * kk + h < D) st[2 * kk] = cbv[kk];
+                            if (h == 0) ids_s[(wave - g0) * 32 + il] = ok ? idl[l] : -1;
+                        }
+                        __syncthreads();
+                        cb_accumulate(tab_l, stage, ids_s, sg * 32, D, wave, lane);
+                        __syncthreads();
                     }
                 }
             }
@@ -277,8 +319,7 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
         __syncthreads();
         float *out = partial + (size_t)blockIdx.x * LKD_total;
         for (int e2 = threadIdx.x; e2 < (p.l_end - p.l_begin) * K * D; e2 += kFusedThreads) {
-            const int kd = e2 / D, dd = e2 - kd * D;
-            out[e2] = acc[(size_t)kd * stride + dd];
+            out[e2] = acc[e2];
         }
     }
 }
@@ -343,13 +384,23 @@ static int fused_wgs(long long B) {
     return (int)g;
 }
 
+// fused kernel LDS: [levels of the launch][K][D] table + a stage of sg waves x 32 rows x (D+1) floats + their ids
+constexpr size_t kFusedLdsBudget = 160 * 1024;
+static size_t fused_stage_bytes(int D, int sg) { return (size_t)sg * 32 * (D + 1) * sizeof(float) + (size_t)sg * 32 * sizeof(int); }
 // register budget: L * KSTEPS residual values per lane -> D <= 32 (KSTEPS <= 16) only
 static bool fused_fits(int D, int K, int L) {
-    return D <= 32 && L <= kFusedMaxL && (size_t)K * (D + 1) * sizeof(float) <= kScatterLdsBudget;
+    return D <= 32 && L <= kFusedMaxL && (size_t)K * D * sizeof(float) + fused_stage_bytes(D, 1) <= kFusedLdsBudget;
+}
+// waves staged at a time: as many as fit next to ONE level's table (8, 4, 2 or 1)
+static int fused_stage_waves(int D, int K) {
+    int sg = kFusedWaves;
+    while (sg > 1 && (size_t)K * D * sizeof(float) + fused_stage_bytes(D, sg) > kFusedLdsBudget) sg >>= 1;
+    return sg;
 }
 // levels whose LDS tables fit together: the fused kernel runs once per such group
 static int fused_levels_per_pass(int D, int K, int L) {
-    int n = (int)(kScatterLdsBudget / ((size_t)K * (D + 1) * sizeof(float)));
+    const size_t left = kFusedLdsBudget - fused_stage_bytes(D, fused_stage_waves(D, K));
+    int n = (int)(left / ((size_t)K * D * sizeof(float)));
     return n < 1 ? 1 : (n > L ? L : n);
 }
 
@@ -386,12 +437,21 @@ static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
 
 using namespace rqhip;
 
+// which path rqhip_rq_backward takes: returns 1 and the fused kernel's geometry (workgroups, waves per workgroup) when
+// the codebook gradient is accumulated in the fixed order restated by the oracle, 0 for the three-kernel path
+extern "C" int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int *n_wg, int *waves_per_wg) {
+    const bool fused = B > 0 && D >= 1 && K >= 1 && L >= 1 && fused_fits(D, K, L);
+    if (n_wg) *n_wg = fused ? fused_wgs(B) : 0;
+    if (waves_per_wg) *waves_per_wg = fused ? kFusedWaves : 0;
+    return fused ? 1 : 0;
+}
+
 // layout: [L,B,D] row scratch | [G, L*K*D] per-workgroup partial tables (LDS scatter path only)
 extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K) {
     if (B <= 0 || D <= 0 || L <= 0 || K <= 0) return 16;
     const size_t rows = (size_t)L * (size_t)B * (size_t)D * sizeof(float);
     const size_t g = fused_fits(D, K, L) ? (size_t)fused_wgs(B) : (size_t)scatter_wgs(B);
-    const size_t partial = scatter_fits_lds(D, K) ? g * (size_t)L * K * D * sizeof(float) : 0;
+    const size_t partial = (fused_fits(D, K, L) || scatter_fits_lds(D, K)) ? g * (size_t)L * K * D * sizeof(float) : 0;
     return rows + partial;
 }
 
@@ -442,16 +502,19 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
             p.write_rows = (l0 == 0);
             const int nl = p.l_end - p.l_begin;
             const int LKD = nl * K * D;
-            const size_t lds = g_codebooks ? (size_t)nl * K * (D + 1) * sizeof(float) : 0;
+            const int sg = fused_stage_waves(D, K);
+            const size_t lds = g_codebooks ? (size_t)nl * K * D * sizeof(float) + fused_stage_bytes(D, sg) : 0;
             auto go = [&](auto kern) -> int {
-                static bool attr = false;
-                if (!attr) {
+                static bool attr[16] = {};   // per device (the attribute belongs to the device's copy of the function)
+                int dev = 0;
+                RQ_RETURN_IF_HIP(hipGetDevice(&dev));
+                if (dev >= 16 || !attr[dev]) {
                     RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         (int)kScatterLdsBudget));
-                    attr = true;
+                                                         (int)kFusedLdsBudget));
+                    if (dev < 16) attr[dev] = true;
                 }
-                hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD);
+                hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD, sg);
                 RQ_CHECK_LAUNCH("rq_backward_fused_kernel");
                 return 0;
             };

@@ -28,6 +28,7 @@ SIGNATURES = {
     "rqhip_rq_forward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),
     "rqhip_rq_backward_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
+    "rqhip_rq_backward_plan": (_int, [_i64, _int, _int, _int, C.POINTER(_int), C.POINTER(_int)]),
     "rqhip_rq_backward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
     "rqhip_gumbel_forward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),

@@ -163,6 +163,28 @@ def test_forward_full_size_properties(B, D, K, L, mode):
 
 # ---------------------------------------------------------------- backward ---------------------------
 
+def _bwd_order(B, D, L, K):
+    """(n_wg, waves) of the fixed-order fused backward kernel, or None when the shape takes the atomic scatter path."""
+    import ctypes as C
+    from rqhip import _lib
+    n_wg, nw = C.c_int(0), C.c_int(0)
+    fused = _lib.lib().rqhip_rq_backward_plan(B, D, L, K, C.byref(n_wg), C.byref(nw))
+    return (n_wg.value, nw.value) if fused else None
+
+
+def _assert_cb_grad(g_cb, x, cbs, mode, ids, g, r_cb, what=""):
+    """Codebook gradient: bit-exact against the oracle's restatement of the kernel's summation order where the
+    fixed-order kernel runs (D <= 32, L <= 4); fp32-rounding tolerance on the atomic scatter path."""
+    B, D = x.shape
+    L, K, _ = cbs.shape
+    order = _bwd_order(B, D, L, K)
+    if order is not None:
+        _, o_cb = o.rq_backward(x, cbs, mode, 0.25, ids, order=order, **g)
+        _assert_bitexact(g_cb, o_cb, "g_codebooks (fixed order) " + what)
+    scale = max(1e-6, float(np.abs(r_cb).max()))
+    np.testing.assert_allclose(g_cb, r_cb, rtol=1e-4, atol=3e-6 * scale)
+
+
 def _run_backward(x, cbs, mode, beta, ids, **g):
     from rqhip import ops
     gg = {k: (None if v is None else _gpu(v)) for k, v in g.items()}
@@ -173,7 +195,9 @@ def _run_backward(x, cbs, mode, beta, ids, **g):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,D,K,L", [(1, 32, 256, 3), (333, 32, 256, 3), (64, 64, 256, 3), (100, 16, 32, 1),
-                                     (77, 24, 100, 4), (40, 128, 64, 2), (2000, 32, 1024, 4), (500, 32, 512, 3)])
+                                     (77, 24, 100, 4), (40, 128, 64, 2), (2000, 32, 1024, 4), (500, 32, 512, 3),
+                                     # the bench shapes at full size: config 2, and a config-4 slice
+                                     (100_000, 32, 256, 3), (60_000, 32, 1024, 4)])
 @pytest.mark.parametrize("which", ["all", "train_like"])
 def test_backward_vs_oracle(mode, B, D, K, L, which):
     rng = np.random.default_rng(B + D + K + L + mode)
@@ -191,9 +215,10 @@ def test_backward_vs_oracle(mode, B, D, K, L, which):
     r_res0, r_cb = o.rq_backward(x, cbs, mode, 0.25, ref["ids"], **g)
     g_res0, g_cb = _run_backward(x, cbs, mode, 0.25, ref["ids"], **g)
     _assert_bitexact(g_res0, r_res0, "g_res0")          # per-row arithmetic: exact
-    # codeword gradients are accumulated across rows with float atomics: order differs, value does not
-    scale = max(1e-6, float(np.abs(r_cb).max()))
-    np.testing.assert_allclose(g_cb, r_cb, rtol=1e-4, atol=2e-6 * scale)
+    _assert_cb_grad(g_cb, x, cbs, mode, ref["ids"], g, r_cb)
+    g_res0_b, g_cb_b = _run_backward(x, cbs, mode, 0.25, ref["ids"], **g)
+    if _bwd_order(B, D, L, K) is not None:
+        _assert_bitexact(g_cb_b, g_cb, "g_codebooks run-to-run")
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "quantize_*.npz"))))
@@ -436,7 +461,6 @@ def test_backward_property_random_shapes():
         r_res0, r_cb = o.rq_backward(x, cbs, mode, 0.25, ref["ids"], **g)
         g_res0, g_cb = _run_backward(x, cbs, mode, 0.25, ref["ids"], **g)
         _assert_bitexact(g_res0, r_res0, f"g_res0 B={B} D={D} K={K} L={L} mode={mode}")
-        scale = max(1e-6, float(np.abs(r_cb).max()))
-        np.testing.assert_allclose(g_cb, r_cb, rtol=1e-4, atol=3e-6 * scale)
+        _assert_cb_grad(g_cb, x, cbs, mode, ref["ids"], g, r_cb, f"B={B} D={D} K={K} L={L} mode={mode}")
 
     run()
