@@ -128,7 +128,8 @@ int rqhip_gumbel_backward(const float *x, int64_t B, int D, const float *codeboo
 /* ------------------------------------------------------------------------------------------------
  * k-means codebook initialisation (init/kmeans.py).  The Lloyd loop, the np.random.choice seeding
  * and the torch.randint reseed of empty clusters stay on the host (they consume host RNG streams
- * the reference's results depend on); these are the two data-parallel steps of one iteration.
+ * the reference's results depend on); rqhip_kmeans_assign / _update are the two data-parallel steps of one
+ * iteration, rqhip_kmeans_lloyd runs batches of iterations between two host visits.
  *
  * rqhip_kmeans_assign : kmeans.py:40-43  assign[i] = argmin_k sum_d (x[i,d]-c[k,d])^2
  * rqhip_kmeans_update : kmeans.py:44-59  c[k] <- mean of its rows (ascending-row sum / count);
@@ -142,6 +143,28 @@ int rqhip_kmeans_assign(const float *x, int64_t B, int D, const float *centroids
 int rqhip_kmeans_update(const float *x, int64_t B, int D, const int64_t *assign, int K,
                         float *centroids, int64_t *counts, float *shift_sq_max,
                         rqhip_stream_t stream);
+/* rqhip_kmeans_lloyd : a BATCH of up to n_iters Lloyd iterations (kmeans.py:64-70) with no host round trip.
+ *   Enqueues n_iters x (assign, update, finalize); each launch first reads state[0] and returns at once when an
+ *   earlier iteration of the batch stopped the run.  state: 4 device ints, zero them before the first batch --
+ *     state[0] stop flag: 0 running, 1 converged (sqrt of the max squared shift < stop_threshold, kmeans.py:68-69),
+ *              2 an empty cluster appeared: its reseed draws from the host's torch RNG (kmeans.py:50-54), so the host
+ *              reseeds (counts[k] == 0 names the clusters; their centroids are untouched), clears state[0] and goes on;
+ *     state[1] iterations completed so far (the one that raised a flag included);
+ *     state[2] fp32 bits of max_k |c_new - c_old|^2 of the last completed iteration (empty clusters excluded).
+ *   centroids [K,D] updated in place, assign [B] / counts [K] hold the last completed iteration's values.
+ *   The host reads the 16-byte state once per batch. */
+int rqhip_kmeans_lloyd(const float *x, int64_t B, int D, float *centroids, int K, int64_t *assign,
+                       int64_t *counts, int *state, int n_iters, float stop_threshold, rqhip_stream_t stream);
+/* Row-sharded form of one iteration: every rank owns a block of rows,
+ *   rqhip_kmeans_partial_sums : assign + this rank's per-cluster sums and counts -> sums [K, D+1] fp32 (count last);
+ *   <caller all-reduces `sums` over the ranks: ONE collective of K (D+1) floats per iteration, RCCL on the stream>
+ *   rqhip_kmeans_apply_sums   : means, shift, empty / convergence flags from the reduced sums (identical on every rank).
+ * Same state words and early-exit rule as rqhip_kmeans_lloyd, so batches of iterations (collectives included) can be
+ * enqueued between two host visits. */
+int rqhip_kmeans_partial_sums(const float *x, int64_t B, int D, const float *centroids, int K, int64_t *assign,
+                              float *sums, int *state, rqhip_stream_t stream);
+int rqhip_kmeans_apply_sums(const float *sums, int K, int D, float *centroids, int64_t *counts, int *state,
+                            float stop_threshold, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Semantic-id statistics.

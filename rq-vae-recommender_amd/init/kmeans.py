@@ -8,15 +8,24 @@ steps of an iteration are HIP kernels (csrc/kmeans.hip):
     assign  (kmeans.py:40-43)  fused distance + argmin, no B x K x D temporary
     update  (kmeans.py:44-59)  per-cluster mean in row order + the convergence statistic of kmeans.py:68
 
-One 12-byte device->host read per iteration (empty-cluster flag + shift) replaces the reference's K-iteration
-Python loop of masked means.
+`Kmeans.run` drives them in BATCHES: `rqhip_kmeans_lloyd` enqueues up to 16 iterations whose kernels stop by
+themselves (device flag) when the run converges or an empty cluster needs the host's RNG; the host reads one
+16-byte state per batch.  The per-iteration host loop this replaces cost ~30x the kernels' time (1.05 s for the
+three levels of the bench warm-up; now ~0.05 s).
 """
 from typing import NamedTuple, Optional
 
 import numpy as np
 import torch
 
+import torch.distributed as dist
+
 from rqhip import ops
+
+# When True, kmeans_init_ treats `x` as THIS RANK'S BLOCK of the rows and runs the row-sharded Lloyd loop (one
+# all-reduce of [K, D+1] sums || counts per iteration, SURVEY.md section 8e).  train_rqvae sets it around the
+# warm-up forward when it feeds every rank its own slice of the first 20 000 items.
+SHARDED_INIT = False
 
 
 def kmeans_init_(tensor: torch.Tensor, x: torch.Tensor) -> None:
@@ -24,7 +33,8 @@ def kmeans_init_(tensor: torch.Tensor, x: torch.Tensor) -> None:
     assert tensor.dim() == 2
     assert x.dim() == 2
     with torch.no_grad():
-        out = Kmeans(k=tensor.shape[0]).run(x)
+        sharded = SHARDED_INIT and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        out = Kmeans(k=tensor.shape[0]).run(x, sharded=sharded)
         tensor.data.copy_(out.centroids)
 
 
@@ -65,12 +75,110 @@ class Kmeans:
         self.assignment = assign
         return shift
 
-    def run(self, x: torch.Tensor) -> KmeansOutput:
+    BATCH = 16  # Lloyd iterations enqueued per host visit
+
+    def run(self, x: torch.Tensor, sharded: bool = False) -> KmeansOutput:
+        if sharded:
+            return self._run_sharded(x)
         x = x.detach().to(torch.float32).contiguous()
         self._init_centroids(x)
-        i = 0
+        B = x.shape[0]
+        dev = x.device
+        assign = torch.empty((B,), dtype=torch.int64, device=dev)
+        counts = torch.empty((self.k,), dtype=torch.int64, device=dev)
+        state = torch.zeros((4,), dtype=torch.int32, device=dev)   # see include/rqhip.h: rqhip_kmeans_lloyd
+        done = 0   # iterations executed (the reference's calls of _update_centroids)
+        i = 0      # the reference's loop counter: iterations that did not converge (kmeans.py:64-70)
         while self.iters is None or i < self.iters:
-            if self._update_centroids(x) < self.stop_threshold:
+            n = self.BATCH if self.iters is None else min(self.BATCH, self.iters - i)
+            ops.kmeans_lloyd(x, self.centroids, assign, counts, state, n, self.stop_threshold)
+            stop, now_done, shift_bits, _ = state.tolist()            # the one sync of this batch
+            ran, done = now_done - done, now_done
+            if stop == 1:        # converged: the reference breaks without counting the iteration
                 break
-            i += 1
+            if stop == 2:        # the last executed iteration met empty clusters: reseed them here, in ascending
+                i += ran - 1     # cluster order, with the host's torch RNG stream (kmeans.py:48-54)
+                shift = float(np.sqrt(np.array([shift_bits], dtype=np.int32).view(np.float32)[0]))
+                empty = (counts == 0).nonzero().flatten().tolist()
+                before = self.centroids[empty].clone()      # the device leaves empty clusters' centroids untouched
+                for cluster in empty:
+                    pick = int(torch.randint(0, B, (1,)))
+                    self.centroids[cluster] = x[pick]
+                moved = self.centroids[empty] - before
+                shift = max(shift, float(torch.linalg.vector_norm(moved, dim=1).max()))
+                if shift < self.stop_threshold:
+                    break
+                i += 1
+                state[0] = 0
+                continue
+            i += ran             # the whole batch ran without converging
+        self.assignment = assign
+        return KmeansOutput(centroids=self.centroids, assignment=self.assignment)
+
+    # ---- row-sharded run (one process per GPU, torch.distributed) ---------------------------------------------
+    def _rows_from_all_ranks(self, x: torch.Tensor, picks, lo: int) -> torch.Tensor:
+        """Global rows `picks` ([n] ints, identical on every rank) -> [n, D] on every rank: the owner of a row puts
+        it into a zero buffer, one all-reduce(sum) assembles the set (x + 0 is exact)."""
+        buf = torch.zeros((len(picks), x.shape[1]), dtype=torch.float32, device=x.device)
+        mine = [(j, p - lo) for j, p in enumerate(picks) if lo <= p < lo + x.shape[0]]
+        if mine:
+            j, r = zip(*mine)
+            buf[torch.as_tensor(j, device=x.device)] = x[torch.as_tensor(r, device=x.device)]
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return buf
+
+    def _run_sharded(self, x: torch.Tensor) -> KmeansOutput:
+        """`x` is this rank's block of rows (blocks in rank order form the global matrix).  Rank 0 owns both RNG
+        streams -- `np.random.choice` for the seed rows, `torch.randint` for reseeds (kmeans.py:35,53) -- and broadcasts
+        the drawn row numbers; per iteration the ranks exchange ONE all-reduce of the [K, D+1] sums || counts, after
+        which every rank computes the same centroids, shift and stop flags.  Sums are formed per rank and then across
+        ranks, so centroids equal a single-GPU run's to fp32 rounding, not bit for bit."""
+        x = x.detach().to(torch.float32).contiguous()
+        dev, rank, world = x.device, dist.get_rank(), dist.get_world_size()
+        sizes = torch.zeros((world,), dtype=torch.int64, device=dev)
+        sizes[rank] = x.shape[0]
+        dist.all_reduce(sizes)
+        sizes = sizes.tolist()
+        lo, B = sum(sizes[:rank]), sum(sizes)
+
+        def draw(fn):  # rank 0 draws, everyone gets the same list
+            box = [fn() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        if B == 0:
+            raise ValueError("Can not choose random element from x, x is empty")
+        seeds = draw(lambda: np.random.choice(B, self.k, replace=False).tolist())
+        self.centroids = self._rows_from_all_ranks(x, seeds, lo).contiguous()
+        assign = torch.empty((x.shape[0],), dtype=torch.int64, device=dev)
+        counts = torch.empty((self.k,), dtype=torch.int64, device=dev)
+        sums = torch.empty((self.k, x.shape[1] + 1), dtype=torch.float32, device=dev)
+        state = torch.zeros((4,), dtype=torch.int32, device=dev)
+        done = i = 0
+        while self.iters is None or i < self.iters:
+            n = self.BATCH if self.iters is None else min(self.BATCH, self.iters - i)
+            for _ in range(n):   # enqueued back to back: the collective runs on the stream too (RCCL)
+                ops.kmeans_partial_sums(x, self.centroids, assign, sums, state)
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+                ops.kmeans_apply_sums(sums, self.centroids, counts, state, self.stop_threshold)
+            stop, now_done, shift_bits, _ = state.tolist()
+            ran, done = now_done - done, now_done
+            if stop == 1:
+                break
+            if stop == 2:
+                i += ran - 1
+                shift = float(np.sqrt(np.array([shift_bits], dtype=np.int32).view(np.float32)[0]))
+                empty = (counts == 0).nonzero().flatten().tolist()
+                picks = draw(lambda: [int(torch.randint(0, B, (1,))) for _ in empty])
+                before = self.centroids[empty].clone()
+                self.centroids[empty] = self._rows_from_all_ranks(x, picks, lo)
+                moved = self.centroids[empty] - before
+                shift = max(shift, float(torch.linalg.vector_norm(moved, dim=1).max()))
+                if shift < self.stop_threshold:
+                    break
+                i += 1
+                state[0] = 0
+                continue
+            i += ran
+        self.assignment = assign
         return KmeansOutput(centroids=self.centroids, assignment=self.assignment)

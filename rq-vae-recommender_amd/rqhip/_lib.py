@@ -37,6 +37,9 @@ SIGNATURES = {
                                      _vp]),
     "rqhip_kmeans_assign": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp]),
     "rqhip_kmeans_update": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "rqhip_kmeans_lloyd": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _int, _f32, _vp]),
+    "rqhip_kmeans_partial_sums": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "rqhip_kmeans_apply_sums": (_int, [_vp, _int, _int, _vp, _vp, _vp, _f32, _vp]),
     "rqhip_dedup_workspace_bytes": (_sz, [_i64]),
     "rqhip_dedup_rank": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_prefix_index_bytes": (_sz, [_i64, _int]),

@@ -154,6 +154,46 @@ def kmeans_update(x: Tensor, assign: Tensor, centroids: Tensor):
     return counts, shift
 
 
+def kmeans_lloyd(x: Tensor, centroids: Tensor, assign: Tensor, counts: Tensor, state: Tensor, n_iters: int,
+                 stop_threshold: float) -> None:
+    """Enqueue a batch of up to n_iters Lloyd iterations (rqhip_kmeans_lloyd); nothing is synchronised.  centroids
+    [K,D] fp32 (updated in place), assign [B] int64, counts [K] int64, state [4] int32 -- all device tensors the
+    caller keeps across batches (see include/rqhip.h for the state words)."""
+    _need_gpu(x, centroids, assign, counts, state)
+    if x.dtype != torch.float32 or not x.is_contiguous() or centroids.dtype != torch.float32 or not centroids.is_contiguous():
+        raise RqHipError("kmeans_lloyd: x and centroids must be contiguous float32")
+    if assign.dtype != torch.int64 or counts.dtype != torch.int64 or state.dtype != torch.int32 or state.numel() < 4:
+        raise RqHipError("kmeans_lloyd: assign/counts must be int64, state int32[4]")
+    B, D = x.shape
+    K = centroids.shape[0]
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rqhip_kmeans_lloyd(_ptr(x), B, D, _ptr(centroids), K, _ptr(assign), _ptr(counts), _ptr(state),
+                                           int(n_iters), float(stop_threshold), _stream())
+        check(rc, "rqhip_kmeans_lloyd")
+
+
+def kmeans_partial_sums(x: Tensor, centroids: Tensor, assign: Tensor, sums: Tensor, state: Tensor) -> None:
+    """Row-sharded Lloyd step, first half (rqhip_kmeans_partial_sums): assign this rank's rows and write their
+    per-cluster sums and counts to sums [K, D+1]; the caller all-reduces `sums`."""
+    _need_gpu(x, centroids, assign, sums, state)
+    B, D = x.shape
+    K = centroids.shape[0]
+    with torch.cuda.device(centroids.device):
+        rc = _lib.lib().rqhip_kmeans_partial_sums(_ptr(x), B, D, _ptr(centroids), K, _ptr(assign), _ptr(sums),
+                                                  _ptr(state), _stream())
+        check(rc, "rqhip_kmeans_partial_sums")
+
+
+def kmeans_apply_sums(sums: Tensor, centroids: Tensor, counts: Tensor, state: Tensor, stop_threshold: float) -> None:
+    """Row-sharded Lloyd step, second half (rqhip_kmeans_apply_sums): means / shift / flags from the reduced sums."""
+    _need_gpu(sums, centroids, counts, state)
+    K, D = centroids.shape
+    with torch.cuda.device(centroids.device):
+        rc = _lib.lib().rqhip_kmeans_apply_sums(_ptr(sums), K, D, _ptr(centroids), _ptr(counts), _ptr(state),
+                                                float(stop_threshold), _stream())
+        check(rc, "rqhip_kmeans_apply_sums")
+
+
 def dedup_rank(ids: Tensor, codebook_size: int = 0, *, want_rank: bool = True):
     """Duplicate statistics of semantic-id tuples (rqhip_dedup_rank).  ids [L,B] int64 ->
     (rank [B] int64 | None, n_distinct [] int64): rank[i] = number of earlier rows with row i's tuple

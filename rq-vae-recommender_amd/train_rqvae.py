@@ -254,13 +254,17 @@ def train(
         model.train()
         if it == 0 and use_kmeans_init:
             # lazy k-means init of every level on its own residuals of the first <= 20 000 items
-            # (train_rqvae.py:178-183); rank 0 computes, everyone receives
-            if is_main:
-                warm = train_dataset[torch.arange(min(20000, len(train_dataset)))]
-                model(warm, t)  # output (and its autograd graph) dropped at once
-            for layer in model.layers:
-                layer.kmeans_initted = True
-            rqdist.broadcast_module(model)
+            # (train_rqvae.py:178-183).  With several ranks each takes its block of those rows through the model and the
+            # Lloyd iterations all-reduce the [K, D+1] sums || counts (init/kmeans.py): every rank
+            # ends with the same codebooks -- unlike the reference, whose ranks would each seed their own
+            import init.kmeans as _km
+            n_warm = min(20000, len(train_dataset))
+            lo, hi = rqdist.shard_bounds(n_warm)
+            _km.SHARDED_INIT = world > 1
+            try:
+                model(train_dataset[torch.arange(lo, hi)], t)  # output (and its autograd graph) dropped at once
+            finally:
+                _km.SHARDED_INIT = False
 
         data = next(train_batches) if gradient_accumulate_every == 1 else None
         if graphed is not None and it >= graph_after:

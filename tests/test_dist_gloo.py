@@ -92,3 +92,94 @@ def test_single_process_defaults():
     assert rqdist.shard_bounds(10) == (0, 10)
     t = torch.arange(4)
     assert rqdist.allgather_rows(t) is t
+
+
+# ---- row-sharded k-means: the collective choreography on two gloo ranks ------------------------
+def _kmeans_worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    from rqhip import dist as rqdist
+    from rqhip import ops
+    from oracle import rq_oracle as o
+    import init.kmeans as km
+    rqdist.init_from_env("cpu")
+
+    # The two array steps are HIP kernels (no CPU path in the product); here they are replaced by the oracle's
+    # restatements so that the HOST logic -- seeding by rank 0, one all-reduce of sums || counts per iteration, identical
+    # stop decisions on every rank, reseed of empty clusters through rank 0's RNG -- runs on CPU tensors over gloo.
+    def fake_partial_sums(x, cent, assign, sums, state):
+        if int(state[0]) != 0:
+            return
+        xn, cn = x.numpy(), cent.numpy()
+        K, D = cn.shape
+        a = o.kmeans_assign(xn, cn) if xn.shape[0] else np.zeros((0,), np.int64)
+        assign.copy_(torch.from_numpy(a))
+        s = np.zeros((K, D + 1), np.float32)
+        for i, k in enumerate(a):
+            s[k, :D] = s[k, :D] + xn[i]
+            s[k, D] += 1
+        sums.copy_(torch.from_numpy(s))
+        state[2] = 0
+
+    def fake_apply_sums(sums, cent, counts, state, thr):
+        if int(state[0]) != 0:
+            return
+        s = sums.numpy()
+        K, D = cent.shape
+        n = s[:, D]
+        old = cent.numpy().copy()
+        new = old.copy()
+        nz = n > 0
+        new[nz] = s[nz, :D] / n[nz, None]
+        cent.copy_(torch.from_numpy(new))
+        counts.copy_(torch.from_numpy(n.astype(np.int64)))
+        shift_sq = np.float32(((new[nz] - old[nz]) ** 2).sum(axis=1).max()) if nz.any() else np.float32(0)
+        state[2] = int(np.array([shift_sq], np.float32).view(np.int32)[0])
+        state[1] += 1
+        if (~nz).any():
+            state[0] = 2
+        elif np.sqrt(shift_sq) < thr:
+            state[0] = 1
+
+    ops.kmeans_partial_sums, ops.kmeans_apply_sums = fake_partial_sums, fake_apply_sums
+    g = torch.Generator().manual_seed(5)
+    K, D, B = 12, 6, 400
+    centers = torch.randn(K // 2, D, generator=g) * 3       # fewer modes than codes: empty clusters do occur
+    X = centers[torch.randint(0, K // 2, (B,), generator=g)] + 0.2 * torch.randn(B, D, generator=g)
+    lo, hi = rqdist.shard_bounds(B)
+    np.random.seed(3)
+    torch.manual_seed(3)          # only rank 0's streams are consumed
+    res = km.Kmeans(k=K).run(X[lo:hi].contiguous(), sharded=True)
+    # every rank holds the same centroids ...
+    both = [torch.zeros_like(res.centroids) for _ in range(world)]
+    dist.all_gather(both, res.centroids)
+    assert torch.equal(both[0], both[1])
+    # ... and they equal a single-process run of the reference loop on the whole matrix (sums in another order)
+    if rank == 0:
+        np.random.seed(3)
+        torch.manual_seed(3)
+        xn = X.numpy()
+        draws = iter(lambda: int(torch.randint(0, B, (1,))), None)
+        cent, assign, _ = o.kmeans_run(xn, np.random.choice(B, K, replace=False), reseed_draws=lambda: next(draws))
+        np.testing.assert_allclose(res.centroids.numpy(), cent, rtol=1e-5, atol=1e-6)
+        assert np.array_equal(res.assignment.numpy(), assign[lo:hi])
+    rqdist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_two_rank_sharded_kmeans_choreography():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kmeans_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]

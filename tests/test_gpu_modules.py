@@ -237,3 +237,87 @@ def test_quantize_module_cosine_distance(name):
     ((out.embeddings * torch.from_numpy(g["g_emb"]).cuda()).sum() + (out.loss * torch.from_numpy(g["g_loss"]).cuda()).sum()).backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(q.embedding.weight.grad.cpu().numpy(), g["grad_codebook"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,D,K,max_iters", [(20000, 32, 256, None), (3000, 32, 64, 5), (5000, 16, 1024, None)])
+def test_kmeans_batched_run_equals_stepwise_oracle(B, D, K, max_iters):
+    """Kmeans.run (batches of device-driven iterations, one host read per batch) against the same loop taken one
+    iteration at a time with the oracle's assign / update: same seed rows, same reseeds, bit-identical centroids."""
+    from init.kmeans import Kmeans
+    from oracle import rq_oracle as o
+    g = torch.Generator().manual_seed(B + K)
+    centers = torch.randn(K // 2, D, generator=g) * 2.0                 # fewer modes than codes -> empty clusters happen
+    x = (centers[torch.randint(0, K // 2, (B,), generator=g)] + 0.3 * torch.randn(B, D, generator=g)).contiguous()
+    np.random.seed(7)
+    torch.manual_seed(7)
+    out = Kmeans(k=K, max_iters=max_iters).run(x.cuda())
+    # stepwise restatement (reference init/kmeans.py:33-72 with the oracle's array steps)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    xn = x.numpy()
+    cent = xn[np.random.choice(B, K, replace=False)].copy()
+    i = 0
+    while max_iters is None or i < max_iters:
+        old = cent.copy()
+        assign = o.kmeans_assign(xn, cent)
+        counts = o.kmeans_update(xn, assign, cent)
+        for k in np.nonzero(counts == 0)[0]:
+            cent[k] = xn[int(torch.randint(0, B, (1,)))]
+        if o.kmeans_shift(cent, old) < 1e-10:
+            break
+        i += 1
+    assert np.array_equal(out.assignment.cpu().numpy(), assign)
+    assert np.array_equal(out.centroids.cpu().numpy().view(np.uint32), cent.view(np.uint32))
+
+
+def test_kmeans_sharded_path_on_one_rank_equals_plain_run():
+    """The row-sharded Lloyd loop (partial sums -> all-reduce over RCCL -> apply) with a single rank must reproduce the
+    plain run bit for bit: same kernels' arithmetic, the collective is the identity."""
+    import os
+    import torch.distributed as dist
+    from init.kmeans import Kmeans
+    g = torch.Generator().manual_seed(11)
+    centers = torch.randn(40, 32, generator=g) * 2.0
+    x = (centers[torch.randint(0, 40, (6000,), generator=g)] + 0.3 * torch.randn(6000, 32, generator=g)).cuda()
+    np.random.seed(9)
+    torch.manual_seed(9)
+    plain = Kmeans(k=64).run(x)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        np.random.seed(9)
+        torch.manual_seed(9)
+        sharded = Kmeans(k=64).run(x, sharded=True)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(plain.assignment, sharded.assignment)
+    assert torch.equal(plain.centroids, sharded.centroids)
+
+
+def test_row_sharded_training_step_equals_full_batch_step():
+    """SURVEY.md section 8e, logical W-way sharding on one GPU: the mean over two row shards of the per-shard gradients
+    (what the flat all-reduce + 1/W produces) equals the gradient of the full-batch step, every parameter, 1e-5."""
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    torch.manual_seed(0)
+    m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
+              n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.STE).cuda()
+    with torch.no_grad():
+        for l, layer in enumerate(m.layers):
+            layer.embedding.weight.copy_(torch.randn(256, 32, device="cuda") * (0.05 / (l + 1)))
+    x = torch.nn.functional.normalize(torch.randn(8192, 768, device="cuda"), dim=-1)
+    m.train()
+
+    def grads(rows):
+        for p in m.parameters():
+            p.grad = None
+        m(SeqBatch(None, None, None, rows, None, None), 0.2).loss.backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    full = grads(x)
+    a, b = grads(x[:4096]), grads(x[4096:])
+    for f, ga, gb in zip(full, a, b):
+        mean = (ga + gb) / 2
+        assert (mean - f).abs().max().item() <= 1e-5 * max(f.abs().max().item(), 1e-3)
