@@ -1,20 +1,21 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 900 -- 'bash tools/profile_bench.sh'
+#   gpurun --timeout 900 -- 'TAG=r02 bash tools/profile_bench.sh'
 # Pass 1: --kernel-trace --stats of the default bench (no CPU baseline leg).  Passes 2, 3: one PMC counter each
 # (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only -- never combined with sys/hip traces.  Outputs under
-# gpurun_out/prof_r01/; tools/summarize_profile.py turns them into the files committed under profiles/.
+# gpurun_out/prof_$TAG/; tools/summarize_profile.py turns them into the files committed under profiles/.
 set -u
 REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
-OUT="$REPO/gpurun_out/prof_r01"
+TAG="${TAG:-r02}"
+OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 300 python "$REPO/bench.py" --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
-    python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+timeout -k 5 300 python "$REPO/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"   # the default line: 200 steps, parity gate, CPU baseline
+timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
+    python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-parity > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
-        python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$c.err"
+    timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
+        python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-parity > /dev/null 2> "$OUT/pmc_$c.err"
 done
 # keep what summarize_profile.py reads (gpurun copies back at most 64 MiB): the stats table, and the counter rows
 # of the hand-written kernels; drop the per-dispatch traces

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_r01/ (written by tools/profile_bench.sh on the GPU box) into the committed evidence:
-   profiles/r01_bench_kernel_stats.csv, r01_bench_kernel_stats_summary.txt, r01_bench_n1.json, r01_pmc_traffic.json
-usage: python tools/summarize_profile.py [gpurun_out/prof_r01]"""
+"""Turn gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh on the GPU box) into the committed evidence:
+   profiles/<tag>_bench_kernel_stats.csv, <tag>_bench_kernel_stats_summary.txt, <tag>_bench_n1.json,
+   <tag>_pmc_traffic_c2.json (the file bench.py reads `roofline.traffic` from)
+usage: python tools/summarize_profile.py [tag, default r02]"""
 import csv
 import glob
 import json
@@ -10,7 +11,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r01")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -22,17 +24,17 @@ def one(pattern):
 
 
 bench = json.loads(open(os.path.join(SRC, "bench_n1.json")).read().strip().splitlines()[-1])
-with open(os.path.join(DST, "r01_bench_n1.json"), "w") as f:
+with open(os.path.join(DST, f"{TAG}_bench_n1.json"), "w") as f:
     f.write(json.dumps(bench) + "\n")
 
 stats = one("stats/**/*kernel_stats.csv")
-shutil.copyfile(stats, os.path.join(DST, "r01_bench_kernel_stats.csv"))
+shutil.copyfile(stats, os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(DST, "r01_bench_kernel_stats_summary.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (MI355X, round 1)\n")
-    f.write(f"# bench line of the same build: profiles/r01_bench_n1.json ({bench['value'] / 1e6:.2f} M items/s, "
+with open(os.path.join(DST, f"{TAG}_bench_kernel_stats_summary.txt"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity` (MI355X, {TAG})\n")
+    f.write(f"# bench line of the same build: profiles/{TAG}_bench_n1.json ({bench['value'] / 1e6:.2f} M items/s, "
             f"{bench['ms_per_step']:.2f} ms/step; roofline launch mean {bench['roofline']['launch_ms_mean'] * 1e3:.1f} us by HIP events)\n")
-    f.write("# top kernels by total time; names shortened; full CSV: r01_bench_kernel_stats.csv\n\n")
+    f.write(f"# top kernels by total time; names shortened; full CSV: {TAG}_bench_kernel_stats.csv\n\n")
     f.write(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}\n")
     for r in rows[:40]:
         f.write(f"{r['Name'][:70]:70s} {int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.1f} "
@@ -44,7 +46,7 @@ with open(os.path.join(DST, "r01_bench_kernel_stats_summary.txt"), "w") as f:
                 f"{float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f}\n")
 
 pmc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 5 "
-                  "--warmup 2 --no-cpu-baseline   (tools/profile_bench.sh)",
+                  "--warmup 2 --no-cpu-baseline --no-parity   (tools/profile_bench.sh)",
        "note": "KB per launch; max = the B=100000 launches (mean includes the 20000-row k-means warm-up launch). gfx950 "
                "correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE under-reports coalesced streaming reads by "
                "2x -> doubled by the consumer (bench.py); WRITE_SIZE uncorrected.",
@@ -72,11 +74,11 @@ if fwk:
     algorithmic = bench["roofline"]["hbm_view"]["algorithmic_bytes_per_row"] * rows
     pmc["rq_forward_kernel"] = {"rows_per_launch": rows, "hbm_bytes_per_launch_corrected": corrected,
                                 "algorithmic_bytes_per_launch": algorithmic, "ratio": corrected / algorithmic}
-with open(os.path.join(DST, "r01_pmc_traffic.json"), "w") as f:
+with open(os.path.join(DST, f"{TAG}_pmc_traffic_c2.json"), "w") as f:
     json.dump(pmc, f, indent=1)
     f.write("\n")
 fw = [k for k in pmc["kernels"] if "rq_forward_kernel" in k]
 for k in fw:
     v = pmc["kernels"][k]
     print(k, "-> traffic per launch (2*FETCH+WRITE) =", (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024 / 1e6, "MB")
-print("wrote profiles/r01_*")
+print(f"wrote profiles/{TAG}_*")
