@@ -229,6 +229,10 @@ int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat, const flo
                                    const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
                                    rqhip_stream_t stream);
 
+/* The three batch means of RqVae.forward (modules/rqvae.py:154,171-172) in one launch:
+ *   out3[0] = mean(recon + quant), out3[1] = mean(recon), out3[2] = mean(quant);  recon, quant [B] fp32, B >= 1. */
+int rqhip_loss_means(const float *recon, const float *quant, int64_t B, float *out3, rqhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of a bias-free Linear(+ReLU) layer with the ReLU backward fused in (SURVEY.md section 8 row f2;
  * reference modules/encoder.py:25-38, autograd of `relu(x @ W.T)`).

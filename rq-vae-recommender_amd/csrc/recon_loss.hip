@@ -134,6 +134,44 @@ __global__ __launch_bounds__(256) void recon_bwd_spec_kernel(const float *__rest
     }
 }
 
+// The three batch means RqVae.forward returns (modules/rqvae.py:154,171-172): mean(recon + quant), mean(recon),
+// mean(quant) -- one launch instead of an elementwise add and three two-stage reductions (3 x 16.6 us at 100 000 rows).
+// One workgroup; thread t adds the float4 groups t, t + 1024, ... in order, then a fixed LDS tree: deterministic.
+__global__ __launch_bounds__(1024) void loss_means_kernel(const float *__restrict__ recon, const float *__restrict__ quant,
+                                                          long long B, float *__restrict__ out) {
+    __shared__ float red[3][1024];
+    const int t = threadIdx.x;
+    float s_sum = 0.0f, s_r = 0.0f, s_q = 0.0f;
+    const bool vec = ((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(quant)) & 15) == 0;
+    const long long n4 = vec ? B / 4 : 0;
+    for (long long i = t; i < n4; i += 1024) {
+        const f32x4 a = reinterpret_cast<const f32x4 *>(recon)[i];
+        const f32x4 b = reinterpret_cast<const f32x4 *>(quant)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s_sum = s_sum + (a[j] + b[j]);
+            s_r = s_r + a[j];
+            s_q = s_q + b[j];
+        }
+    }
+    for (long long i = 4 * n4 + t; i < B; i += 1024) {
+        const float a = recon[i], b = quant[i];
+        s_sum = s_sum + (a + b);
+        s_r = s_r + a;
+        s_q = s_q + b;
+    }
+    red[0][t] = s_sum; red[1][t] = s_r; red[2][t] = s_q;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c][t] = red[c][t] + red[c][t + s];
+        }
+        __syncthreads();
+    }
+    if (t < 3) out[t] = red[t][0] / (float)B;
+}
+
 static int row_grid(long long B) {
     long long want = (B + 3) / 4, cap = (long long)cu_count() * 8;
     if (want < 1) want = 1;
@@ -210,5 +248,16 @@ extern "C" int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat
     hipLaunchKernelGGL(recon_bwd_spec_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        x_hat, (long long)ld_hat, x, (long long)ld_x, g_out, (long long)B, N, row_scale, g_spec);
     RQ_CHECK_LAUNCH("recon_bwd_spec_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_loss_means(const float *recon, const float *quant, int64_t B, float *out3, rqhip_stream_t stream) {
+    if (B <= 0 || !recon || !quant || !out3) {
+        set_error("loss_means: bad arguments");
+        return RQHIP_EARG;
+    }
+    hipLaunchKernelGGL(loss_means_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), recon, quant,
+                       (long long)B, out3);
+    RQ_CHECK_LAUNCH("loss_means_kernel");
     return RQHIP_OK;
 }

@@ -169,9 +169,26 @@ __device__ __forceinline__ void cb_accumulate(float *__restrict__ tab_l, const f
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const int id = __builtin_amdgcn_readlane(myid, j);
+            // the next row of this wave too, when it belongs to ANOTHER code: two independent read-add-write chains in
+            // flight instead of one (same code: strictly one after the other -- the order of the sum is the contract)
+            int j2 = -1, id2 = -1;
+            if (m) {
+                j2 = __builtin_ctzll(m);
+                id2 = __builtin_amdgcn_readlane(myid, j2);
+                if (id2 != id) m &= m - 1; else j2 = -1;
+            }
             if (lane < D) {
                 float *t = tab_l + (size_t)id * D + lane;
-                *t = *t + stage[(size_t)(base + j) * (D + 1) + lane];
+                if (j2 >= 0) {
+                    float *t2 = tab_l + (size_t)id2 * D + lane;
+                    const float a = *t, b = *t2;
+                    const float va = stage[(size_t)(base + j) * (D + 1) + lane];
+                    const float vb = stage[(size_t)(base + j2) * (D + 1) + lane];
+                    *t = a + va;
+                    *t2 = b + vb;
+                } else {
+                    *t = *t + stage[(size_t)(base + j) * (D + 1) + lane];
+                }
             }
         }
     }

@@ -26,7 +26,7 @@ from modules.loss import CategoricalReconstuctionLoss, ReconstructionLoss
 from modules.normalize import l2norm
 from modules.quantize import Quantize, QuantizeForwardMode
 from rqhip import ops
-from rqhip.autograd import RqStackFunction
+from rqhip.autograd import LossMeansFunction, RqStackFunction
 
 # The reference sets "high" here (rqvae.py:19): on its CPU path that is plain fp32 (bit-identical to "highest",
 # SURVEY probe 3), but on ROCm "high" switches the MLP GEMMs to a reduced-precision tf32 class.  Parity is judged
@@ -172,14 +172,18 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         x_hat = torch.cat([l2norm(x_hat[..., :-n]), x_hat[..., -n:]], dim=-1) if n != 0 else x_hat
         reconstruction = self.reconstruction_loss(x_hat, x)
         rqvae_loss = st.loss
-        loss = (reconstruction + rqvae_loss).mean()
+        if reconstruction.dim() == 1 and reconstruction.is_cuda and reconstruction.dtype == torch.float32:
+            # the three batch means of rqvae.py:154,171-172 in one launch
+            loss, recon_mean, rq_mean = LossMeansFunction.apply(reconstruction, rqvae_loss)
+        else:
+            loss, recon_mean, rq_mean = (reconstruction + rqvae_loss).mean(), reconstruction.mean(), rqvae_loss.mean()
         with torch.no_grad():
             _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
             p_unique_ids = n_distinct / st.ids.shape[1]                   # rqvae.py:159-167
         return RqVaeComputedLosses(
             loss=loss,
-            reconstruction_loss=reconstruction.mean(),
-            rqvae_loss=rqvae_loss.mean(),
+            reconstruction_loss=recon_mean,
+            rqvae_loss=rq_mean,
             embs_norm=st.embs_norm,
             p_unique_ids=p_unique_ids,
         )

@@ -105,3 +105,26 @@ class ReconLossFunction(torch.autograd.Function):
         if not (need_hat or need_x):
             return None, None
         return ops.recon_loss_backward(x_hat, x, _dense(g_out), need_hat, need_x)
+
+
+class LossMeansFunction(torch.autograd.Function):
+    """(loss, reconstruction_loss, rqvae_loss) of RqVae.forward -- mean(recon + quant), mean(recon), mean(quant) -- as one
+    launch.  Backward is what autograd derives for the three means: every row of `recon` receives
+    (g_loss + g_recon_mean) / B, every row of `quant` (g_loss + g_quant_mean) / B."""
+
+    @staticmethod
+    def forward(ctx, recon: Tensor, quant: Tensor):
+        ctx.n = recon.numel()
+        out = ops.loss_means(recon, quant)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_rmean, g_qmean):
+        def rows(a, b):
+            parts = [g for g in (a, b) if g is not None]
+            if not parts:
+                return None
+            g = parts[0] if len(parts) == 1 else parts[0] + parts[1]
+            return (g / ctx.n).expand(ctx.n)
+        return (rows(g_loss, g_rmean) if ctx.needs_input_grad[0] else None,
+                rows(g_loss, g_qmean) if ctx.needs_input_grad[1] else None)

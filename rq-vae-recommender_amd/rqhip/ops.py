@@ -406,6 +406,19 @@ def recon_loss_backward_spec(x_hat: Tensor, x: Tensor, g_out: Tensor, row_scale:
     return g_spec
 
 
+def loss_means(recon: Tensor, quant: Tensor) -> Tensor:
+    """[3] = mean(recon + quant), mean(recon), mean(quant) in one launch (rqhip_loss_means)."""
+    _need_gpu(recon, quant)
+    recon, quant = _f32c(recon, "recon"), _f32c(quant, "quant")
+    if recon.dim() != 1 or recon.shape != quant.shape or recon.numel() == 0:
+        raise RqHipError(f"loss_means: need two non-empty [B] tensors, got {tuple(recon.shape)}, {tuple(quant.shape)}")
+    with torch.cuda.device(recon.device):
+        out = torch.empty((3,), dtype=torch.float32, device=recon.device)
+        check(_lib.lib().rqhip_loss_means(_ptr(recon), _ptr(quant), recon.numel(), _ptr(out), _stream()),
+              "rqhip_loss_means")
+    return out
+
+
 def linear_wgrad_supported(n_out: int, n_in: int) -> bool:
     return bool(_lib.lib().rqhip_linear_wgrad_supported(int(n_out), int(n_in)))
 
