@@ -321,6 +321,64 @@ def gen_sid_match():
         np.savez_compressed(os.path.join(OUT, f"topk_{tag}.npz"), **save)
 
 
+def gen_config3_step(q, r, km, sch):
+    """BASELINE configuration 3 at its real shape (reference configs/rqvae_ml32m.gin:4-25): 768 -> [512,256,128] -> 64,
+    3 x 256 codes, ROTATION_TRICK, batch 64, AdamW lr 1e-4 / weight decay 0.01, k-means initialised codebooks.
+    One full training step of the reference (forward, backward, optimizer step).  The MLP weights are regenerable
+    (torch.manual_seed(0) construction; a sha256 pins them), so only inputs, codebooks and compact views of the
+    1.15 M-parameter gradients / updates are stored: everything for the codebooks, norm + sum + a 8 x 16 corner for
+    every MLP weight."""
+    import hashlib
+    fwd = r.RqVae.forward._torchdynamo_orig_callable
+    torch.manual_seed(0)
+    model = r.RqVae(input_dim=768, embed_dim=64, hidden_dims=[512, 256, 128], codebook_size=256,
+                    codebook_kmeans_init=False, codebook_mode=q.QuantizeForwardMode.ROTATION_TRICK, n_layers=3,
+                    commitment_weight=0.25, n_cat_features=0)
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        if "embedding" not in k:
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(v.numpy()).view(np.uint8).reshape(-1))
+    g = torch.Generator().manual_seed(303)
+    x_init = torch.nn.functional.normalize(torch.randn(4096, 768, generator=g), dim=-1)
+    x = torch.nn.functional.normalize(torch.randn(64, 768, generator=g), dim=-1)
+    model.eval()
+    with torch.no_grad():                      # codebooks: the reference's k-means, level by level (10 iterations)
+        res = model.encode(x_init)
+        for l, layer in enumerate(model.layers):
+            np.random.seed(300 + l)
+            torch.manual_seed(300 + l)
+            layer.embedding.weight.copy_(km.Kmeans(k=256, max_iters=10).run(res.clone()).centroids)
+            res = res - layer(res, temperature=0.2).embeddings
+    save = {"x": np32(x), "weights_sha256": h.hexdigest(), "lr": np.float64(1e-4), "weight_decay": np.float64(0.01),
+            "codebooks": np.stack([np32(l.embedding.weight) for l in model.layers])}
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    batch = sch.SeqBatch(user_ids=None, ids=None, ids_fut=None, x=x, x_fut=None, seq_mask=None)
+    opt.zero_grad()
+    out = fwd(model, batch, 0.2)
+    with torch.no_grad():
+        save["sem_ids"] = model.get_semantic_ids(x, 0.2).sem_ids.numpy().astype(np.int64)
+    out.loss.backward()
+    opt.step()
+    for name in ("loss", "reconstruction_loss", "rqvae_loss", "p_unique_ids"):
+        save[name] = np32(getattr(out, name))
+    save["embs_norm"] = np32(out.embs_norm)
+
+    def compact(prefix, k, t):
+        if "embedding" in k:
+            save[f"{prefix}::{k}"] = np32(t)
+        else:
+            save[f"{prefix}_stat::{k}"] = np.array([t.norm().item(), t.sum().item()], np.float64)
+            save[f"{prefix}_corner::{k}"] = np32(t[:8, :16])
+
+    for k, v in model.named_parameters():
+        compact("grad", k, v.grad)
+        compact("delta", k, v.detach() - before[k])
+    np.savez_compressed(os.path.join(OUT, "rqvae_c3_step.npz"), **save)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -328,12 +386,16 @@ def main():
         gen_sid_match()
         return
     q, r, km, sem, sch = import_reference()
+    if "--only-config3" in sys.argv:
+        gen_config3_step(q, r, km, sch)
+        return
     gen_quantize(q)
     gen_gumbel(q)
     gen_cosine(q)
     gen_rqvae(q, r, sch)
     gen_kmeans(km)
     gen_dedup(q, r, sem, sch)
+    gen_config3_step(q, r, km, sch)
     gen_sid_match()
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {total / 1024:.0f} KiB -> {os.path.abspath(OUT)}")

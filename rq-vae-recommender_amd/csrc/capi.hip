@@ -14,13 +14,19 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    return dev;
+}
+
 int cu_count() {
-    static int cached = 0;
-    if (cached > 0) return cached;
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    static int cached[kMaxDevices] = {};   // per device: a process may drive several GPUs
+    const int dev = current_device();
+    if (dev < kMaxDevices && cached[dev] > 0) return cached[dev];
+    int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-    cached = n;
+    if (dev < kMaxDevices) cached[dev] = n;
     return n;
 }
 

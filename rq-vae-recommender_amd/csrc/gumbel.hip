@@ -392,12 +392,8 @@ extern "C" int rqhip_gumbel_forward(const float *x, int64_t B, int D, const floa
     p.x = x; p.cb = codebook; p.U = U; p.ids = ids; p.emb = emb; p.loss = loss;
     p.B = B; p.D = D; p.K = K; p.Kpad = (K + 63) & ~63; p.temperature = temperature; p.beta = beta;
     const size_t lds = gumbel_lds_floats(D, K, p.Kpad, false) * sizeof(float);
-    static bool attr_fwd = false;
-    if (!attr_fwd) {
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<false, false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_fwd = true;
-    }
+    static LdsGrant attr_fwd;
+    RQ_RETURN_IF_HIP(attr_fwd.ensure(reinterpret_cast<const void *>(gumbel_kernel<false, false>), 160 * 1024));
     hipLaunchKernelGGL((gumbel_kernel<false, false>), dim3(gumbel_grid(B)), dim3(kGThreads), lds,
                        reinterpret_cast<hipStream_t>(stream), p);
     RQ_CHECK_LAUNCH("gumbel_kernel<fwd>");
@@ -448,14 +444,9 @@ extern "C" int rqhip_gumbel_backward(const float *x, int64_t B, int D, const flo
     p.partial = reinterpret_cast<float *>(workspace);
     p.B = B; p.D = D; p.K = K; p.Kpad = (K + 63) & ~63; p.temperature = temperature; p.beta = beta;
     const size_t lds = gumbel_lds_floats(D, K, p.Kpad, true) * sizeof(float);
-    static bool attr_bwd = false;
-    if (!attr_bwd) {
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<true, false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gumbel_kernel<true, true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_bwd = true;
-    }
+    static LdsGrant grant_plain, grant_acc;
+    RQ_RETURN_IF_HIP(grant_plain.ensure(reinterpret_cast<const void *>(gumbel_kernel<true, false>), 160 * 1024));
+    RQ_RETURN_IF_HIP(grant_acc.ensure(reinterpret_cast<const void *>(gumbel_kernel<true, true>), 160 * 1024));
     if (K <= 64 * kGAccPerLane && D <= kGAccD)
         hipLaunchKernelGGL((gumbel_kernel<true, true>), dim3(grid), dim3(kGThreads), lds, s, p);
     else

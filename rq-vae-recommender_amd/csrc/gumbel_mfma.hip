@@ -426,12 +426,8 @@ int gumbel_mfma_backward(const GumbelMfmaParams &p0, hipStream_t s) {
     const size_t lds = gm_lds_floats_bwd(p.K) * sizeof(float);
     const int grid = gumbel_mfma_backward_grid(p.B);
     auto go = [&](auto kern) -> int {
-        static bool attr = false;
-        if (!attr) {
-            RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
-        }
+        static LdsGrant attr;
+        RQ_RETURN_IF_HIP(attr.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kGmThreads), lds, s, p);
         RQ_CHECK_LAUNCH("gumbel_mfma_backward_kernel");
         return 0;
@@ -450,12 +446,8 @@ int gumbel_mfma_forward(const GumbelMfmaParams &p0, hipStream_t s) {
     const size_t lds = gm_lds_floats(p.K) * sizeof(float);
     const int grid = gm_grid(p.n_tiles, 2);
     auto go = [&](auto kern) -> int {
-        static bool attr = false;
-        if (!attr) {
-            RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
-        }
+        static LdsGrant attr;
+        RQ_RETURN_IF_HIP(attr.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kGmThreads), lds, s, p);
         RQ_CHECK_LAUNCH("gumbel_mfma_forward_kernel");
         return 0;

@@ -522,15 +522,8 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
             const int sg = fused_stage_waves(D, K);
             const size_t lds = g_codebooks ? (size_t)nl * K * D * sizeof(float) + fused_stage_bytes(D, sg) : 0;
             auto go = [&](auto kern) -> int {
-                static bool attr[16] = {};   // per device (the attribute belongs to the device's copy of the function)
-                int dev = 0;
-                RQ_RETURN_IF_HIP(hipGetDevice(&dev));
-                if (dev >= 16 || !attr[dev]) {
-                    RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         (int)kFusedLdsBudget));
-                    if (dev < 16) attr[dev] = true;
-                }
+                static LdsGrant grant;
+                RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kFusedLdsBudget));
                 hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD, sg);
                 RQ_CHECK_LAUNCH("rq_backward_fused_kernel");
                 return 0;
@@ -589,12 +582,8 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     const size_t level_bytes = (size_t)K * (D + 1) * sizeof(float);
     int per_pass = (int)(kScatterLdsBudget / level_bytes);
     if (per_pass < 1) per_pass = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rq_cbgrad_scatter_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScatterLdsBudget));
-        attr_set = true;
-    }
+    static LdsGrant scatter_grant;
+    RQ_RETURN_IF_HIP(scatter_grant.ensure(reinterpret_cast<const void *>(rq_cbgrad_scatter_kernel), (int)kScatterLdsBudget));
     for (int l0 = 0; l0 < L; l0 += per_pass) {
         const int nl = (L - l0 < per_pass) ? L - l0 : per_pass;
         hipLaunchKernelGGL(rq_cbgrad_scatter_kernel, dim3(G), dim3(256), nl * level_bytes, s, p.ws, ids, (long long)B,

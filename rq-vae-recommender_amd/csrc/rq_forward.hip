@@ -710,12 +710,8 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
     auto go = [&](auto kern) -> int {
         // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of the per-call
         // path and out of hipGraph captures); the limit only ever grows
-        static size_t granted = 0;
-        if (lds > granted) {
-            RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            granted = kLdsBudget;
-        }
+        static LdsGrant grant;
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kLdsBudget));
         profile_begin(s);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
         profile_end(s);

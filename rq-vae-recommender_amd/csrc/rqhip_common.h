@@ -39,7 +39,23 @@ inline int check_hip(hipError_t e, const char *what) {
         if (_rc) return _rc;                                                        \
     } while (0)
 
-int cu_count();
+int cu_count();          // compute units of the CURRENT device (cached per device)
+constexpr int kMaxDevices = 16;
+int current_device();    // hipGetDevice, 0 on error
+
+// Raise a kernel's dynamic-LDS limit once per (kernel instantiation, DEVICE): the attribute belongs to each device's
+// copy of the function, so a process that drives several GPUs must set it on every one of them.  Usage:
+//   static LdsGrant g;  RQ_RETURN_IF_HIP(g.ensure(reinterpret_cast<const void *>(kernel), bytes));
+struct LdsGrant {
+    bool done[kMaxDevices] = {};
+    hipError_t ensure(const void *kernel, int bytes) {
+        const int dev = current_device();
+        if (dev < kMaxDevices && done[dev]) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev < kMaxDevices) done[dev] = true;
+        return e;
+    }
+};
 
 // bench-only kernel timing (capi.hip); no-ops unless rqhip_profile_enable(n > 0) was called
 void profile_begin(hipStream_t s);

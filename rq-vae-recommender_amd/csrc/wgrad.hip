@@ -283,14 +283,8 @@ extern "C" int rqhip_linear_wgrad_plan(int64_t M, int N, int K, int *msplit) {
 template <int TA, int TB, int WA, int WB, int MC>
 static int wgrad_launch(const WgradParams &p, const WgradPlan &pl, bool mask, hipStream_t s) {
     auto go = [&](auto kern) -> int {
-        static bool attr_set[16] = {};
-        int dev = 0;
-        RQ_RETURN_IF_HIP(hipGetDevice(&dev));
-        if (dev < 16 && !attr_set[dev]) {
-            RQ_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set[dev] = true;
-        }
+        static LdsGrant grant;
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
         hipLaunchKernelGGL(kern, dim3(pl.nslab_n * pl.nslab_k * pl.msplit), dim3(64 * WA * WB), pl.lds, s, p);
         RQ_CHECK_LAUNCH("wgrad_kernel");
         return 0;

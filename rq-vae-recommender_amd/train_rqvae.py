@@ -119,13 +119,24 @@ class _GraphedStep:
         self._opt.step()
         return out
 
-    def capture(self) -> None:
+    def capture(self, x: torch.Tensor) -> None:
+        """Capture one step on the current batch.  The two warm-up steps graph capture needs run on that batch too, and
+        their optimizer updates are rolled back (parameters and optimizer state are snapshotted and restored), so a
+        capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
+        import copy
+        self.x.copy_(x)
+        params = [p.detach().clone() for p in self._model.parameters()]
+        opt_state = copy.deepcopy(self._opt.state_dict())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
             for _ in range(2):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, saved in zip(self._model.parameters(), params):
+                p.copy_(saved)
+        self._opt.load_state_dict(opt_state)
         self._reducer.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -268,11 +279,14 @@ def train(
 
         data = next(train_batches) if gradient_accumulate_every == 1 else None
         if graphed is not None and it >= graph_after:
+            if len(train_dataset) < batch_size:
+                raise ValueError(f"use_hip_graph needs full batches: the training split has {len(train_dataset)} rows, "
+                                 f"batch_size is {batch_size}")
             while data.x.shape[0] != batch_size:   # graph mode trains on full batches only: epoch tails are skipped
                 data = next(train_batches)
         if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
             if graphed.graph is None:
-                graphed.capture()
+                graphed.capture(data.x)
             model_output = graphed.run(data.x)
             total_loss = model_output.loss.detach()
         else:

@@ -321,3 +321,51 @@ def test_row_sharded_training_step_equals_full_batch_step():
     for f, ga, gb in zip(full, a, b):
         mean = (ga + gb) / 2
         assert (mean - f).abs().max().item() <= 1e-5 * max(f.abs().max().item(), 1e-3)
+
+
+def test_config3_real_shape_training_step_matches_reference():
+    """BASELINE configuration 3 at its real shape (rqvae_ml32m.gin: D = 64, rotation trick, batch 64, AdamW 1e-4 / 0.01):
+    one full training step -- forward, backward, optimizer update -- against the reference's own step
+    (tests/golden/rqvae_c3_step.npz, oracle/gen_golden.py:gen_config3_step)."""
+    import hashlib
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    g = load_golden("rqvae_c3_step.npz")
+    torch.manual_seed(0)
+    m = RqVae(input_dim=768, embed_dim=64, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
+              n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.ROTATION_TRICK,
+              commitment_weight=0.25)
+    h = hashlib.sha256()
+    for k, v in m.state_dict().items():
+        if "embedding" not in k:
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(v.numpy()).view(np.uint8).reshape(-1))
+    assert h.hexdigest() == str(g["weights_sha256"])       # same seeded construction as the reference
+    with torch.no_grad():
+        for l, layer in enumerate(m.layers):
+            layer.embedding.weight.copy_(torch.from_numpy(g["codebooks"][l]))
+    m = m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    x = torch.from_numpy(g["x"]).cuda()
+    out = m(SeqBatch(None, None, None, x, None, None), 0.2)
+    with torch.no_grad():
+        ids = m.get_semantic_ids(x, 0.2).sem_ids.cpu().numpy()
+    out.loss.backward()
+    opt.step()
+    assert np.array_equal(ids, g["sem_ids"])
+    for name in ("loss", "reconstruction_loss", "rqvae_loss", "p_unique_ids"):
+        assert abs(float(getattr(out, name)) - float(g[name])) < 1e-5, name
+    np.testing.assert_allclose(out.embs_norm.cpu().numpy(), g["embs_norm"], rtol=1e-4, atol=1e-6)
+    for k, v in m.named_parameters():
+        for prefix, t in (("grad", v.grad), ("delta", v.detach() - before[k])):
+            t = t.float().cpu()
+            scale = max(float(t.abs().max()), 1e-12)
+            if "embedding" in k:
+                np.testing.assert_allclose(t.numpy(), g[f"{prefix}::{k}"], rtol=1e-3, atol=2e-5 * scale, err_msg=f"{prefix} {k}")
+            else:
+                stat = g[f"{prefix}_stat::{k}"]
+                assert abs(float(t.norm()) - stat[0]) <= 1e-3 * stat[0] + 1e-9, (prefix, k)
+                np.testing.assert_allclose(t[:8, :16].numpy(), g[f"{prefix}_corner::{k}"], rtol=2e-3, atol=2e-5 * scale,
+                                           err_msg=f"{prefix} {k}")
