@@ -359,13 +359,20 @@ def test_config3_real_shape_training_step_matches_reference():
         assert abs(float(getattr(out, name)) - float(g[name])) < 1e-5, name
     np.testing.assert_allclose(out.embs_norm.cpu().numpy(), g["embs_norm"], rtol=1e-4, atol=1e-6)
     for k, v in m.named_parameters():
-        for prefix, t in (("grad", v.grad), ("delta", v.detach() - before[k])):
-            t = t.float().cpu()
-            scale = max(float(t.abs().max()), 1e-12)
-            if "embedding" in k:
-                np.testing.assert_allclose(t.numpy(), g[f"{prefix}::{k}"], rtol=1e-3, atol=2e-5 * scale, err_msg=f"{prefix} {k}")
-            else:
+        grad, delta = v.grad.float().cpu(), (v.detach() - before[k]).float().cpu()
+        gscale = max(float(grad.abs().max()), 1e-12)
+        if "embedding" in k:
+            ref_g, ref_d = g[f"grad::{k}"], g[f"delta::{k}"]
+            got_g, got_d = grad.numpy(), delta.numpy()
+        else:
+            for prefix, t in (("grad", grad), ("delta", delta)):
                 stat = g[f"{prefix}_stat::{k}"]
                 assert abs(float(t.norm()) - stat[0]) <= 1e-3 * stat[0] + 1e-9, (prefix, k)
-                np.testing.assert_allclose(t[:8, :16].numpy(), g[f"{prefix}_corner::{k}"], rtol=2e-3, atol=2e-5 * scale,
-                                           err_msg=f"{prefix} {k}")
+            ref_g, ref_d = g[f"grad_corner::{k}"], g[f"delta_corner::{k}"]
+            got_g, got_d = grad[:8, :16].numpy(), delta[:8, :16].numpy()
+        np.testing.assert_allclose(got_g, ref_g, rtol=2e-3, atol=2e-5 * gscale, err_msg=f"grad {k}")
+        # the first AdamW update is -lr * g / (|g| + 1e-8) - lr * wd * p: ill-conditioned where the gradient is ~0, so
+        # the update is compared where the gradient is not negligible (elsewhere only its bound lr * (1 + wd |p|))
+        solid = np.abs(ref_g) > 1e-3 * gscale
+        np.testing.assert_allclose(got_d[solid], ref_d[solid], rtol=2e-3, atol=1e-9, err_msg=f"delta {k}")
+        assert np.abs(got_d).max() <= float(g["lr"]) * 1.05 + 1e-7
