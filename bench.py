@@ -245,7 +245,7 @@ def main():
     model, kmeans_s = build_model(device, X[: min(20000, B)], LEVELS, CODES)
     rqdist.broadcast_module(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)  # one multi-tensor kernel
-    reducer = rqdist.FlatGradReducer(model.parameters())
+    reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
     batches = [SeqBatch(None, None, None, X[lo:min(B, lo + micro)], None, None) for lo in range(0, B, micro)]
     n_micro = len(batches)
 

@@ -16,6 +16,18 @@ from modules.normalize import L2NormalizationLayer
 from rqhip import ops
 
 
+def _grad_sink(w: Tensor):
+    """The parameter's slice of a flat gradient buffer (rqhip.dist.FlatGradReducer.attach), usable for the FIRST
+    gradient of a step only: later ones must be accumulated by autograd, not overwritten."""
+    view = getattr(w, "_rq_grad_view", None)
+    return view if (view is not None and w.grad is None) else None
+
+
+def _adopt(gw: Tensor, sink) -> Tensor:
+    """A fresh alias of the sink: autograd takes a gradient tensor over as `.grad` only when nobody else holds it."""
+    return gw.view_as(gw) if sink is not None else gw
+
+
 def _hip_wgrad_ok(g: Tensor, w: Tensor) -> bool:
     return (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[0] > 0
             and ops.linear_wgrad_supported(w.shape[0], w.shape[1]))
@@ -37,13 +49,14 @@ class _LinearReLU(torch.autograd.Function):
     def backward(ctx, gy: Tensor):
         x, w, y = ctx.saved_tensors
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        sink = _grad_sink(w) if need_w else None
         if need_w and _hip_wgrad_ok(gy, w):
-            gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x)
+            gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x, out=sink)
         else:
             g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
-            gw = g.t().mm(x) if need_w else None
+            gw = (torch.mm(g.t(), x, out=sink) if sink is not None else g.t().mm(x)) if need_w else None
         gx = g.mm(w) if need_x else None
-        return gx, gw, None
+        return gx, (_adopt(gw, sink) if need_w else None), None
 
 
 class _LinearPlain(torch.autograd.Function):
@@ -63,7 +76,12 @@ class _LinearPlain(torch.autograd.Function):
             # without a mask to fuse the hand-written kernel only wins on the small layers; the 768 x 512 one stays
             # with the library (measured 626 vs 600 us at 100 000 rows)
             small = w.shape[0] * w.shape[1] <= 256 * 256
-            gw = ops.linear_wgrad(gy, None, x)[0] if (small and _hip_wgrad_ok(gy, w)) else gy.t().mm(x)
+            sink = _grad_sink(w)
+            if small and _hip_wgrad_ok(gy, w):
+                gw = ops.linear_wgrad(gy, None, x, out=sink)[0]
+            else:
+                gw = torch.mm(gy.t(), x, out=sink) if sink is not None else gy.t().mm(x)
+            gw = _adopt(gw, sink)
         gx = gy.mm(w) if need_x else None
         return gx, gw
 

@@ -136,7 +136,7 @@ class Quantize(nn.Module):
         with torch.no_grad():
             xn = x / x.norm(dim=1, keepdim=True)
             cn = codebook / codebook.norm(dim=1, keepdim=True)
-            ids = RqStackFunction.apply(xn, cn.unsqueeze(0), MODE_EVAL, 0.0, False)[2][0]
+            ids = RqStackFunction.apply(xn, cn.unsqueeze(0), MODE_EVAL, 0.0, False, None)[2][0]
         emb = self.get_item_embeddings(ids)
         if not self.training:
             return QuantizeOutput(embeddings=emb, ids=ids, loss=self.quantize_loss(query=x, value=emb))
@@ -170,5 +170,5 @@ class Quantize(nn.Module):
             raise Exception("Unsupported Quantize forward mode.")
 
         embs, _res, ids, loss, _sum, _norm = RqStackFunction.apply(x, codebook.unsqueeze(0), self.hip_mode(), beta,
-                                                                   True)
+                                                                   True, None)
         return QuantizeOutput(embeddings=embs[0], ids=ids[0], loss=loss)

@@ -130,8 +130,11 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
     def _quantize_stack(self, res: Tensor, gumbel_t: float, want_levels: bool) -> _StackResult:
         if self._can_fuse():
             codebooks = torch.stack([layer.codebook() for layer in self.layers])  # [L,K,D], autograd splits it back
+            sink = getattr(self, "_rq_cb_grad_sink", None)
+            if sink is not None and not all(layer.plain_codebook for layer in self.layers):
+                sink = None
             out = RqStackFunction.apply(res, codebooks, self.layers[0].hip_mode(), float(self.commitment_weight),
-                                        want_levels)
+                                        want_levels, sink)
             return _StackResult(*out)
         # level-by-level (first call with lazy k-means init, or Gumbel-softmax training): the reference's loop
         # (rqvae.py:125-132), each level being one L=1 launch of the same kernels

@@ -30,10 +30,12 @@ class RqStackFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, res0: Tensor, codebooks: Tensor, mode: int, beta: float, want_levels: bool):
+    def forward(ctx, res0: Tensor, codebooks: Tensor, mode: int, beta: float, want_levels: bool, grad_sink=None):
+        """grad_sink (optional): object with `.view` ([L,K,D] slice of a flat gradient buffer) and `.params` (the L
+        codebook parameters); the codebook gradient is written there when it is the first gradient of the step."""
         out = ops.rq_forward(res0, codebooks, mode, beta, want_embs=want_levels, want_residuals=want_levels)
         ctx.save_for_backward(res0, codebooks, out.ids)
-        ctx.mode, ctx.beta, ctx.want_levels = mode, beta, want_levels
+        ctx.mode, ctx.beta, ctx.want_levels, ctx.grad_sink = mode, beta, want_levels, grad_sink
         embs = out.embs if want_levels else res0.new_empty((0,))
         residuals = out.residuals if want_levels else res0.new_empty((0,))
         if want_levels:
@@ -47,13 +49,19 @@ class RqStackFunction(torch.autograd.Function):
         res0, codebooks, ids = ctx.saved_tensors
         need_res0, need_cb = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_res0 or need_cb):
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if not ctx.want_levels:
             g_embs = g_resid = None
+        sink = ctx.grad_sink
+        out_cb = None
+        if need_cb and sink is not None and tuple(sink.view.shape) == tuple(codebooks.shape) and all(
+                p.grad is None for p in sink.params):
+            out_cb = sink.view      # first gradient of the step: straight into the flat buffer (autograd's stack backward
+                                    # hands each level's slice to its parameter as a view)
         g_res0, g_cb = ops.rq_backward(res0, codebooks, ctx.mode, ctx.beta, ids, g_embs=_dense(g_embs),
                                        g_embsum=_dense(g_embsum), g_resid=_dense(g_resid), g_loss=_dense(g_loss),
-                                       need_res0=need_res0, need_codebooks=need_cb)
-        return g_res0, g_cb, None, None, None
+                                       need_res0=need_res0, need_codebooks=need_cb, out_g_codebooks=out_cb)
+        return g_res0, (g_cb.view_as(g_cb) if out_cb is not None else g_cb), None, None, None, None
 
 
 class GumbelLevelFunction(torch.autograd.Function):

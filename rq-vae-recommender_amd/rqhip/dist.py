@@ -76,16 +76,18 @@ def broadcast_module(module: nn.Module, src: int = 0) -> None:
 
 
 class FlatGradReducer:
-    """One collective per step for all gradients, without per-parameter accumulation kernels.
+    """One collective per step for all gradients, without per-parameter accumulation kernels and without a packing copy.
 
     Usage per step:  reducer.zero_()  ->  loss.backward() (any number of times)  ->  reducer.allreduce_mean()
     ->  optimizer.step().
 
-    `zero_()` drops the .grad tensors, so autograd ASSIGNS fresh gradients (no `grad += new` kernel per
-    parameter; those 11 small adds were 0.37 ms of a 6.8 ms step on MI355X).  With one rank nothing else
-    happens.  With W > 1 ranks `allreduce_mean()` packs the gradients into one flat fp32 buffer with a single
-    `torch.cat(out=...)`, all-reduces it in place, scales by 1/W and re-points every .grad at its slice of the
-    buffer (views, no copies), which is what the optimizer then reads.
+    `zero_()` drops the .grad tensors, so autograd ASSIGNS fresh gradients (no `grad += new` kernel per parameter;
+    those 11 small adds were 0.37 ms of a 6.8 ms step on MI355X).  `attach(model)` tells the backward functions of
+    this package (modules/encoder.py, rqhip/autograd.py) where each parameter's slice of the flat fp32 buffer is: they
+    then WRITE the step's first gradient of every weight / codebook straight into it and hand autograd an alias, so
+    `.grad` already lives in the buffer when backward ends -- `allreduce_mean()` is the bare all-reduce + 1/W scale.
+    Gradients produced by other code (a parameter this package does not know) are packed the old way, with one
+    `torch.cat(out=...)`.  With one rank nothing is exchanged.
     """
 
     def __init__(self, params: Iterable[nn.Parameter]) -> None:
@@ -95,11 +97,31 @@ class FlatGradReducer:
         dev, dtype = self.params[0].device, self.params[0].dtype
         self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dtype)
         self._views = []
+        self._offsets = []
         offset = 0
         for p in self.params:
             n = p.numel()
             self._views.append(self.flat[offset:offset + n].view_as(p))
+            self._offsets.append(offset)
             offset += n
+
+    def attach(self, model: Optional[nn.Module] = None) -> "FlatGradReducer":
+        """Publish the slices: `param._rq_grad_view` for every parameter and, for an RqVae whose level codebooks are plain
+        embeddings lying back to back in the buffer, `model._rq_cb_grad_sink` for the fused quantiser backward."""
+        from types import SimpleNamespace
+        for p, v in zip(self.params, self._views):
+            p._rq_grad_view = v
+        layers = getattr(model, "layers", None)
+        if layers is not None and len(layers) > 0 and all(hasattr(l, "embedding") for l in layers):
+            cbs = [l.embedding.weight for l in layers]
+            idx = [next((i for i, p in enumerate(self.params) if p is c), None) for c in cbs]
+            shapes_ok = all(c.shape == cbs[0].shape for c in cbs)
+            if None not in idx and shapes_ok and all(b == a + 1 for a, b in zip(idx, idx[1:])):
+                K, D = cbs[0].shape
+                off = self._offsets[idx[0]]
+                model._rq_cb_grad_sink = SimpleNamespace(view=self.flat[off:off + len(cbs) * K * D].view(len(cbs), K, D),
+                                                         params=cbs)
+        return self
 
     def zero_(self) -> None:
         """Use instead of optimizer.zero_grad()."""
@@ -111,12 +133,14 @@ class FlatGradReducer:
         w = world_size()
         if w == 1 and not (dist.is_available() and dist.is_initialized()):
             return self.flat
-        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        torch.cat(grads, out=self.flat)
+        for p, v in zip(self.params, self._views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():   # produced by code that does not know the buffer: one small copy
+                v.copy_(p.grad)
+            p.grad = v
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / w)
-        for p, v in zip(self.params, self._views):
-            p.grad = v
         return self.flat
 
 

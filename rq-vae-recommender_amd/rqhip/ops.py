@@ -93,7 +93,7 @@ def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_
 def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Tensor, *,
                 g_embs: Optional[Tensor] = None, g_embsum: Optional[Tensor] = None,
                 g_resid: Optional[Tensor] = None, g_loss: Optional[Tensor] = None,
-                need_res0: bool = True, need_codebooks: bool = True):
+                need_res0: bool = True, need_codebooks: bool = True, out_g_codebooks: Optional[Tensor] = None):
     """Closed-form backward of rq_forward (rqhip_rq_backward) -> (g_res0 [B,D] | None, g_codebooks [L,K,D] | None)."""
     _need_gpu(res0, codebooks, ids, g_embs, g_embsum, g_resid, g_loss)
     res0, codebooks = _f32c(res0, "res0"), _f32c(codebooks, "codebooks")
@@ -110,7 +110,11 @@ def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Te
     with torch.cuda.device(dev):
         l = _lib.lib()
         g_res0 = torch.empty((B, D), dtype=torch.float32, device=dev) if need_res0 else None
-        g_cb = torch.empty((L, K, D), dtype=torch.float32, device=dev) if need_codebooks else None
+        g_cb = None
+        if need_codebooks:
+            g_cb = out_g_codebooks if out_g_codebooks is not None else torch.empty((L, K, D), dtype=torch.float32, device=dev)
+            if tuple(g_cb.shape) != (L, K, D) or g_cb.dtype != torch.float32 or not g_cb.is_contiguous():
+                raise RqHipError("rq_backward: out_g_codebooks must be a contiguous float32 [L,K,D] tensor")
         wsb = l.rqhip_rq_backward_workspace_bytes(B, D, L, K)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
         rc = l.rqhip_rq_backward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(g_embs),
@@ -423,10 +427,11 @@ def linear_wgrad_supported(n_out: int, n_in: int) -> bool:
     return bool(_lib.lib().rqhip_linear_wgrad_supported(int(n_out), int(n_in)))
 
 
-def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool = True):
+def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool = True, out: Optional[Tensor] = None):
     """dW [N,K] = (g * (y > 0))^T x with the ReLU backward fused (rqhip_linear_wgrad); y None = layer without ReLU.
     Returns (dW, g_pre): g_pre = the masked gradient in a fresh tensor when `want_masked` and y is given (the input
-    of the data-gradient GEMM that follows), g itself when there is no mask, None when not wanted."""
+    of the data-gradient GEMM that follows), g itself when there is no mask, None when not wanted.  `out`: a
+    contiguous fp32 [N,K] tensor to receive dW (e.g. the parameter's slice of a flat gradient buffer)."""
     _need_gpu(g, y, x)
     g, x = _f32c(g, "g"), _f32c(x, "x")
     y = _f32c(y, "y")
@@ -437,7 +442,9 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
     dev = g.device
     with torch.cuda.device(dev):
         l = _lib.lib()
-        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+        if out is not None and (tuple(out.shape) != (N, K) or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise RqHipError("linear_wgrad: `out` must be a contiguous float32 [N,K] tensor")
+        dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
         wsb = l.rqhip_linear_wgrad_workspace_bytes(M, N, K)
         ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
         gm = torch.empty_like(g) if (want_masked and y is not None) else None

@@ -244,7 +244,7 @@ def train(
         start_iter = state["iter"] + 1
 
     rqdist.broadcast_module(model)
-    reducer = rqdist.FlatGradReducer(model.parameters())
+    reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
 
     tokenizer = SemanticIdTokenizer(
         input_dim=vae_input_dim, hidden_dims=vae_hidden_dims, output_dim=vae_embed_dim,

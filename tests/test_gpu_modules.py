@@ -376,3 +376,39 @@ def test_config3_real_shape_training_step_matches_reference():
         solid = np.abs(ref_g) > 1e-3 * gscale
         np.testing.assert_allclose(got_d[solid], ref_d[solid], rtol=2e-3, atol=1e-9, err_msg=f"delta {k}")
         assert np.abs(got_d).max() <= float(g["lr"]) * 1.05 + 1e-7
+
+
+def test_flat_reducer_attach_puts_gradients_in_the_flat_buffer_without_copies():
+    """rqhip.dist.FlatGradReducer.attach: the backward functions write each weight / codebook gradient straight into its
+    slice of the flat all-reduce buffer (first gradient of a step) and autograd accumulates later ones there; values
+    equal an un-attached run bit for bit."""
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    from rqhip.dist import FlatGradReducer
+
+    def make():
+        torch.manual_seed(0)
+        m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
+                  n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.STE).cuda()
+        with torch.no_grad():
+            for l, layer in enumerate(m.layers):
+                layer.embedding.weight.copy_(torch.randn(256, 32, device="cuda") * (0.05 / (l + 1)))
+        return m.train()
+
+    x = torch.nn.functional.normalize(torch.randn(6000, 768, device="cuda"), dim=-1)
+    halves = [SeqBatch(None, None, None, x[:3000], None, None), SeqBatch(None, None, None, x[3000:], None, None)]
+    plain, attached = make(), make()
+    red = FlatGradReducer(attached.parameters()).attach(attached)
+    assert hasattr(attached, "_rq_cb_grad_sink")
+    for n_micro in (1, 2):
+        for p in plain.parameters():
+            p.grad = None
+        red.zero_()
+        for b in halves[:n_micro]:
+            plain(b, 0.2).loss.backward()
+            attached(b, 0.2).loss.backward()
+        base = red.flat.untyped_storage().data_ptr()
+        for (name, p), q, v in zip(attached.named_parameters(), plain.parameters(), red._views):
+            assert p.grad.untyped_storage().data_ptr() == base and p.grad.data_ptr() == v.data_ptr(), name
+            assert torch.equal(p.grad, q.grad), name
