@@ -13,7 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from modules.normalize import L2NormalizationLayer
-from rqhip import ops
+from rqhip import ops, torch_ops
 
 
 def _grad_sink(w: Tensor):
@@ -117,15 +117,17 @@ class MLP(nn.Module):
         if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
             return self.mlp(x)
         layers = list(self.mlp)
+        as_ops = torch_ops.enabled()   # registered torch.library operators instead of the autograd Functions
         i = 0
         while i < len(layers):
             layer = layers[i]
             if (isinstance(layer, nn.Linear) and layer.bias is None and i + 1 < len(layers)
                     and isinstance(layers[i + 1], nn.ReLU)):
-                x = _LinearReLU.apply(x, layer.weight, self._zero_bias(layer.out_features, x))
+                x = (torch.ops.rqhip.linear_relu(x, layer.weight) if as_ops
+                     else _LinearReLU.apply(x, layer.weight, self._zero_bias(layer.out_features, x)))
                 i += 2
             elif isinstance(layer, nn.Linear) and layer.bias is None:
-                x = _LinearPlain.apply(x, layer.weight)
+                x = torch.ops.rqhip.linear_plain(x, layer.weight) if as_ops else _LinearPlain.apply(x, layer.weight)
                 i += 1
             else:
                 x = layer(x)

@@ -3,6 +3,7 @@
 `QuantizeLoss` exists for API compatibility: inside Quantize/RqVae the same quantity is produced by the
 fused HIP kernel (csrc/rq_forward.hip) and its gradient by csrc/rq_backward.hip.  `ReconstructionLoss` is a fused
 HIP kernel too (csrc/recon_loss.hip); the categorical variant adds PyTorch-ROCm BCE on the trailing columns."""
+import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
@@ -15,6 +16,10 @@ class ReconstructionLoss(nn.Module):
 
     def forward(self, x_hat: Tensor, x: Tensor) -> Tensor:
         lead = x.shape[:-1]
+        from rqhip import torch_ops
+        if torch_ops.enabled():
+            out = torch.ops.rqhip.recon_loss(x_hat.reshape(-1, x_hat.shape[-1]), x.reshape(-1, x.shape[-1]))
+            return out.reshape(lead)
         out = ReconLossFunction.apply(x_hat.reshape(-1, x_hat.shape[-1]), x.reshape(-1, x.shape[-1]))
         return out.reshape(lead)
 

@@ -25,7 +25,7 @@ from modules.encoder import MLP
 from modules.loss import CategoricalReconstuctionLoss, ReconstructionLoss
 from modules.normalize import l2norm
 from modules.quantize import Quantize, QuantizeForwardMode
-from rqhip import ops
+from rqhip import ops, torch_ops
 from rqhip.autograd import LossMeansFunction, RqStackFunction
 
 # The reference sets "high" here (rqvae.py:19): on its CPU path that is plain fp32 (bit-identical to "highest",
@@ -130,6 +130,9 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
     def _quantize_stack(self, res: Tensor, gumbel_t: float, want_levels: bool) -> _StackResult:
         if self._can_fuse():
             codebooks = torch.stack([layer.codebook() for layer in self.layers])  # [L,K,D], autograd splits it back
+            if torch_ops.enabled():   # the same kernels as registered torch.library operators (traceable)
+                return _StackResult(*torch.ops.rqhip.rq_stack(res, codebooks, self.layers[0].hip_mode(),
+                                                              float(self.commitment_weight), want_levels))
             sink = getattr(self, "_rq_cb_grad_sink", None)
             if sink is not None and not all(layer.plain_codebook for layer in self.layers):
                 sink = None
@@ -177,11 +180,17 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         rqvae_loss = st.loss
         if reconstruction.dim() == 1 and reconstruction.is_cuda and reconstruction.dtype == torch.float32:
             # the three batch means of rqvae.py:154,171-172 in one launch
-            loss, recon_mean, rq_mean = LossMeansFunction.apply(reconstruction, rqvae_loss)
+            if torch_ops.enabled():
+                loss, recon_mean, rq_mean = torch.ops.rqhip.loss_means(reconstruction, rqvae_loss).unbind(0)
+            else:
+                loss, recon_mean, rq_mean = LossMeansFunction.apply(reconstruction, rqvae_loss)
         else:
             loss, recon_mean, rq_mean = (reconstruction + rqvae_loss).mean(), reconstruction.mean(), rqvae_loss.mean()
         with torch.no_grad():
-            _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
+            if torch_ops.enabled():
+                n_distinct = torch.ops.rqhip.distinct_tuples(st.ids, self.codebook_size)
+            else:
+                _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
             p_unique_ids = n_distinct / st.ids.shape[1]                   # rqvae.py:159-167
         return RqVaeComputedLosses(
             loss=loss,

@@ -1,0 +1,224 @@
+"""The hot-path ops as first-class PyTorch operators (`torch.ops.rqhip.*`), registered with `torch.library`.
+
+SURVEY.md section 7 / VERDICT r1 item 8: the autograd bridges of rqhip/autograd.py are `torch.autograd.Function`s around
+ctypes calls, which dynamo cannot look into.  Here every kernel entry point the RQ-VAE step uses is ALSO a
+`torch.library.custom_op` with a fake (shape) implementation and a registered autograd formula whose backward is itself
+an op, so that
+
+  * `torch.compile(model, backend="aot_eager", fullgraph=...)` and other tracers see opaque, schema-checked nodes
+    instead of graph breaks (no inductor / Triton is involved or needed: the ops ARE the kernels), and
+  * `torch.library.opcheck` can validate schema, fake tensors and autograd registration (tests/test_gpu_torch_ops.py).
+
+The direct Function path stays the default in eager mode: a custom_op call costs a few more microseconds of Python
+dispatch than the bare ctypes call, which matters at the reference's launch-bound batch sizes.  `enable()` (or
+RQHIP_TORCH_OPS=1) switches modules/rqvae.py and modules/encoder.py to the registered ops.
+
+Each op names the C entry point it wraps (include/rqhip.h); there is no arithmetic here.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+_ENABLED = os.environ.get("RQHIP_TORCH_OPS") == "1"
+
+
+def enable(on: bool = True) -> None:
+    global _ENABLED
+    _ENABLED = bool(on)
+
+
+def enabled() -> bool:
+    """True when the module mirrors should call torch.ops.rqhip.* (explicitly enabled, or while a compiler traces)."""
+    return _ENABLED or torch.compiler.is_compiling()
+
+
+# ---- residual-quantisation stack (rqhip_rq_forward / rqhip_rq_backward) ---------------------------------------------
+@torch.library.custom_op("rqhip::rq_stack", mutates_args=())
+def rq_stack(res0: Tensor, codebooks: Tensor, mode: int, beta: float, want_levels: bool) -> List[Tensor]:
+    out = ops.rq_forward(res0, codebooks, mode, beta, want_embs=want_levels, want_residuals=want_levels)
+    empty = res0.new_empty((0,))
+    return [out.embs if want_levels else empty, out.residuals if want_levels else empty.clone(), out.ids, out.loss,
+            out.emb_sum, out.embs_norm]
+
+
+@rq_stack.register_fake
+def _(res0, codebooks, mode, beta, want_levels):
+    B, D = res0.shape
+    L = codebooks.shape[0]
+    lvl = (L, B, D) if want_levels else (0,)
+    return [res0.new_empty(lvl), res0.new_empty(lvl), res0.new_empty((L, B), dtype=torch.int64), res0.new_empty((B,)),
+            res0.new_empty((B, D)), res0.new_empty((B, L))]
+
+
+@torch.library.custom_op("rqhip::rq_stack_backward", mutates_args=())
+def rq_stack_backward(res0: Tensor, codebooks: Tensor, ids: Tensor, mode: int, beta: float,
+                      g_embs: Optional[Tensor], g_resid: Optional[Tensor], g_loss: Optional[Tensor],
+                      g_embsum: Optional[Tensor]) -> List[Tensor]:
+    c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+    g_res0, g_cb = ops.rq_backward(res0, codebooks, mode, beta, ids, g_embs=c(g_embs), g_embsum=c(g_embsum),
+                                   g_resid=c(g_resid), g_loss=c(g_loss))
+    return [g_res0, g_cb]
+
+
+@rq_stack_backward.register_fake
+def _(res0, codebooks, ids, mode, beta, g_embs, g_resid, g_loss, g_embsum):
+    return [torch.empty_like(res0), torch.empty_like(codebooks)]
+
+
+def _rq_setup(ctx, inputs, output):
+    res0, codebooks, mode, beta, want_levels = inputs
+    ctx.save_for_backward(res0, codebooks, output[2])
+    ctx.mode, ctx.beta, ctx.want_levels = mode, beta, want_levels
+
+
+def _rq_backward(ctx, grads):
+    g_embs, g_resid, _g_ids, g_loss, g_embsum, _g_norm = grads
+    res0, codebooks, ids = ctx.saved_tensors
+    if not ctx.want_levels:
+        g_embs = g_resid = None
+    g_res0, g_cb = torch.ops.rqhip.rq_stack_backward(res0, codebooks, ids, ctx.mode, ctx.beta, g_embs, g_resid, g_loss,
+                                                     g_embsum)
+    return g_res0, g_cb, None, None, None
+
+
+rq_stack.register_autograd(_rq_backward, setup_context=_rq_setup)
+
+
+# ---- Linear(+ReLU) of the MLPs: library GEMM forward, hand-written weight gradient backward --------------------------
+@torch.library.custom_op("rqhip::linear_relu", mutates_args=())
+def linear_relu(x: Tensor, w: Tensor) -> Tensor:
+    return torch._addmm_activation(x.new_zeros((w.shape[0],)), x, w.t())
+
+
+@linear_relu.register_fake
+def _(x, w):
+    return x.new_empty((x.shape[0], w.shape[0]))
+
+
+@torch.library.custom_op("rqhip::linear_backward", mutates_args=())
+def linear_backward(gy: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, need_x: bool) -> List[Tensor]:
+    """(gx, gw) of y = relu(x w^T) (y given) or y = x w^T (y None): rqhip_linear_wgrad + one library GEMM."""
+    gy = gy.contiguous()
+    small_or_masked = y is not None or w.shape[0] * w.shape[1] <= 256 * 256
+    if small_or_masked and ops.linear_wgrad_supported(w.shape[0], w.shape[1]) and gy.shape[0] > 0:
+        gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x)
+    else:
+        g = gy if y is None else torch.ops.aten.threshold_backward(gy, y, 0.0)
+        gw = g.t().mm(x)
+    gx = g.mm(w) if need_x else gy.new_empty((0,))
+    return [gx, gw]
+
+
+@linear_backward.register_fake
+def _(gy, y, x, w, need_x):
+    return [torch.empty_like(x) if need_x else gy.new_empty((0,)), torch.empty_like(w)]
+
+
+def _lr_setup(ctx, inputs, output):
+    x, w = inputs
+    ctx.save_for_backward(x, w, output)
+
+
+def _lr_backward(ctx, gy):
+    x, w, y = ctx.saved_tensors
+    need_x = ctx.needs_input_grad[0]
+    gx, gw = torch.ops.rqhip.linear_backward(gy, y, x, w, need_x)
+    return (gx if need_x else None), gw
+
+
+linear_relu.register_autograd(_lr_backward, setup_context=_lr_setup)
+
+
+@torch.library.custom_op("rqhip::linear_plain", mutates_args=())
+def linear_plain(x: Tensor, w: Tensor) -> Tensor:
+    return x.mm(w.t())
+
+
+@linear_plain.register_fake
+def _(x, w):
+    return x.new_empty((x.shape[0], w.shape[0]))
+
+
+def _lp_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _lp_backward(ctx, gy):
+    x, w = ctx.saved_tensors
+    need_x = ctx.needs_input_grad[0]
+    gx, gw = torch.ops.rqhip.linear_backward(gy, None, x, w, need_x)
+    return (gx if need_x else None), gw
+
+
+linear_plain.register_autograd(_lp_backward, setup_context=_lp_setup)
+
+
+# ---- reconstruction loss, loss means, id statistics --------------------------------------------------------------------
+@torch.library.custom_op("rqhip::recon_loss", mutates_args=())
+def recon_loss(x_hat: Tensor, x: Tensor) -> Tensor:
+    return ops.recon_loss_forward(x_hat, x)
+
+
+@recon_loss.register_fake
+def _(x_hat, x):
+    return x.new_empty((x.shape[0],))
+
+
+@torch.library.custom_op("rqhip::recon_loss_backward", mutates_args=())
+def recon_loss_backward(x_hat: Tensor, x: Tensor, g_out: Tensor) -> Tensor:
+    return ops.recon_loss_backward(x_hat, x, g_out.contiguous(), True, False)[0]
+
+
+@recon_loss_backward.register_fake
+def _(x_hat, x, g_out):
+    return x_hat.new_empty(tuple(x_hat.shape))
+
+
+def _rl_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _rl_backward(ctx, g_out):
+    x_hat, x = ctx.saved_tensors
+    return torch.ops.rqhip.recon_loss_backward(x_hat, x, g_out), None
+
+
+recon_loss.register_autograd(_rl_backward, setup_context=_rl_setup)
+
+
+@torch.library.custom_op("rqhip::loss_means", mutates_args=())
+def loss_means(recon: Tensor, quant: Tensor) -> Tensor:
+    return ops.loss_means(recon, quant)
+
+
+@loss_means.register_fake
+def _(recon, quant):
+    return recon.new_empty((3,))
+
+
+def _lm_setup(ctx, inputs, output):
+    ctx.n = inputs[0].numel()
+
+
+def _lm_backward(ctx, g):   # g [3]: wrt mean(recon + quant), mean(recon), mean(quant)
+    return ((g[0] + g[1]) / ctx.n).expand(ctx.n), ((g[0] + g[2]) / ctx.n).expand(ctx.n)
+
+
+loss_means.register_autograd(_lm_backward, setup_context=_lm_setup)
+
+
+@torch.library.custom_op("rqhip::distinct_tuples", mutates_args=())
+def distinct_tuples(ids: Tensor, codebook_size: int) -> Tensor:
+    """Number of distinct id tuples of ids [L,B] (rqhip_dedup_rank without the rank output)."""
+    return ops.dedup_rank(ids, codebook_size, want_rank=False)[1]
+
+
+@distinct_tuples.register_fake
+def _(ids, codebook_size):
+    return ids.new_empty(())
