@@ -176,7 +176,8 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         n = self.n_cat_feats
         # rqvae.py:147-150: with n == 0 the `[..., :-0]` slice is EMPTY, so nothing is normalised
         x_hat = torch.cat([l2norm(x_hat[..., :-n]), x_hat[..., -n:]], dim=-1) if n != 0 else x_hat
-        reconstruction = self.reconstruction_loss(x_hat, x)
+        # (the kernels are fp32: a float64 / fp16 batch is compared in the model's dtype, as it was encoded)
+        reconstruction = self.reconstruction_loss(x_hat, x if x.dtype == x_hat.dtype else x.to(x_hat.dtype))
         rqvae_loss = st.loss
         if reconstruction.dim() == 1 and reconstruction.is_cuda and reconstruction.dtype == torch.float32:
             # the three batch means of rqvae.py:154,171-172 in one launch
