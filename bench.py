@@ -125,9 +125,10 @@ def cpu_baseline(batch_rows, levels, codes, budget_s=24.0):
     x640 = x[:640].contiguous()
     r640 = torch_port.time_training_steps(x640, steps=max(5, int(per / 0.05)) if per < 3 else 60, warmup=2, **kw)
     torch.set_num_threads(cores)
-    return {"value": round(r["items_per_s"], 1), "unit": "items/s", "cores": cores, "threads_used": t, "kind": "port",
+    return {"value": round(r["items_per_s"], 1), "unit": "items/s", "cores": t, "host_hardware_threads": cores, "kind": "port",
             "sample": f"{r['steps']} fwd+bwd+AdamW steps of {batch_rows} rows ({r['seconds']:.1f} s) at the best of "
-                      f"{cand} threads; torch-CPU port of the reference program (oracle/torch_port.py), same model shape",
+                      f"{cand} threads (`cores` = the thread count that won); torch-CPU port of the reference program "
+                      f"(oracle/torch_port.py), same model shape",
             "threads_sweep_items_per_s": sweep,
             "batch640_items_per_s": round(r640["items_per_s"], 1),
             "note": "the reference's own modules on the 8-vCPU build container: BASELINE.md section 2 "
