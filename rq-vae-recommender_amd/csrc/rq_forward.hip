@@ -812,12 +812,15 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     if (all_coop) want = p.n_tiles;
     const int grid = (int)(want < cap ? want : cap);
     const long long total_waves = (long long)grid * waves_per_wg;
-    // a partly filled last round (53 of 3125 tiles at 100 000 rows) puts a whole extra tile on one SIMD of each CU it
-    // lands on; when it is at most one tile per workgroup it is done cooperatively instead, a quarter per SIMD
+    // A partly filled last round (53 of 3125 tiles at 100 000 rows) puts a whole extra tile on one SIMD of each CU it
+    // lands on; when it is at most one tile per workgroup it is done cooperatively instead, a quarter per SIMD.  Rounds
+    // are counted per SIMD (4 per CU: waves are enumerated wave-major, four consecutive waves of a workgroup sit on its
+    // four SIMDs), not per wave slot: at D = 64 (8 waves per workgroup) 3125 tiles are 3 x 1024 + 53, and the 53 used to
+    // run as ordinary tiles of a fourth SIMD round on 53 CUs.
     p.coop_first = all_coop ? 0 : p.n_tiles;
     static const bool coop_tail = getenv("RQ_NO_COOP_TAIL") == nullptr;  // developer A/B switch, read once
     if (!all_coop && p.resident && coop_tail) {
-        const long long rem = p.n_tiles % total_waves;
+        const long long rem = p.n_tiles % ((long long)grid * 4);
         if (rem > 0 && rem <= grid) p.coop_first = p.n_tiles - rem;
     }
     p.n_iter = (int)((p.coop_first + total_waves - 1) / total_waves);
