@@ -376,7 +376,7 @@ def gen_config3_step(q, r, km, sch):
     for k, v in model.named_parameters():
         compact("grad", k, v.grad)
         compact("delta", k, v.detach() - before[k])
-    np.savez_compressed(os.path.join(OUT, "rqvae_c3_step.npz"), **save)
+    np.savez_compressed(os.path.join(OUT, "config3_step.npz"), **save)
 
 
 def main():

@@ -326,12 +326,12 @@ def test_row_sharded_training_step_equals_full_batch_step():
 def test_config3_real_shape_training_step_matches_reference():
     """BASELINE configuration 3 at its real shape (rqvae_ml32m.gin: D = 64, rotation trick, batch 64, AdamW 1e-4 / 0.01):
     one full training step -- forward, backward, optimizer update -- against the reference's own step
-    (tests/golden/rqvae_c3_step.npz, oracle/gen_golden.py:gen_config3_step)."""
+    (tests/golden/config3_step.npz, oracle/gen_golden.py:gen_config3_step)."""
     import hashlib
     from data.schemas import SeqBatch
     from modules.quantize import QuantizeForwardMode
     from modules.rqvae import RqVae
-    g = load_golden("rqvae_c3_step.npz")
+    g = load_golden("config3_step.npz")
     torch.manual_seed(0)
     m = RqVae(input_dim=768, embed_dim=64, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
               n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.ROTATION_TRICK,
