@@ -226,3 +226,31 @@ def test_item_data_refuses_to_invent_a_corpus(tmp_path, monkeypatch, capsys):
     ds = ItemData(root=str(tmp_path / "dataset" / "amazon"))
     assert ds.synthetic and len(ds) == 40
     assert "SYNTHETIC" in capsys.readouterr().out
+
+
+def test_bench_relaunches_itself_under_torchrun_for_multi_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside a torchrun environment must start its own N ranks."""
+    import importlib
+    import os
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--config", "c4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit:
+        pass
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    assert a[-6:] == ["--gpus", "4", "--config", "c4", "--steps", "2"] and a[-7].endswith("bench.py")
+    # and inside a torchrun environment it does not relaunch: the world size must simply match --gpus
+    assert bench.CONFIGS["c4"]["rows"] == 1_250_000 and bench.CONFIGS["c4"]["codes"] == 1024
