@@ -12,7 +12,7 @@
 // (D == 32, K <= 256) and batches of >= 4096 rows the entry points below hand over to gumbel_mfma.hip.
 //
 // Limits: D <= 128 and the LDS footprint below must fit 160 KiB (K*D <= ~16k floats for backward);
-// otherwise RQHIP_EUNSUPPORTED.  Transcendentals (logf/expf) differ from glibc's in the last ulp: results
+// otherwise RQHIP_EUNSUPPORTED.  Transcendentals are the hardware v_log_f32 / v_exp_f32 (gumbel_mfma.h): results
 // match the oracle to ~1e-6 relative, not bit for bit; ids (noise-free argmin) are exact.
 #include "gumbel_mfma.h"
 #include "rqhip_common.h"
@@ -61,6 +61,7 @@ template <bool BACKWARD, bool REGACC>
 __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D, K = p.K, Kpad = p.Kpad, KS = K + 1;
+    const float inv_t = 1.0f / p.temperature;
     float *Ct = sm;
     float *csq = Ct + (size_t)D * KS;
     float *wave_base = csq + Kpad;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
                 float yy = -__builtin_inff();
                 if (k < K) {
                     const float u = p.U[(size_t)row * K + k];
-                    const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);
-                    yy = ((-dist[g]) + gn) / p.temperature;
+                    const float gn = gm_gumbel(u);
+                    yy = ((-dist[g]) + gn) * inv_t;
                 }
                 y[g] = yy;
                 mx = fmaxf(mx, yy);
@@ -165,16 +166,17 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
         for (int g = 0; g < kGMaxPerLane; ++g) {
             if (g < per_lane) {
                 const int k = lane + 64 * g;
-                const float ev = (k < K) ? expf(y[g] - mx) : 0.0f;
+                const float ev = (k < K) ? gm_exp(y[g] - mx) : 0.0f;
                 y[g] = ev;
                 zs = zs + ev;
             }
         }
         const float Z = wave_sum(zs);
+        const float rz = 1.0f / Z;
 #pragma unroll
         for (int g = 0; g < kGMaxPerLane; ++g) {
             if (g < per_lane) {
-                y[g] = y[g] / Z;  // weights
+                y[g] = y[g] * rz;  // weights
                 ws[lane + 64 * g] = y[g];
             }
         }
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(kGThreads) void gumbel_kernel(const GumbelParams p)
             for (int g = 0; g < kGMaxPerLane; ++g) {
                 if (g < per_lane) {
                     const int k = lane + 64 * g;
-                    const float dy = (y[g] * (dw[g] - sw)) / p.temperature;
+                    const float dy = (y[g] * (dw[g] - sw)) * inv_t;
                     const float ddk = (k < K) ? -dy : 0.0f;
                     dw[g] = ddk;
                     dds[k] = ddk;

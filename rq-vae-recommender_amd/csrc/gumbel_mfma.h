@@ -24,4 +24,21 @@ int gumbel_mfma_backward(const GumbelMfmaParams &p, hipStream_t s);
 // the chip with 32-row tiles); RQ_GUMBEL_MFMA_MIN_ROWS overrides (developer / test switch)
 long long gumbel_mfma_min_rows();
 
+#ifdef __HIPCC__
+// Softmax arithmetic of both Gumbel kernels (~150 -> ~50 VALU instructions per (row, code)):
+//   * both logarithms of the Gumbel noise and the softmax exponential are the hardware v_log_f32 / v_exp_f32.  Measured
+//     on MI355X over the whole 2^24-point grid of torch.rand (tools/log_probe.hip): t = -log(u) to 1.6e-7 relative
+//     (also for u -> 1, where a sloppy inner log would be amplified by the outer one), the Gumbel value to 1.7e-6
+//     absolute (|g| <= 17), exp to ~1e-7 relative above the denormal range (denormal results flush to 0);
+//   * the divisions by the temperature and by the softmax sum are multiplications by one IEEE reciprocal per call /
+//     per row.
+// Results differ from the oracle's libm / division chain by a few 1e-7 relative (tests: rtol 2e-4 forward, 2e-3
+// backward); ids come from the noise-free distances and are not affected.
+__device__ __forceinline__ float gm_gumbel(float u) {   // -log(-log(u + 1e-20) + 1e-20), gumbel.py:10-11
+    const float t = -(__builtin_amdgcn_logf(u + 1e-20f) * 0.69314718055994530942f);
+    return -(__builtin_amdgcn_logf(t + 1e-20f) * 0.69314718055994530942f);
+}
+__device__ __forceinline__ float gm_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+#endif
+
 }  // namespace rqhip

@@ -26,6 +26,9 @@
 
 namespace rqhip {
 
+
+
+
 typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_forward_kernel(const G
     constexpr int K = NT * 32;
     const float *imgA = sm, *csq = sm + (size_t)K * 32, *crow = csq + K;
     gm_stage(sm, p.cb, K);
+    const float inv_t = 1.0f / p.temperature;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int il = lane & 31, h = lane >> 5;
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_forward_kernel(const G
                 if (dv != dv) nanidx = min(nanidx, code);
                 else if (dv < lbest) { lbest = dv; lidx = code; }  // codes ascend with (t, j): first minimum kept
                 const float u = u4[j >> 2][j & 3];
-                const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);  // gumbel.py:10-11
-                const float yy = ((-dv) + gn) / p.temperature;       // gumbel.py:18
+                const float gn = gm_gumbel(u);                       // gumbel.py:10-11
+                const float yy = ((-dv) + gn) * inv_t;               // gumbel.py:18
                 y[t][j] = yy;
                 mx = fmaxf(mx, yy);
             }
@@ -145,11 +149,12 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_forward_kernel(const G
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float ev = expf(y[t][j] - mx);
+                const float ev = gm_exp(y[t][j] - mx);
                 y[t][j] = ev;
                 zs = zs + ev;
             }
         const float Z = zs + shfl_xor32(zs);
+        const float rz = 1.0f / Z;
 
         // emb = w @ C: reduction over the codes, two per instruction (k = 0: this lane half's code, k = 1: the
         // other half's), 16 x NT instructions; A = C[code][d = lane & 31]
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_forward_kernel(const G
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int code = 32 * t + 8 * (j >> 2) + 4 * h + (j & 3);
-                const float wv = y[t][j] / Z;  // softmax weight (gumbel.py:19)
+                const float wv = y[t][j] * rz;  // softmax weight (gumbel.py:19)
                 y[t][j] = wv;
                 eacc = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[(size_t)code * 33 + il], wv, eacc, 0, 0, 0);
             }
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_backward_kernel(const 
     float *imgA = sm;
     const float *csq = sm + (size_t)K * 32, *crow = csq + K;
     gm_stage(sm, p.cb, K);
+    const float inv_t = 1.0f / p.temperature;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int il = lane & 31, h = lane >> 5;
@@ -254,8 +260,8 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_backward_kernel(const 
                 const int code = 32 * t + 8 * (j >> 2) + 4 * h + (j & 3);
                 const float dv = (xsq + csq[code]) - 2.0f * acc[j];
                 const float u = u4[j >> 2][j & 3];
-                const float gn = -logf(-logf(u + 1e-20f) + 1e-20f);
-                const float yy = ((-dv) + gn) / p.temperature;
+                const float gn = gm_gumbel(u);
+                const float yy = ((-dv) + gn) * inv_t;
                 w[t][j] = yy;
                 mx = fmaxf(mx, yy);
             }
@@ -266,18 +272,19 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_backward_kernel(const 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float ev = expf(w[t][j] - mx);
+                const float ev = gm_exp(w[t][j] - mx);
                 w[t][j] = ev;
                 zs = zs + ev;
             }
         const float Z = zs + shfl_xor32(zs);
+        const float rz = 1.0f / Z;
         gm_f32x16 eacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int code = 32 * t + 8 * (j >> 2) + 4 * h + (j & 3);
-                const float wv = w[t][j] / Z;
+                const float wv = w[t][j] * rz;
                 w[t][j] = wv;
                 eacc = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[(size_t)code * 33 + il], wv, eacc, 0, 0, 0);
             }
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(kGmThreads) void gumbel_mfma_backward_kernel(const 
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int cit = 8 * (j >> 2) + 4 * h + (j & 3);
-                const float dy = (w[t][j] * (dacc[j] - sw)) / p.temperature;
+                const float dy = (w[t][j] * (dacc[j] - sw)) * inv_t;
                 const float ddk = -dy;
                 sddl = sddl + ddk;
                 gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[(size_t)(32 * t + cit) * 33 + il], ddk, gacc, 0, 0, 0);
