@@ -87,3 +87,25 @@ if __name__ == "__main__":
             bwd(a.reps)
         if a.what in ("kmeans", "all"):
             kmeans(a.reps)
+
+# tie-margin variant of the forward kernel (tokenisation with flags): what the runner-up tournament costs
+if True:
+    import torch as _t
+    from rqhip import ops as _ops
+    _g = _t.Generator().manual_seed(0)
+    _x = (_t.randn(100_000, 32, generator=_g) * 0.5).cuda()
+    _cb = (_t.randn(3, 256, 32, generator=_g) * 0.3).cuda()
+
+    def _time(fn, n=20):
+        for _ in range(3):
+            fn()
+        a, b = _t.cuda.Event(enable_timing=True), _t.cuda.Event(enable_timing=True)
+        _t.cuda.synchronize(); a.record()
+        for _ in range(n):
+            fn()
+        b.record(); _t.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+
+    t0 = _time(lambda: _ops.rq_forward(_x, _cb, 0, 0.25, want_embs=False, want_residuals=False))
+    t1 = _time(lambda: _ops.rq_forward(_x, _cb, 0, 0.25, want_embs=False, want_residuals=False, want_margin=True))
+    print(f"fwd eval B=100000 3x256: call {t0:.1f} us plain, {t1:.1f} us with tie_margin (+{(t1 / t0 - 1) * 100:.0f} %)")
