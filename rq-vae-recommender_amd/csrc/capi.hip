@@ -31,6 +31,20 @@ int cu_count() {
 }
 
 
+__global__ void fill_words_kernel(uint32_t *dst, uint32_t word, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = word;
+}
+
+int fill_words(void *dst, uint32_t word, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / 4;
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t *>(dst), word, n);
+    RQ_CHECK_LAUNCH("fill_words_kernel");
+    return 0;
+}
+
 static hipEvent_t *g_ev = nullptr;   // 2 * g_cap events
 static int g_cap = 0, g_n = 0;
 static bool g_open = false;

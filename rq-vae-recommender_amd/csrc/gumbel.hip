@@ -419,7 +419,7 @@ extern "C" int rqhip_gumbel_backward(const float *x, int64_t B, int D, const flo
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (B == 0) {
-        RQ_RETURN_IF_HIP(hipMemsetAsync(g_codebook, 0, sizeof(float) * (size_t)K * D, s));
+        if (int rc = fill_words(g_codebook, 0u, sizeof(float) * (size_t)K * D, s)) return rc;
         return RQHIP_OK;
     }
     const bool mfma = B >= gumbel_mfma_min_rows() && gumbel_mfma_supported(D, K, x, U, g_emb, g_x) &&

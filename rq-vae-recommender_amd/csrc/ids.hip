@@ -241,7 +241,7 @@ extern "C" int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int
     unsigned *vals1 = reinterpret_cast<unsigned *>(ws + lay.off_vals1);
     unsigned *hist = reinterpret_cast<unsigned *>(ws + lay.off_hist);
 
-    RQ_RETURN_IF_HIP(hipMemsetAsync(count, 0, 8, s));
+    if (int rc = fill_words(count, 0u, 8, s)) return rc;
     if (B == 0) {
         if (n_distinct) {
             hipLaunchKernelGGL(ids_store_count_kernel, dim3(1), dim3(1), 0, s, count, n_distinct);
@@ -249,7 +249,7 @@ extern "C" int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int
         }
         return RQHIP_OK;
     }
-    RQ_RETURN_IF_HIP(hipMemsetAsync(table, 0xff, lay.table_slots * 4, s));
+    if (int rc = fill_words(table, 0xffffffffu, lay.table_slots * 4, s)) return rc;
     const int tb = 256;
     const int gb = (int)((B + tb - 1) / tb);
     hipLaunchKernelGGL(ids_group_kernel, dim3(gb), dim3(tb), 0, s, ids, (long long)B, L, table,

@@ -311,7 +311,8 @@ extern "C" int rqhip_kmeans_update(const float *x, int64_t B, int D, const int64
         return RQHIP_EUNSUPPORTED;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (shift_sq_max) RQ_RETURN_IF_HIP(hipMemsetAsync(shift_sq_max, 0, sizeof(float), s));
+    if (shift_sq_max)
+        if (int rc = fill_words(shift_sq_max, 0u, sizeof(float), s)) return rc;
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(K), dim3(64), 0, s, x, (long long)B, D, assign, K, centroids,
                        counts, reinterpret_cast<unsigned int *>(shift_sq_max), (const int *)nullptr, (float *)nullptr);
     RQ_CHECK_LAUNCH("kmeans_update_kernel");

@@ -496,7 +496,7 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool lds_path = scatter_fits_lds(D, K);
     if (g_codebooks && (B == 0 || !lds_path))
-        RQ_RETURN_IF_HIP(hipMemsetAsync(g_codebooks, 0, sizeof(float) * (size_t)L * K * D, s));
+        if (int rc = fill_words(g_codebooks, 0u, sizeof(float) * (size_t)L * K * D, s)) return rc;
     if (B == 0) return RQHIP_OK;
     RqBwdParams p;
     p.res0 = res0; p.cb = codebooks; p.ids = ids; p.g_embs = g_embs; p.g_embsum = g_embsum;

@@ -61,6 +61,12 @@ struct LdsGrant {
 void profile_begin(hipStream_t s);
 void profile_end(hipStream_t s);
 
+// Fill `bytes` (a multiple of 4) at `dst` (4-byte aligned) with the 32-bit pattern `word`, as a KERNEL on stream s.
+// Used instead of hipMemsetAsync everywhere in the library: memset nodes captured into a hipGraph broke replay
+// (hang / memory access fault after a few hundred replays interleaved with eager launches, ROCm 7.0 runtime of
+// torch 2.10; tools/graph_piece_probe.py), kernel nodes do not.
+int fill_words(void *dst, uint32_t word, size_t bytes, hipStream_t s);
+
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ int shfl_xor32(int v) { return __shfl_xor(v, 32, 64); }
 

@@ -152,7 +152,7 @@ extern "C" int rqhip_prefix_index_build(const int64_t *corpus, int64_t N, int H,
         return RQHIP_EWORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    RQ_RETURN_IF_HIP(hipMemsetAsync(index, 0xff, need, s));
+    if (int rc = fill_words(index, 0xffffffffu, need, s)) return rc;
     if (N == 0) return RQHIP_OK;
     const int tb = 256;
     hipLaunchKernelGGL(prefix_build_kernel, dim3((unsigned)((N + tb - 1) / tb)), dim3(tb), 0, s, corpus, (long long)N,
@@ -200,7 +200,7 @@ extern "C" int rqhip_topk_first_match(const int64_t *actual, const int64_t *top_
     }
     if (B == 0) return RQHIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    RQ_RETURN_IF_HIP(hipMemsetAsync(rank, 0xff, (size_t)B * sizeof(int64_t), s));
+    if (int rc = fill_words(rank, 0xffffffffu, (size_t)B * sizeof(int64_t), s)) return rc;
     if (K == 0) return RQHIP_OK;
     const long long total = (long long)B * K;
     if (total >= (1ll << 40)) {

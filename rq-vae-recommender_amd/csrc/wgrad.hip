@@ -315,7 +315,7 @@ extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) {
-        RQ_RETURN_IF_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), s));
+        if (int rc = fill_words(dW, 0u, (size_t)N * K * sizeof(float), s)) return rc;
         return RQHIP_OK;
     }
     const WgradPlan pl = wgrad_plan(M, N, K);

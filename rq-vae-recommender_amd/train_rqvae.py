@@ -125,18 +125,20 @@ class _GraphedStep:
         capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
         import copy
         self.x.copy_(x)
-        params = [p.detach().clone() for p in self._model.parameters()]
-        opt_state = copy.deepcopy(self._opt.state_dict())
+        rollback = os.environ.get("RQ_GRAPH_NO_ROLLBACK") != "1"   # developer switch
+        params = [p.detach().clone() for p in self._model.parameters()] if rollback else []
+        opt_state = copy.deepcopy(self._opt.state_dict()) if rollback else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
             for _ in range(2):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for p, saved in zip(self._model.parameters(), params):
-                p.copy_(saved)
-        self._opt.load_state_dict(opt_state)
+        if rollback:
+            with torch.no_grad():
+                for p, saved in zip(self._model.parameters(), params):
+                    p.copy_(saved)
+            self._opt.load_state_dict(opt_state)
         self._reducer.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -147,7 +149,8 @@ class _GraphedStep:
         del out
 
     def run(self, x: torch.Tensor):
-        self.x.copy_(x)
+        if os.environ.get("RQ_GRAPH_FIXED_BATCH") != "1":   # developer switch: replay on the captured batch
+            self.x.copy_(x)
         self.graph.replay()
         return self.out
 
@@ -269,7 +272,7 @@ def train(
             # Lloyd iterations all-reduce the [K, D+1] sums || counts (init/kmeans.py): every rank
             # ends with the same codebooks -- unlike the reference, whose ranks would each seed their own
             import init.kmeans as _km
-            n_warm = min(20000, len(train_dataset))
+            n_warm = min(int(os.environ.get("RQ_WARM_ROWS", "20000")), len(train_dataset))
             lo, hi = rqdist.shard_bounds(n_warm)
             _km.SHARDED_INIT = world > 1
             try:

@@ -72,3 +72,16 @@ def test_hip_graph_step_matches_eager(tmp_path, monkeypatch):
                       do_eval=True, log_every=1, use_hip_graph=flag, batch_size=500)
         runs.append(res)
     assert abs(runs[0]["loss"] - runs[1]["loss"]) < 2e-3 * max(1.0, abs(runs[0]["loss"])), runs
+
+
+def test_hip_graph_survives_hundreds_of_replays_interleaved_with_eager_work(tmp_path, monkeypatch):
+    """Round-2 defect: the graph mode faulted after ~250 iterations.  Cause: hipMemsetAsync calls of the library (the id
+    statistics) became memset NODES of the captured graph, and those broke replay once eager launches were interleaved
+    (tools/graph_piece_probe.py); every memset is now a kernel (csrc/capi.hip:fill_words).  600 graphed iterations of
+    the config-3 loop, eager gathers and copies between all of them."""
+    import numpy as np
+    torch.manual_seed(3)
+    np.random.seed(3)
+    res, _ = _run("rqvae_ml32m.gin", tmp_path, monkeypatch, iterations=600, eval_every=600, save_model_every=10 ** 6,
+                  log_every=200, use_hip_graph=True)
+    assert res["loss"] == res["loss"] and res["loss"] < 5.0

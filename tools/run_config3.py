@@ -12,12 +12,12 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")]
 os.environ.setdefault("RQ_SYNTH_ITEMS", "87585")
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import train_rqvae  # noqa: E402
-from rqhip import ginlite  # noqa: E402
-
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+if os.environ.get("RQ_C3_MODE"):   # (the parent process stays light: no torch, no GPU context)
+    import numpy as np  # noqa: E402
+    import torch  # noqa: E402
+    import train_rqvae  # noqa: E402
+    from rqhip import ginlite  # noqa: E402
 def run(graph: bool) -> None:
     ginlite.clear_config()
     ginlite.parse_config_file(os.path.join(ROOT, "rq-vae-recommender_amd", "configs", "rqvae_ml32m.gin"))
