@@ -16,7 +16,7 @@ What is MI355X-native about it:
   * the progress-bar losses are read back every `log_every` steps instead of three `.cpu().item()` syncs
     per step (train_rqvae.py:197-199);
   * at the reference's batch sizes (640 / 64 rows) a step is ~45 kernel launches of a few microseconds each, i.e.
-    launch-bound: with `use_hip_graph=True` (EXPERIMENTAL, off by default, single GPU) the whole step (forward,
+    launch-bound: with `use_hip_graph=True` (off in the signature, ON in the shipped gin configs; single GPU) the whole step (forward,
     HIP quantisation kernels, backward, fused AdamW) is captured into a hipGraph and replayed on full-size batches
     (0.99 -> 0.38 ms per step at batch 640 on MI355X in tools/bench_small_batch.py); epoch-tail batches are
     skipped, and the graph is re-captured after every eval / tokenisation / checkpoint excursion because replaying
@@ -283,10 +283,13 @@ def train(
         data = next(train_batches) if gradient_accumulate_every == 1 else None
         if graphed is not None and it >= graph_after:
             if len(train_dataset) < batch_size:
-                raise ValueError(f"use_hip_graph needs full batches: the training split has {len(train_dataset)} rows, "
-                                 f"batch_size is {batch_size}")
-            while data.x.shape[0] != batch_size:   # graph mode trains on full batches only: epoch tails are skipped
-                data = next(train_batches)
+                # no full batch exists: the graphed step (static batch shape) cannot be used -- train eagerly
+                print(f"use_hip_graph: the training split has {len(train_dataset)} rows < batch_size {batch_size}; "
+                      "falling back to the eager step")
+                graphed = None
+            else:
+                while data.x.shape[0] != batch_size:   # graph mode trains on full batches only: epoch tails are skipped
+                    data = next(train_batches)
         if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
             if graphed.graph is None:
                 graphed.capture(data.x)
