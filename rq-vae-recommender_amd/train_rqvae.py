@@ -19,8 +19,9 @@ What is MI355X-native about it:
     launch-bound: with `use_hip_graph=True` (off in the signature, ON in the shipped gin configs; single GPU) the whole step (forward,
     HIP quantisation kernels, backward, fused AdamW) is captured into a hipGraph and replayed on full-size batches
     (0.99 -> 0.38 ms per step at batch 640 on MI355X in tools/bench_small_batch.py); epoch-tail batches are
-    skipped, and the graph is re-captured after every eval / tokenisation / checkpoint excursion because replaying
-    across eager GEMMs of new shapes faulted (rocBLAS moves its workspace) -- hence opt-in.
+    skipped, and the graph is re-captured after every eval / tokenisation / checkpoint excursion (a precaution kept
+    from round 1; the faults seen then came from memset nodes in the captured graph, since replaced by kernels --
+    DESIGN.md section 8).
 wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
 """
 import os
