@@ -222,6 +222,7 @@ def main():
     os.dup2(2, 1)
 
     from rqhip import dist as rqdist
+    from rqhip import autograd as rq_autograd
     from rqhip import ops, tuning
     from data.schemas import SeqBatch
 
@@ -253,8 +254,10 @@ def main():
     def step():
         reducer.zero_()
         for b in batches:
-            out = model(b, gumbel_t=0.2)
-            (out.loss if n_micro == 1 else out.loss * (b.x.shape[0] / B)).backward()
+            share = b.x.shape[0] / B            # this micro-batch's share of the step's mean loss
+            with rq_autograd.loss_scale(share):  # (hint for the speculative reconstruction-loss gradient)
+                out = model(b, gumbel_t=0.2)
+            (out.loss if n_micro == 1 else out.loss * share).backward()
         reducer.allreduce_mean()
         opt.step()
         return out

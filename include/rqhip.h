@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 200 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin */
+#define RQHIP_VERSION 201 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin */
 
 #define RQHIP_OK 0
 #define RQHIP_EARG (-1)         /* bad pointer / size / mode */
@@ -93,15 +93,16 @@ int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks
  *     g_embs [L,B,D] wrt embs, g_embsum [B,D] wrt emb_sum, g_resid [L,B,D] wrt residuals,
  *     g_loss [B] wrt loss
  *   outputs: g_res0 [B,D] (may be NULL; exact per-row arithmetic), g_codebooks [L,K,D] (may be NULL; OVERWRITTEN).
- *     For D <= 32, L <= 4 (rqhip_rq_backward_plan returns 1) the rows of a code are summed in a FIXED order -- no
- *     atomics; bit-reproducible and restated by the oracle.  Other shapes scatter with LDS float atomics: the sum
- *     order is then not fixed and g_codebooks is reproducible to fp32 rounding only.
+ *     For L <= 4 and either D <= 32 or (EVAL / STE, D % 4 == 0, D <= 64) -- rqhip_rq_backward_plan returns 1 -- the rows
+ *     of a code are summed in a FIXED order: no atomics, bit-reproducible, restated by the oracle.  Other shapes scatter
+ *     with LDS float atomics: the sum order is then not fixed and g_codebooks is reproducible to fp32 rounding only.
  *   workspace: rqhip_rq_backward_workspace_bytes(B,D,L,K) bytes
  */
 size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K);
-/* 1 when the fixed-order fused kernel is used; then *n_wg / *waves_per_wg give its launch geometry (the summation
- * order is a function of them: oracle/rq_oracle.c:rqo_rq_backward_ordered) */
-int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int *n_wg, int *waves_per_wg);
+/* 1 when a fixed-order kernel is used (tensors 16-byte aligned, as torch allocates them); then *n_wg, *units_per_wg
+ * and *unit_rows give the geometry the summation order is a function of (workgroup b takes the unit_rows-row units
+ * (round * units_per_wg + j) * n_wg + b in ascending order: oracle/rq_oracle.c:rqo_rq_backward_ordered) */
+int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int mode, int *n_wg, int *units_per_wg, int *unit_rows);
 int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                       int mode, float beta, const int64_t *ids, const float *g_embs,
                       const float *g_embsum, const float *g_resid, const float *g_loss,
@@ -232,6 +233,12 @@ int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat, const flo
 /* The three batch means of RqVae.forward (modules/rqvae.py:154,171-172) in one launch:
  *   out3[0] = mean(recon + quant), out3[1] = mean(recon), out3[2] = mean(quant);  recon, quant [B] fp32, B >= 1. */
 int rqhip_loss_means(const float *recon, const float *quant, int64_t B, float *out3, rqhip_stream_t stream);
+/* Its backward (autograd of the three `.mean()`s): g_loss, g_recon_mean, g_quant_mean are device scalars (gradients wrt
+ * out3[0..2]; each may be NULL = no gradient).  rows_recon[i] = (g_loss + g_recon_mean) * (1/B) and
+ * rows_quant[i] = (g_loss + g_quant_mean) * (1/B) for every i < B, 1/B rounded to fp32 first as PyTorch's mean backward
+ * does on the device (either output may be NULL). */
+int rqhip_loss_means_backward(const float *g_loss, const float *g_recon_mean, const float *g_quant_mean, int64_t B,
+                              float *rows_recon, float *rows_quant, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of a bias-free Linear(+ReLU) layer with the ReLU backward fused in (SURVEY.md section 8 row f2;

@@ -247,16 +247,18 @@ int rqo_rq_backward(const float *res0, int64_t B, int D, const float *codebooks,
 }
 
 /* Same gradients, but the codebook gradient is accumulated in the FIXED order of csrc/rq_backward.hip's fused
- * kernel, so that the GPU result can be compared bit for bit (the kernel has no atomics: inside a workgroup every
- * code is owned by one wave, which adds the rows in order):
- *   workgroup b of n_wg, wave j of nw, round it  ->  32-row tile  (it * nw + j) * n_wg + b;
- *   partial_b[l][id] += V_l(row)   for it ascending, j ascending, rows of the tile ascending   (fp32 adds from 0);
+ * kernels, so that the GPU result can be compared bit for bit (the kernels have no atomics: inside a workgroup every
+ * code is owned by one wave, which adds the rows in order).  The geometry comes from rqhip_rq_backward_plan:
+ *   workgroup b of n_wg, unit j of nw, round it  ->  unit_rows-row unit  (it * nw + j) * n_wg + b
+ *   (pair-layout kernel: a unit is one wave's 32-row tile, nw = 8; flat EVAL/STE kernel: a unit is the workgroup's whole
+ *   round of 1024 / (D/4) rows, nw = 1);
+ *   partial_b[l][id] += V_l(row)   for it ascending, j ascending, rows of the unit ascending   (fp32 adds from 0);
  *   g_codebooks = (s0 + s1) + (s2 + s3),  s_q = 0 + partial_q + partial_{q+4} + ...   (rq_cbgrad_reduce_kernel). */
 int rqo_rq_backward_ordered(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                             int mode, float beta, const int64_t *ids, const float *g_embs,
                             const float *g_embsum, const float *g_resid, const float *g_loss,
-                            float *g_res0, float *g_codebooks, int n_wg, int nw) {
-    if (n_wg <= 0 || nw <= 0 || !g_codebooks) return RQO_EARG;
+                            float *g_res0, float *g_codebooks, int n_wg, int nw, int unit_rows) {
+    if (n_wg <= 0 || nw <= 0 || unit_rows <= 0 || !g_codebooks) return RQO_EARG;
     const size_t LKD = (size_t)L * K * D;
     float *V = (float *)malloc(sizeof(float) * (size_t)L * (size_t)(B > 0 ? B : 1) * D);
     float *part = (float *)calloc((size_t)n_wg * LKD, sizeof(float));
@@ -264,14 +266,14 @@ int rqo_rq_backward_ordered(const float *res0, int64_t B, int D, const float *co
     int rc = rq_backward_core(res0, B, D, codebooks, L, K, mode, beta, ids, g_embs, g_embsum, g_resid, g_loss, g_res0,
                               0, V);
     if (rc) { free(V); free(part); return rc; }
-    const int64_t n_tiles = (B + 31) / 32, waves = (int64_t)n_wg * nw;
+    const int64_t n_tiles = (B + unit_rows - 1) / unit_rows, waves = (int64_t)n_wg * nw;
     for (int b = 0; b < n_wg; ++b) {
         float *pb = part + (size_t)b * LKD;
         for (int64_t it = 0; it * waves < n_tiles; ++it)
             for (int j = 0; j < nw; ++j) {
                 int64_t tile = it * waves + (int64_t)j * n_wg + b;
                 if (tile >= n_tiles) continue;
-                for (int64_t i = tile * 32; i < tile * 32 + 32 && i < B; ++i)
+                for (int64_t i = tile * unit_rows; i < (tile + 1) * unit_rows && i < B; ++i)
                     for (int l = 0; l < L; ++l) {
                         float *dE = pb + ((size_t)l * K + ids[(size_t)l * B + i]) * D;
                         const float *v = V + ((size_t)l * B + i) * D;

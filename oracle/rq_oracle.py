@@ -81,8 +81,8 @@ def rq_forward(res0, codebooks, mode: int, beta: float = 0.25, want_margin: bool
 def rq_backward(res0, codebooks, mode: int, beta: float, ids, g_embs=None, g_embsum=None,
                 g_resid=None, g_loss=None, order=None):
     """Closed-form backward of rq_forward.  Returns (g_res0 [B,D], g_codebooks [L,K,D]).
-    order=None: codebook gradients summed over rows in ascending order; order=(n_wg, nw): in the fixed order of the
-    fused HIP kernel launched with n_wg workgroups of nw waves (rqhip_rq_backward_plan), for bit-exact comparison."""
+    order=None: codebook gradients summed over rows in ascending order; order=(n_wg, units_per_wg, unit_rows): in the
+    fixed order of the HIP kernel with that geometry (rqhip_rq_backward_plan), for bit-exact comparison."""
     res0, codebooks = _f(res0), _f(codebooks)
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     B, D = res0.shape
@@ -98,7 +98,7 @@ def rq_backward(res0, codebooks, mode: int, beta: float, ids, g_embs=None, g_emb
     if order is None:
         rc = lib().rqo_rq_backward(*args)
     else:
-        rc = lib().rqo_rq_backward_ordered(*args, C.c_int(int(order[0])), C.c_int(int(order[1])))
+        rc = lib().rqo_rq_backward_ordered(*args, C.c_int(int(order[0])), C.c_int(int(order[1])), C.c_int(int(order[2])))
     _chk(rc, "rq_backward")
     return g_res0, g_cb
 

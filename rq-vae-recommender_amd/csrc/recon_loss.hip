@@ -172,6 +172,25 @@ __global__ __launch_bounds__(1024) void loss_means_kernel(const float *__restric
     if (t < 3) out[t] = red[t][0] / (float)B;
 }
 
+// Backward of the three means: every row of `recon` receives (g_loss + g_recon_mean) * (1/B), every row of `quant`
+// (g_loss + g_quant_mean) * (1/B) -- the arithmetic of PyTorch's own mean backward on the device, which multiplies by
+// the fp32 reciprocal of a scalar divisor -- written as the two dense [B] vectors the next kernels read, in one launch
+// instead of add / scale / expand-copy per vector.
+__global__ __launch_bounds__(256) void loss_means_bwd_kernel(const float *__restrict__ g_loss, const float *__restrict__ g_recon,
+                                                             const float *__restrict__ g_quant, long long B,
+                                                             float *__restrict__ rows_recon, float *__restrict__ rows_quant) {
+    const float inv = 1.0f / (float)B;
+    const float gl = g_loss ? *g_loss : 0.0f;
+    // one term: that term; two terms: their fp32 sum (g_loss first, as the autograd engine accumulates them)
+    const float sr = (g_loss && g_recon) ? gl + *g_recon : (g_recon ? *g_recon : gl);
+    const float sq = (g_loss && g_quant) ? gl + *g_quant : (g_quant ? *g_quant : gl);
+    const float vr = sr * inv, vq = sq * inv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long long)gridDim.x * blockDim.x) {
+        if (rows_recon) rows_recon[i] = vr;
+        if (rows_quant) rows_quant[i] = vq;
+    }
+}
+
 static int row_grid(long long B) {
     long long want = (B + 3) / 4, cap = (long long)cu_count() * 8;
     if (want < 1) want = 1;
@@ -248,6 +267,20 @@ extern "C" int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat
     hipLaunchKernelGGL(recon_bwd_spec_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        x_hat, (long long)ld_hat, x, (long long)ld_x, g_out, (long long)B, N, row_scale, g_spec);
     RQ_CHECK_LAUNCH("recon_bwd_spec_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_loss_means_backward(const float *g_loss, const float *g_recon_mean, const float *g_quant_mean,
+                                         int64_t B, float *rows_recon, float *rows_quant, rqhip_stream_t stream) {
+    if (B <= 0 || (!rows_recon && !rows_quant)) {
+        set_error("loss_means_backward: bad arguments");
+        return RQHIP_EARG;
+    }
+    long long g = (B + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(loss_means_bwd_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g_loss,
+                       g_recon_mean, g_quant_mean, (long long)B, rows_recon, rows_quant);
+    RQ_CHECK_LAUNCH("loss_means_bwd_kernel");
     return RQHIP_OK;
 }
 

@@ -16,6 +16,7 @@
 //   atomics on 24 576 addresses at B = 100 k) measured 6.1 ms on MI355X, 60x the whole forward.
 // Kernel 3 (reduce): g_codebooks[j] = sum over workgroups of partial[g][j], fixed order.
 // When one level's table exceeds LDS (K (D+1) 4 B > 150 KiB) kernel 1 falls back to global atomics.
+#include <stdlib.h>
 #include "rq_rowmath.h"
 
 namespace rqhip {
@@ -33,7 +34,15 @@ struct RqBwdParams {
     // fused kernel only: this launch scatters the codeword gradients of levels [l_begin, l_end) (the ones whose tables
     // fit LDS together) and writes g_res0 iff write_rows
     int l_begin, l_end, write_rows;
+#ifdef RQ_BWD_PROBE
+    int probe;  // developer A/B build only (tools/probe_backward.sh): bit mask of phases to skip, from $RQ_BWD_PROBE
+#endif
 };
+#ifdef RQ_BWD_PROBE
+#define RQ_PROBE(bit) (p.probe & (bit))
+#else
+#define RQ_PROBE(bit) 0
+#endif
 
 template <int KSTEPS, int MODE>
 __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
@@ -341,6 +350,201 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
     }
 }
 
+// ---- flat variant for EVAL / STE, D % 4 == 0, D <= 64: the backward of these two modes is purely elementwise ----------
+// Nothing in the EVAL / STE recursion crosses features (no dot products -- those belong to the rotation trick), so the
+// pair layout of the matrix kernels buys nothing here and costs L * KSTEPS registers per lane (247 VGPRs, two waves per
+// SIMD, two half-filled rounds at B = 100 000).  This kernel maps one lane to FOUR consecutive features of one row:
+//   * D/4 lanes per row, R = 1024 / (D/4) rows per workgroup and round; every global access is one 16-byte load / store
+//     and a wave touches whole consecutive rows; ~50 VGPRs, 16 waves per CU;
+//   * software pipeline: the row data of round it+1 (res0, upstream gradients, gathered codewords) and the ids of round
+//     it+2 are in flight while round it accumulates;
+//   * embedding backward, no atomics ("owner computes"), ONE staging phase per round for all the levels of the launch:
+//     each lane parks its 4 codeword-gradient values per level in the LDS stage [levels][R][D] and the table row
+//     key = level * K + id in keys[]; after one barrier every table row is updated by exactly one owner -- half-wave
+//     key & 31 when D <= 32, wave key & 15 otherwise -- which adds the staged vectors of its keys in ascending row
+//     order with plain LDS read / add / write.  The sum order of a code is therefore: workgroup b of G, round it ascending (rows
+//     [(it G + b) R, (it G + b) R + R)), row ascending -- oracle/rq_oracle.c:rqo_rq_backward_ordered with
+//     unit_rows = R, nw = 1 -- followed by the same 4-segment reduce over workgroups.
+constexpr int kFlatThreads = 1024;
+constexpr int kFlatWaves = kFlatThreads / 64;
+constexpr int kFlatMaxD = 64;
+// per-owner lists of the staged rows an owner has to add, (key << 12 | staged row): kListCap entries per pass (+2 so the
+// prefetch of the next pair never leaves the allocation); more rows of one owner in a round take another pass
+constexpr int kListCap = 32, kListStride = kListCap + 2;
+constexpr size_t kFlatListBytes = 2 * kFlatWaves * kListStride * sizeof(unsigned);
+
+template <int MODE, bool PAIR>
+__global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const RqBwdParams p, float *__restrict__ partial,
+                                                                       int LKD_total, int R, int LPR) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int D = p.D, L = p.L, K = p.K;
+    const int nl = p.l_end - p.l_begin;
+    const int tbl = p.g_cb ? nl * K * D : 0;                 // [levels of this launch][K][D]
+    float *stage = acc + tbl;                               // [nl][R][D]
+    int *keys = reinterpret_cast<int *>(stage + (size_t)nl * R * D);  // [nl][R]
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int e = threadIdx.x * 4; e < tbl; e += kFlatThreads * 4) *reinterpret_cast<f32x4 *>(acc + e) = zero4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rl = tid / LPR, ch = tid - rl * LPR;          // row slot inside the round, 16-byte chunk inside the row
+    const bool slot = rl < R;
+    const long long blocks = (p.B + R - 1) / R;
+    const long long n_rounds = (blocks + gridDim.x - 1) / gridDim.x;   // same for every workgroup (barriers below)
+
+    auto row_of = [&](long long it) -> long long {          // this lane's row in round it, or B (= none)
+        const long long blk = it * gridDim.x + blockIdx.x;
+        const long long row = blk * R + rl;
+        return (slot && it < n_rounds && blk < blocks && row < p.B) ? row : p.B;
+    };
+    auto ld4 = [&](const float *base, long long row) -> f32x4 {
+        return *reinterpret_cast<const f32x4 *>(base + (size_t)row * D + 4 * ch);
+    };
+    auto load_ids = [&](long long row, int(&id)[kFusedMaxL]) {
+#pragma unroll
+        for (int l = 0; l < kFusedMaxL; ++l) id[l] = (l < L && row < p.B) ? (int)p.ids[(size_t)l * p.B + row] : 0;
+    };
+    auto gather = [&](long long row, const int(&id)[kFusedMaxL], f32x4(&e)[kFusedMaxL]) {
+#pragma unroll
+        for (int l = 0; l < kFusedMaxL; ++l)
+            e[l] = (l < L && row < p.B) ? *reinterpret_cast<const f32x4 *>(p.cb + ((size_t)l * K + id[l]) * D + 4 * ch) : zero4;
+    };
+
+    long long row_c = row_of(0), row_n = row_of(1);
+    int id_c[kFusedMaxL], id_n[kFusedMaxL], id_nn[kFusedMaxL];
+    f32x4 e_c[kFusedMaxL], e_n[kFusedMaxL];
+    load_ids(row_c, id_c);
+    f32x4 r0_c = row_c < p.B ? ld4(p.res0, row_c) : zero4, r0_n;
+    f32x4 gs_c = (p.g_embsum && row_c < p.B) ? ld4(p.g_embsum, row_c) : zero4, gs_n;
+    float gl_c = (p.g_loss && row_c < p.B) ? p.g_loss[row_c] : 0.0f, gl_n;
+    load_ids(row_n, id_n);
+    gather(row_c, id_c, e_c);
+
+    for (long long it = 0; it < n_rounds; ++it) {
+        const bool ok = row_c < p.B;
+        // ---- this round's rows: residual chain forward, then the levels backwards carrying G = dL/d res_l ------------
+        f32x4 r[kFusedMaxL];
+        r[0] = r0_c;
+#pragma unroll
+        for (int l = 0; l + 1 < kFusedMaxL; ++l) {
+            if (l + 1 < L) {
+                const f32x4 o = (MODE == RQHIP_MODE_EVAL) ? e_c[l] : r[l] + (e_c[l] - r[l]);   // level_output<MODE>
+                r[l + 1] = r[l] - o;
+            }
+        }
+        f32x4 G = zero4;
+#pragma unroll
+        for (int l = kFusedMaxL - 1; l >= 0; --l) {
+            if (l < L) {
+                f32x4 A = zero4, gr = zero4;
+                if (p.g_embs && ok) A = ld4(p.g_embs + (size_t)l * p.B * D, row_c);
+                if (p.g_resid && ok) gr = ld4(p.g_resid + (size_t)l * p.B * D, row_c);
+                if (p.g_embsum) A = A + gs_c;
+                A = A - G;
+                const f32x4 commit = ((2.0f * p.beta) * (r[l] - e_c[l])) * gl_c;
+                const f32x4 embg = (2.0f * (e_c[l] - r[l])) * gl_c;
+                f32x4 cbv;
+                if (MODE == RQHIP_MODE_EVAL) {
+                    cbv = A + embg;
+                    G = (gr + G) + commit;
+                } else {
+                    G = ((gr + G) + A) + commit;
+                    cbv = embg;
+                }
+                if (p.g_cb && l >= p.l_begin && l < p.l_end && slot && !RQ_PROBE(4)) {   // (level test is uniform)
+                    const int li = l - p.l_begin;
+                    *reinterpret_cast<f32x4 *>(stage + ((size_t)li * R + rl) * D + 4 * ch) = cbv;
+                    if (ch == 0) keys[li * R + rl] = ok ? li * K + id_c[l] : -1;
+                }
+            }
+        }
+        if (ok && p.g_res0 && p.write_rows) *reinterpret_cast<f32x4 *>(p.g_res0 + (size_t)row_c * D + 4 * ch) = G;
+
+        // ---- next round's row data and the ids after that: in flight during the accumulation --------------------------
+        const long long row_nn = row_of(it + 2);
+        r0_n = row_n < p.B ? ld4(p.res0, row_n) : zero4;
+        gs_n = (p.g_embsum && row_n < p.B) ? ld4(p.g_embsum, row_n) : zero4;
+        gl_n = (p.g_loss && row_n < p.B) ? p.g_loss[row_n] : 0.0f;
+        gather(row_n, id_n, e_n);
+        load_ids(row_nn, id_nn);
+
+        if (p.g_cb && !RQ_PROBE(4)) {
+            __syncthreads();
+            const int items = RQ_PROBE(2) ? 0 : nl * R;
+            // Owners: half-waves (D <= 32; 32 of them) or waves (16).  Everything below is per-lane VALU + LDS work: a
+            // first version picked the rows with scalar ballot / readlane logic and was bound by the CU's one scalar
+            // unit (4.2 us per 128-row round); a second walked per-batch bit masks and paid three dependent LDS
+            // latencies per batch of 64 rows (2.8 us).  Now each wave first lists its owners' rows of the whole round
+            // (one pass over the keys), then adds them from the list with the next pair prefetched.
+            const int f = PAIR ? (lane & 31) : lane, half = PAIR ? (lane >> 5) : 0;
+            const int nown = PAIR ? 2 * kFlatWaves : kFlatWaves;
+            const int own0 = PAIR ? 2 * wave : wave;                        // this wave's first (or only) owner
+            unsigned *lists = reinterpret_cast<unsigned *>(keys + (size_t)nl * R);
+            const unsigned *mylist = lists + (own0 + half) * kListStride;
+            for (int lo = 0;; lo += kListCap) {
+                // build: every lane looks at one staged row per batch; rows of this wave's owners get their rank
+                // (rows before them in the round with the same owner) and go to slot rank - lo of the owner's list
+                int cnt0 = 0, cnt1 = 0;
+                for (int base = 0; base < items; base += 64) {
+                    const int item = base + lane;
+                    const int mykey = item < items ? keys[item] : -1;
+                    const int own = mykey & (nown - 1);
+                    const bool mine0 = mykey >= 0 && own == own0;
+                    const bool mine1 = PAIR && mykey >= 0 && own == own0 + 1;
+                    const unsigned long long m0 = __ballot(mine0), m1 = PAIR ? __ballot(mine1) : 0ull;
+                    const unsigned long long mm = mine1 ? m1 : m0;
+                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                    const int slot_i = (mine1 ? cnt1 : cnt0) + before - lo;
+                    if ((mine0 || mine1) && slot_i >= 0 && slot_i < kListCap && !RQ_PROBE(1))
+                        lists[(own0 + (mine1 ? 1 : 0)) * kListStride + slot_i] = ((unsigned)mykey << 12) | (unsigned)item;
+                    cnt0 += __popcll(m0);
+                    cnt1 += __popcll(m1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the lists are written and read by this wave only
+                // add: two rows per step, the pair after them already on its way; both table values are read before
+                // either is written, and when the two rows hit the same code the first sum is forwarded in registers,
+                // so the adds of one code stay strictly in row order
+                int n = (half ? cnt1 : cnt0) - lo;
+                n = n < 0 ? 0 : (n > kListCap ? kListCap : n);
+                if (RQ_PROBE(1)) n = 0;
+                unsigned e0 = mylist[0], e1 = mylist[1];
+                for (int i = 0; i < n; i += 2) {
+                    const unsigned ne0 = mylist[i + 2], ne1 = mylist[i + 3];
+                    const bool two = i + 1 < n;
+                    const int ka = (int)(e0 >> 12), ja = (int)(e0 & 4095u);
+                    const int kb = two ? (int)(e1 >> 12) : ka, jb = two ? (int)(e1 & 4095u) : ja;
+                    if (f < D) {
+                        float *ta = acc + (size_t)ka * D + f, *tb = acc + (size_t)kb * D + f;
+                        const float t_a = *ta, s_a = stage[(size_t)ja * D + f];
+                        const float t_b = *tb, s_b = stage[(size_t)jb * D + f];
+                        const float va = t_a + s_a;
+                        const float vb = ((kb == ka) ? va : t_b) + s_b;
+                        *ta = va;
+                        if (two) *tb = vb;
+                    }
+                    e0 = ne0;
+                    e1 = ne1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if ((cnt0 > cnt1 ? cnt0 : cnt1) <= lo + kListCap) break;
+            }
+            __syncthreads();
+        }
+
+        row_c = row_n; row_n = row_nn;
+        r0_c = r0_n; gs_c = gs_n; gl_c = gl_n;
+#pragma unroll
+        for (int l = 0; l < kFusedMaxL; ++l) { id_c[l] = id_n[l]; id_n[l] = id_nn[l]; e_c[l] = e_n[l]; }
+    }
+
+    if (p.g_cb) {
+        __syncthreads();
+        float *out = partial + (size_t)blockIdx.x * LKD_total;
+        for (int e = threadIdx.x * 4; e < (RQ_PROBE(8) ? 0 : tbl); e += kFlatThreads * 4)
+            *reinterpret_cast<f32x4 *>(out + e) = *reinterpret_cast<const f32x4 *>(acc + e);
+    }
+}
+
 // ---- kernel 2: LDS-private scatter of V into per-workgroup codebook-gradient tables -----------------------
 // thread (rs, d): rs = row slot inside the workgroup's step, d = feature.  DR = D rounded up to a power of 2.
 __global__ __launch_bounds__(256) void rq_cbgrad_scatter_kernel(const float *__restrict__ V,
@@ -421,6 +625,29 @@ static int fused_levels_per_pass(int D, int K, int L) {
     return n < 1 ? 1 : (n > L ? L : n);
 }
 
+// flat kernel (EVAL / STE): rows per workgroup and round, LDS per level of the launch, launch geometry
+static bool flat_shape_ok(int D, int L) { return D % 4 == 0 && D <= kFlatMaxD && L <= kFusedMaxL; }
+static int flat_rows(int D) { return kFlatThreads / (D / 4); }
+static size_t flat_level_bytes(int D, int K) {
+    const size_t R = flat_rows(D);
+    return (size_t)K * D * sizeof(float) + R * D * sizeof(float) + R * sizeof(int);
+}
+static bool flat_fits(int D, int K, int L) {
+    return flat_shape_ok(D, L) && flat_level_bytes(D, K) + kFlatListBytes <= kFusedLdsBudget;
+}
+static int flat_levels_per_pass(int D, int K, int L) {
+    const int n = (int)((kFusedLdsBudget - kFlatListBytes) / flat_level_bytes(D, K));
+    return n < 1 ? 1 : (n > L ? L : n);
+}
+static int flat_wgs(long long B, int D) {
+    const long long R = flat_rows(D);
+    long long g = (B + R - 1) / R;
+    const long long cap = cu_count();
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 static int scatter_wgs(long long B) {
     long long g = (B + 255) / 256;
     if (g > kMaxScatterWgs) g = kMaxScatterWgs;
@@ -454,22 +681,29 @@ static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
 
 using namespace rqhip;
 
-// which path rqhip_rq_backward takes: returns 1 and the fused kernel's geometry (workgroups, waves per workgroup) when
-// the codebook gradient is accumulated in the fixed order restated by the oracle, 0 for the three-kernel path
-extern "C" int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int *n_wg, int *waves_per_wg) {
-    const bool fused = B > 0 && D >= 1 && K >= 1 && L >= 1 && fused_fits(D, K, L);
-    if (n_wg) *n_wg = fused ? fused_wgs(B) : 0;
-    if (waves_per_wg) *waves_per_wg = fused ? kFusedWaves : 0;
-    return fused ? 1 : 0;
+// which path rqhip_rq_backward takes for 16-byte aligned tensors: returns 1 and the geometry that fixes the summation
+// order of the codebook gradient (workgroups, row units per workgroup and round, rows per unit) when it is accumulated
+// in the order restated by the oracle, 0 for the three-kernel path
+extern "C" int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int mode, int *n_wg, int *units_per_wg,
+                                      int *unit_rows) {
+    const bool ok = B > 0 && D >= 1 && K >= 1 && L >= 1;
+    const bool flat = ok && mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L);
+    const bool fused = ok && !flat && fused_fits(D, K, L);
+    if (n_wg) *n_wg = flat ? flat_wgs(B, D) : fused ? fused_wgs(B) : 0;
+    if (units_per_wg) *units_per_wg = flat ? 1 : fused ? kFusedWaves : 0;
+    if (unit_rows) *unit_rows = flat ? flat_rows(D) : fused ? 32 : 0;
+    return (flat || fused) ? 1 : 0;
 }
 
 // layout: [L,B,D] row scratch | [G, L*K*D] per-workgroup partial tables (LDS scatter path only)
 extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K) {
     if (B <= 0 || D <= 0 || L <= 0 || K <= 0) return 16;
     const size_t rows = (size_t)L * (size_t)B * (size_t)D * sizeof(float);
-    const size_t g = fused_fits(D, K, L) ? (size_t)fused_wgs(B) : (size_t)scatter_wgs(B);
-    const size_t partial = (fused_fits(D, K, L) || scatter_fits_lds(D, K)) ? g * (size_t)L * K * D * sizeof(float) : 0;
-    return rows + partial;
+    size_t g = 0;   // per-workgroup partial tables: the most any path of this shape launches
+    if (fused_fits(D, K, L)) g = (size_t)fused_wgs(B);
+    if (flat_fits(D, K, L) && (size_t)flat_wgs(B, D) > g) g = (size_t)flat_wgs(B, D);
+    if (scatter_fits_lds(D, K) && (size_t)scatter_wgs(B) > g) g = (size_t)scatter_wgs(B);
+    return rows + g * (size_t)L * K * D * sizeof(float);
 }
 
 extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
@@ -504,10 +738,48 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     p.ws = reinterpret_cast<float *>(workspace);
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.beta = beta;
     p.atomic_scatter = lds_path ? 0 : 1;
+#ifdef RQ_BWD_PROBE
+    p.probe = getenv("RQ_BWD_PROBE") ? atoi(getenv("RQ_BWD_PROBE")) : 0;
+#endif
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L) && al16(res0) && al16(codebooks) && al16(g_embs) &&
+        al16(g_embsum) && al16(g_resid) && al16(g_res0) && al16(workspace)) {
+        const int R = flat_rows(D), LPR = D / 4;
+        const int G = flat_wgs(B, D);
+        float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
+        const int per_pass = g_codebooks ? flat_levels_per_pass(D, K, L) : L;
+        for (int l0 = 0; l0 < L; l0 += per_pass) {
+            p.l_begin = l0;
+            p.l_end = (l0 + per_pass < L) ? l0 + per_pass : L;
+            p.write_rows = (l0 == 0);
+            const int nl = p.l_end - p.l_begin;
+            const int LKD = nl * K * D;
+            const size_t lds = g_codebooks ? (size_t)nl * flat_level_bytes(D, K) + kFlatListBytes : 0;
+            auto go = [&](auto kern) -> int {
+                static LdsGrant grant;
+                RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kFusedLdsBudget));
+                hipLaunchKernelGGL(kern, dim3(G), dim3(kFlatThreads), lds, s, p, partial, LKD, R, LPR);
+                RQ_CHECK_LAUNCH("rq_backward_flat_kernel");
+                return 0;
+            };
+            int rcf;
+            if (mode == RQHIP_MODE_EVAL)
+                rcf = D <= 32 ? go(rq_backward_flat_kernel<RQHIP_MODE_EVAL, true>)
+                              : go(rq_backward_flat_kernel<RQHIP_MODE_EVAL, false>);
+            else
+                rcf = D <= 32 ? go(rq_backward_flat_kernel<RQHIP_MODE_STE, true>)
+                              : go(rq_backward_flat_kernel<RQHIP_MODE_STE, false>);
+            if (rcf) return rcf;
+            if (!g_codebooks) break;  // nothing to scatter: the first launch has written g_res0
+            hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD,
+                               g_codebooks + (size_t)l0 * K * D);
+            RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+        }
+        return RQHIP_OK;
+    }
     if (fused_fits(D, K, L)) {
         const int G = fused_wgs(B);
         float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
-        auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
         const bool vec = D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) &&
                          al16(g_resid) && al16(g_res0);
         // one launch per group of levels whose tables fit LDS together (all of them for 3 x 256 x 32; one level at a

@@ -130,7 +130,10 @@ __global__ void rq_csq_kernel(const float *__restrict__ cb, int L, int K, int Kp
 // image float4 (q,h,c), element j  =  C[kbase+c][d = 2*(4q+j)+h]   (0 beyond K or D)
 // `nbuf` consecutive buffers are filled from `nbuf` consecutive codebooks (resident mode: all levels at once,
 // so that a thread has up to kStageBatch independent 16-byte loads in flight before its first LDS write).
-constexpr int kStageBatch = 4;
+#ifndef RQ_STAGE_BATCH
+#define RQ_STAGE_BATCH 4   // (developer A/B: tools/ab_build.sh)
+#endif
+constexpr int kStageBatch = RQ_STAGE_BATCH;
 
 template <int KSTEPS, int NT>
 __device__ __forceinline__ void stage_codes(float *buf0, int buf_floats, int nbuf, const float *__restrict__ cb0,

@@ -28,7 +28,7 @@ SIGNATURES = {
     "rqhip_rq_forward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),
     "rqhip_rq_backward_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
-    "rqhip_rq_backward_plan": (_int, [_i64, _int, _int, _int, C.POINTER(_int), C.POINTER(_int)]),
+    "rqhip_rq_backward_plan": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "rqhip_rq_backward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
     "rqhip_gumbel_forward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
@@ -51,6 +51,7 @@ SIGNATURES = {
     "rqhip_recon_loss_forward_spec": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _f32, _vp, _vp, _vp]),
     "rqhip_recon_loss_backward_spec": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _vp, _vp]),
     "rqhip_loss_means": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rqhip_loss_means_backward": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rqhip_linear_wgrad_supported": (_int, [_int, _int]),
     "rqhip_linear_wgrad_plan": (_int, [_i64, _int, _int, C.POINTER(_int)]),
     "rqhip_linear_wgrad_workspace_bytes": (_sz, [_i64, _int, _int]),

@@ -34,6 +34,7 @@ class RqStackFunction(torch.autograd.Function):
         """grad_sink (optional): object with `.view` ([L,K,D] slice of a flat gradient buffer) and `.params` (the L
         codebook parameters); the codebook gradient is written there when it is the first gradient of the step."""
         out = ops.rq_forward(res0, codebooks, mode, beta, want_embs=want_levels, want_residuals=want_levels)
+        ctx.set_materialize_grads(False)   # outputs nobody used arrive as None (= NULL at the C ABI), not as zero tensors
         ctx.save_for_backward(res0, codebooks, out.ids)
         ctx.mode, ctx.beta, ctx.want_levels, ctx.grad_sink = mode, beta, want_levels, grad_sink
         embs = out.embs if want_levels else res0.new_empty((0,))
@@ -83,6 +84,29 @@ class GumbelLevelFunction(torch.autograd.Function):
         return g_x, g_cb, None, None, None
 
 
+# The factor the caller will apply to the batch-mean loss before calling backward() (1 / gradient_accumulate_every, or a
+# micro-batch's share of a larger batch).  Only a HINT for the speculative reconstruction-loss gradient below: a wrong
+# value costs the saved pass, never correctness.
+_LOSS_SCALE = 1.0
+
+
+class loss_scale:
+    """`with loss_scale(s): out = model(batch, t)` -- tell the forward that `out.loss * s` is what will be backpropagated."""
+
+    def __init__(self, s: float) -> None:
+        self.s, self.prev = float(s), 1.0
+
+    def __enter__(self):
+        global _LOSS_SCALE
+        self.prev, _LOSS_SCALE = _LOSS_SCALE, self.s
+        return self
+
+    def __exit__(self, *exc):
+        global _LOSS_SCALE
+        _LOSS_SCALE = self.prev
+        return False
+
+
 class ReconLossFunction(torch.autograd.Function):
     """Row-wise squared error (reference modules/loss.py:5-10) as one HIP pass forward and one backward.
 
@@ -96,7 +120,10 @@ class ReconLossFunction(torch.autograd.Function):
         B = x.shape[0]
         ctx.spec = B > 0 and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and ops.recon_spec_ok(x_hat, x)
         if ctx.spec:
-            ctx.row_scale = float(torch.tensor(1.0, dtype=torch.float32) / B)   # fp32 1/B, as autograd's mean computes it
+            # fp32 (loss scale) * fp32 (1 / B): what autograd's multiply + mean backward hand to every row on the device
+            # (a scalar divisor becomes a multiplication by its fp32 reciprocal there, and in rqhip_loss_means_backward)
+            one = torch.tensor(1.0, dtype=torch.float32)
+            ctx.row_scale = float(torch.tensor(_LOSS_SCALE, dtype=torch.float32) * (one / B))
             out, g_spec = ops.recon_loss_forward_spec(x_hat, x, ctx.row_scale)
             ctx.save_for_backward(x_hat, x, g_spec)
             return out
@@ -117,22 +144,21 @@ class ReconLossFunction(torch.autograd.Function):
 
 class LossMeansFunction(torch.autograd.Function):
     """(loss, reconstruction_loss, rqvae_loss) of RqVae.forward -- mean(recon + quant), mean(recon), mean(quant) -- as one
-    launch.  Backward is what autograd derives for the three means: every row of `recon` receives
-    (g_loss + g_recon_mean) / B, every row of `quant` (g_loss + g_quant_mean) / B."""
+    launch.  Backward is what autograd derives for the three means, also one launch: every row of `recon` receives
+    (g_loss + g_recon_mean) * (1/B), every row of `quant` (g_loss + g_quant_mean) * (1/B)."""
 
     @staticmethod
     def forward(ctx, recon: Tensor, quant: Tensor):
         ctx.n = recon.numel()
+        ctx.set_materialize_grads(False)   # unused means arrive as None, not as zero tensors to add
         out = ops.loss_means(recon, quant)
         return out[0], out[1], out[2]
 
     @staticmethod
     def backward(ctx, g_loss, g_rmean, g_qmean):
-        def rows(a, b):
-            parts = [g for g in (a, b) if g is not None]
-            if not parts:
-                return None
-            g = parts[0] if len(parts) == 1 else parts[0] + parts[1]
-            return (g / ctx.n).expand(ctx.n)
-        return (rows(g_loss, g_rmean) if ctx.needs_input_grad[0] else None,
-                rows(g_loss, g_qmean) if ctx.needs_input_grad[1] else None)
+        need_r = ctx.needs_input_grad[0] and (g_loss is not None or g_rmean is not None)
+        need_q = ctx.needs_input_grad[1] and (g_loss is not None or g_qmean is not None)
+        if g_rmean is None and g_qmean is None and g_loss is not None and need_r and need_q:
+            rows, _ = ops.loss_means_backward(g_loss, None, None, ctx.n, True, False)
+            return rows, rows       # the usual case (only `loss` is backpropagated): one vector serves both inputs
+        return ops.loss_means_backward(g_loss, g_rmean, g_qmean, ctx.n, need_r, need_q)

@@ -410,6 +410,22 @@ def recon_loss_backward_spec(x_hat: Tensor, x: Tensor, g_out: Tensor, row_scale:
     return g_spec
 
 
+def loss_means_backward(g_loss: Optional[Tensor], g_recon: Optional[Tensor], g_quant: Optional[Tensor], n: int,
+                        want_recon: bool = True, want_quant: bool = True):
+    """Row gradients of the three means (rqhip_loss_means_backward): two dense [n] vectors (None where not wanted)."""
+    ref = next((g for g in (g_loss, g_recon, g_quant) if g is not None), None)
+    if ref is None or not (want_recon or want_quant):
+        return None, None
+    _need_gpu(ref)
+    gs = [None if g is None else _f32c(g.reshape(()), "g") for g in (g_loss, g_recon, g_quant)]
+    with torch.cuda.device(ref.device):
+        rows_r = torch.empty((n,), dtype=torch.float32, device=ref.device) if want_recon else None
+        rows_q = torch.empty((n,), dtype=torch.float32, device=ref.device) if want_quant else None
+        check(_lib.lib().rqhip_loss_means_backward(_ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), n, _ptr(rows_r), _ptr(rows_q),
+                                                   _stream()), "rqhip_loss_means_backward")
+    return rows_r, rows_q
+
+
 def loss_means(recon: Tensor, quant: Tensor) -> Tensor:
     """[3] = mean(recon + quant), mean(recon), mean(quant) in one launch (rqhip_loss_means)."""
     _need_gpu(recon, quant)

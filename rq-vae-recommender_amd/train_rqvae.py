@@ -38,6 +38,7 @@ from modules.rqvae import RqVae
 from modules.tokenizer.semids import SemanticIdTokenizer
 from modules.utils import parse_config
 from rqhip import dist as rqdist
+from rqhip.autograd import loss_scale
 from rqhip import tuning
 
 try:
@@ -301,7 +302,8 @@ def train(
             total_loss = 0
             for _ in range(gradient_accumulate_every):
                 data = data if data is not None else next(train_batches)
-                model_output = model(data, gumbel_t=t)
+                with loss_scale(1.0 / gradient_accumulate_every):   # hint for the speculative recon-loss gradient
+                    model_output = model(data, gumbel_t=t)
                 loss = model_output.loss / gradient_accumulate_every
                 loss.backward()
                 total_loss = total_loss + loss.detach()

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol_and_binding_covers_them():
 def test_version_and_error_string_without_gpu():
     from rqhip import _lib
     l = _lib.lib()
-    assert l.rqhip_version() == 200
+    assert l.rqhip_version() == 201
     # argument validation happens before any HIP call, so it is testable on a CPU-only box
     rc = l.rqhip_rq_forward(None, 4, 32, None, 3, 256, 1, 0.25, None, None, None, None, None, None, None, None, 0, None)
     assert rc == -1
@@ -66,5 +66,6 @@ def test_workspace_queries():
     l = _lib.lib()
     assert l.rqhip_rq_forward_workspace_bytes(3, 256) == (3 * 256 + 3) * 4
     assert l.rqhip_rq_forward_workspace_bytes(2, 100) == (2 * 128 + 2) * 4
-    assert l.rqhip_rq_backward_workspace_bytes(1000, 32, 3, 256) == 3 * 1000 * 32 * 4 + 4 * 3 * 256 * 32 * 4
+    # [L,B,D] row scratch + one [L,K,D] partial table per workgroup of the widest launch (8 x 128-row units here)
+    assert l.rqhip_rq_backward_workspace_bytes(1000, 32, 3, 256) == 3 * 1000 * 32 * 4 + 8 * 3 * 256 * 32 * 4
     assert l.rqhip_dedup_workspace_bytes(1000) >= 2048 * 4 + 4 * 1000 * 4

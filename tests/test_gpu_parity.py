@@ -163,21 +163,23 @@ def test_forward_full_size_properties(B, D, K, L, mode):
 
 # ---------------------------------------------------------------- backward ---------------------------
 
-def _bwd_order(B, D, L, K):
-    """(n_wg, waves) of the fixed-order fused backward kernel, or None when the shape takes the atomic scatter path."""
+def _bwd_order(B, D, L, K, mode):
+    """(n_wg, units per workgroup, rows per unit) of the fixed-order backward kernels, or None when the shape takes the
+    atomic scatter path."""
     import ctypes as C
     from rqhip import _lib
-    n_wg, nw = C.c_int(0), C.c_int(0)
-    fused = _lib.lib().rqhip_rq_backward_plan(B, D, L, K, C.byref(n_wg), C.byref(nw))
-    return (n_wg.value, nw.value) if fused else None
+    n_wg, nw, unit = C.c_int(0), C.c_int(0), C.c_int(0)
+    fixed = _lib.lib().rqhip_rq_backward_plan(B, D, L, K, mode, C.byref(n_wg), C.byref(nw), C.byref(unit))
+    return (n_wg.value, nw.value, unit.value) if fixed else None
 
 
 def _assert_cb_grad(g_cb, x, cbs, mode, ids, g, r_cb, what=""):
     """Codebook gradient: bit-exact against the oracle's restatement of the kernel's summation order where the
-    fixed-order kernel runs (D <= 32, L <= 4); fp32-rounding tolerance on the atomic scatter path."""
+    fixed-order kernels run (L <= 4 and D <= 32, or EVAL / STE with D % 4 == 0, D <= 64); fp32-rounding tolerance on the
+    atomic scatter path."""
     B, D = x.shape
     L, K, _ = cbs.shape
-    order = _bwd_order(B, D, L, K)
+    order = _bwd_order(B, D, L, K, mode)
     if order is not None:
         _, o_cb = o.rq_backward(x, cbs, mode, 0.25, ids, order=order, **g)
         _assert_bitexact(g_cb, o_cb, "g_codebooks (fixed order) " + what)
@@ -217,8 +219,34 @@ def test_backward_vs_oracle(mode, B, D, K, L, which):
     _assert_bitexact(g_res0, r_res0, "g_res0")          # per-row arithmetic: exact
     _assert_cb_grad(g_cb, x, cbs, mode, ref["ids"], g, r_cb)
     g_res0_b, g_cb_b = _run_backward(x, cbs, mode, 0.25, ref["ids"], **g)
-    if _bwd_order(B, D, L, K) is not None:
+    if _bwd_order(B, D, L, K, mode) is not None:
         _assert_bitexact(g_cb_b, g_cb, "g_codebooks run-to-run")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("pattern", ["one_code", "two_codes", "same_owner", "runs"])
+def test_backward_skewed_ids(mode, pattern):
+    """Codebook gradient when many rows of a round share a code or an owner (collapsed codebooks, duplicated items): the
+    owner's list of the flat kernel overflows into further passes and equal codes meet inside one step (register
+    forwarding).  The backward takes the ids as given, so they need not be the argmin."""
+    B, D, K, L = 3000, 32, 256, 3
+    rng = np.random.default_rng(17 + mode)
+    x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, D)) * 0.4).astype(np.float32)
+    if pattern == "one_code":
+        ids = np.full((L, B), 5, np.int64)
+    elif pattern == "two_codes":
+        ids = rng.choice([3, 200], size=(L, B)).astype(np.int64)
+    elif pattern == "same_owner":          # every code is congruent mod 32: one owner takes all rows of a level
+        ids = (rng.integers(0, K // 32, size=(L, B)) * 32 + 7).astype(np.int64)
+    else:                                   # runs of equal codes of random length
+        ids = np.repeat(rng.integers(0, K, size=(L, B // 3 + 1)), 3, axis=1)[:, :B].astype(np.int64)
+    g = dict(g_embs=None, g_embsum=(rng.standard_normal((B, D)) / B).astype(np.float32), g_resid=None,
+             g_loss=rng.random(B).astype(np.float32))
+    r_res0, r_cb = o.rq_backward(x, cbs, mode, 0.25, ids, **g)
+    g_res0, g_cb = _run_backward(x, cbs, mode, 0.25, ids, **g)
+    _assert_bitexact(g_res0, r_res0, "g_res0")
+    _assert_cb_grad(g_cb, x, cbs, mode, ids, g, r_cb, pattern)
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "quantize_*.npz"))))
@@ -398,9 +426,51 @@ def test_recon_loss_speculative_gradient_equals_plain_pair():
         reduce(out).backward()
         want, _ = ops.recon_loss_backward(base, x, g_rows.contiguous(), True, False)
         assert torch.equal(xh.grad, want)
+    # gradient accumulation: the caller announces the factor it applies to the mean loss (rqhip.autograd.loss_scale);
+    # right or wrong, the hint never changes the result
+    from rqhip.autograd import loss_scale
+    for hint, applied in ((0.25, 0.25), (1.0 / 3.0, 1.0 / 3.0), (0.5, 0.125)):
+        xh = base.clone().requires_grad_(True)
+        with loss_scale(hint):
+            out = ReconLossFunction.apply(xh, x)
+        g_rows = torch.autograd.grad(out.mean() * applied, out, retain_graph=True)[0]
+        (out.mean() * applied).backward()
+        want, _ = ops.recon_loss_backward(base, x, g_rows.contiguous(), True, False)
+        assert torch.equal(xh.grad, want)
+        if hint == applied:   # the expectation held: every row's upstream gradient is the announced fp32 value
+            want_row = float(torch.tensor(hint, dtype=torch.float32) * (torch.tensor(1.0, dtype=torch.float32) / B))
+            assert torch.equal(g_rows, torch.full_like(g_rows, want_row))
     # inference (no gradient requested) takes the plain kernel
     with torch.no_grad():
         assert torch.equal(ReconLossFunction.apply(base, x), ops.recon_loss_forward(base, x))
+
+
+def test_loss_means_and_their_backward_equal_autograd():
+    """LossMeansFunction (csrc/recon_loss.hip loss_means / loss_means_bwd): the three means to fp32 rounding of a
+    different summation order, and the row gradients equal to what autograd derives for mean(r + q), mean(r), mean(q)
+    under any mix of used / unused outputs -- bit for bit when one mean feeds an input (the training step), to one
+    rounding when two do ((a + b) * (1/n) here, a * (1/n) + b * (1/n) there)."""
+    from rqhip.autograd import LossMeansFunction
+    torch.manual_seed(11)
+    for n in (1, 7, 100_000):
+        r0 = torch.rand(n, device="cuda") * 3
+        q0 = torch.rand(n, device="cuda")
+        for weights in ((1.0, None, None), (0.5, 2.0, None), (None, None, 3.0), (1.0, 0.25, 0.125), (None, 1.0, None)):
+            r, q = r0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+            outs = LossMeansFunction.apply(r, q)
+            rr, qr = r0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+            refs = ((rr + qr).mean(), rr.mean(), qr.mean())
+            for a, b in zip(outs, refs):
+                assert torch.allclose(a, b, rtol=2e-6, atol=0)
+            sum(w * o for w, o in zip(weights, outs) if w is not None).backward()
+            sum(w * o for w, o in zip(weights, refs) if w is not None).backward()
+            for got, want, terms in ((r.grad, rr.grad, (weights[0], weights[1])), (q.grad, qr.grad, (weights[0], weights[2]))):
+                if want is None:
+                    assert got is None
+                elif sum(t is not None for t in terms) == 1:
+                    assert torch.equal(got, want), (n, weights)
+                else:
+                    assert torch.allclose(got, want, rtol=3e-7, atol=0), (n, weights)
 
 
 # ---------------------------------------------------------------- property tests ----------------------
