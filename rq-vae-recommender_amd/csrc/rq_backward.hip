@@ -353,141 +353,183 @@ __global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const 
 // ---- flat variant for EVAL / STE, D % 4 == 0, D <= 64: the backward of these two modes is purely elementwise ----------
 // Nothing in the EVAL / STE recursion crosses features (no dot products -- those belong to the rotation trick), so the
 // pair layout of the matrix kernels buys nothing here and costs L * KSTEPS registers per lane (247 VGPRs, two waves per
-// SIMD, two half-filled rounds at B = 100 000).  This kernel maps one lane to FOUR consecutive features of one row:
-//   * D/4 lanes per row, R = 1024 / (D/4) rows per workgroup and round; every global access is one 16-byte load / store
-//     and a wave touches whole consecutive rows; ~50 VGPRs, 16 waves per CU;
-//   * software pipeline: the row data of round it+1 (res0, upstream gradients, gathered codewords) and the ids of round
-//     it+2 are in flight while round it accumulates;
-//   * embedding backward, no atomics ("owner computes"), ONE staging phase per round for all the levels of the launch:
-//     each lane parks its 4 codeword-gradient values per level in the LDS stage [levels][R][D] and the table row
-//     key = level * K + id in keys[]; after one barrier every table row is updated by exactly one owner -- half-wave
-//     key & 31 when D <= 32, wave key & 15 otherwise -- which adds the staged vectors of its keys in ascending row
-//     order with plain LDS read / add / write.  The sum order of a code is therefore: workgroup b of G, round it ascending (rows
-//     [(it G + b) R, (it G + b) R + R)), row ascending -- oracle/rq_oracle.c:rqo_rq_backward_ordered with
-//     unit_rows = R, nw = 1 -- followed by the same 4-segment reduce over workgroups.
+// SIMD, two half-filled rounds at B = 100 000).  This kernel maps one lane to FOUR consecutive features of one row and
+// splits the workgroup's 16 waves into two roles that run concurrently (one workgroup per CU is all the LDS allows, so
+// the overlap of the HBM-bound and the LDS-bound half of the work has to happen INSIDE the workgroup):
+//   * waves 0-7, "rows": D/4 lanes per row, R = 512 / (D/4) rows per step; every global access is one 16-byte load /
+//     store and a wave touches whole consecutive rows.  The row data of step h+1 (res0, upstream gradients, gathered
+//     codewords) and the ids of step h+2 are in flight while step h is computed (software pipeline).  Each lane parks
+//     its 4 codeword-gradient values per level in the LDS stage [h & 1][levels][R][D] and the table row
+//     key = level * K + id in keys[h & 1][][];
+//   * waves 8-15, "owners": the embedding backward of the rows staged in step h-1, no atomics.  Every row of the
+//     workgroup's LDS table [levels][K][D] is updated by exactly one owner -- half-wave key & 15 when D <= 32, wave
+//     key & 7 otherwise -- which adds the staged vectors of its keys in ascending row order with plain LDS read / add /
+//     write;
+//   * one barrier per step hands the stage buffer over.
+// The sum order of a code is therefore: workgroup b of G, step h ascending (rows [(h G + b) R, (h G + b) R + R)), row
+// ascending -- oracle/rq_oracle.c:rqo_rq_backward_ordered with unit_rows = R, nw = 1 -- followed by the same 4-segment
+// reduce over workgroups.
 constexpr int kFlatThreads = 1024;
-constexpr int kFlatWaves = kFlatThreads / 64;
+constexpr int kFlatRowThreads = 512;                    // waves 0-7
+constexpr int kFlatOwnerWaves = 8;                      // waves 8-15
 constexpr int kFlatMaxD = 64;
 // per-owner lists of the staged rows an owner has to add, (key << 12 | staged row): kListCap entries per pass (+2 so the
-// prefetch of the next pair never leaves the allocation); more rows of one owner in a round take another pass
+// prefetch of the next pair never leaves the allocation); more rows of one owner in a step take another pass
 constexpr int kListCap = 32, kListStride = kListCap + 2;
-constexpr size_t kFlatListBytes = 2 * kFlatWaves * kListStride * sizeof(unsigned);
+constexpr size_t kFlatListBytes = 2 * kFlatOwnerWaves * kListStride * sizeof(unsigned);
 
-template <int MODE, bool PAIR>
+// NL: number of levels when known at compile time (3, 4), 0 = p.L.  TRAIN: the upstream gradients are the training
+// step's -- g_embsum and g_loss given, g_embs and g_resid absent -- so their loads and tests are compiled out.  (The rows
+// role is bound by instruction issue, not by HBM: ~400 VALU instructions per lane and step in the first version, 64-bit
+// address chains, per-load predication, tests of L and of four optional pointers.)
+template <int MODE, bool PAIR, int NL, bool TRAIN>
 __global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const RqBwdParams p, float *__restrict__ partial,
                                                                        int LKD_total, int R, int LPR) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float acc[];
-    const int D = p.D, L = p.L, K = p.K;
+    constexpr int LM = NL ? NL : kFusedMaxL;
+    const int D = p.D, L = NL ? NL : p.L, K = p.K;
     const int nl = p.l_end - p.l_begin;
     const int tbl = p.g_cb ? nl * K * D : 0;                 // [levels of this launch][K][D]
-    float *stage = acc + tbl;                               // [nl][R][D]
-    int *keys = reinterpret_cast<int *>(stage + (size_t)nl * R * D);  // [nl][R]
+    const int items = nl * R;                               // staged rows x levels per step
+    float *stage0 = acc + tbl;                              // [2][nl][R][D]
+    int *keys0 = reinterpret_cast<int *>(stage0 + 2 * (size_t)items * D);   // [2][nl][R]
+    unsigned *lists = reinterpret_cast<unsigned *>(keys0 + 2 * items);
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int e = threadIdx.x * 4; e < tbl; e += kFlatThreads * 4) *reinterpret_cast<f32x4 *>(acc + e) = zero4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rl = tid / LPR, ch = tid - rl * LPR;          // row slot inside the round, 16-byte chunk inside the row
-    const bool slot = rl < R;
+    const bool row_role = tid < kFlatRowThreads;             // wave-uniform
     const long long blocks = (p.B + R - 1) / R;
-    const long long n_rounds = (blocks + gridDim.x - 1) / gridDim.x;   // same for every workgroup (barriers below)
+    const long long n_steps = (blocks + gridDim.x - 1) / gridDim.x;   // same for every workgroup (barriers below)
 
-    auto row_of = [&](long long it) -> long long {          // this lane's row in round it, or B (= none)
-        const long long blk = it * gridDim.x + blockIdx.x;
-        const long long row = blk * R + rl;
-        return (slot && it < n_rounds && blk < blocks && row < p.B) ? row : p.B;
+    // ---- state of the "rows" role ---------------------------------------------------------------------------------------
+    // Addresses are a uniform base (scalar registers) + a 32-bit byte offset per lane (the host checks B * D * 4 < 2^32).
+    // Lanes without a row (tail of the last step, idle slots) read row B-1 like everybody else and do not store.
+    const int rl = (tid & (kFlatRowThreads - 1)) / LPR, ch = (tid & (kFlatRowThreads - 1)) - rl * LPR;
+    const bool slot = rl < R;                                // row slot inside the step, 16-byte chunk inside the row
+    const unsigned Bm1 = (unsigned)(p.B - 1), chb = (unsigned)ch * 16u, rowb = (unsigned)D * 4u;
+    auto at = [](const void *base, unsigned byte_off) { return reinterpret_cast<const char *>(base) + byte_off; };
+    auto ld4 = [&](const float *base, unsigned byte_off) { return *reinterpret_cast<const f32x4 *>(at(base, byte_off)); };
+    auto row_of = [&](long long h, bool &ok) -> unsigned {  // this lane's (clamped) row in step h; ok: it owns that row
+        const long long blk = h * gridDim.x + blockIdx.x;
+        const bool live = h < n_steps && blk < blocks;       // uniform
+        const unsigned row = (live ? (unsigned)(blk * R) : 0u) + (unsigned)rl;
+        ok = live && slot && row <= Bm1;
+        return row < Bm1 ? row : Bm1;
     };
-    auto ld4 = [&](const float *base, long long row) -> f32x4 {
-        return *reinterpret_cast<const f32x4 *>(base + (size_t)row * D + 4 * ch);
-    };
-    auto load_ids = [&](long long row, int(&id)[kFusedMaxL]) {
+    auto load_ids = [&](unsigned row, int(&id)[LM]) {
 #pragma unroll
-        for (int l = 0; l < kFusedMaxL; ++l) id[l] = (l < L && row < p.B) ? (int)p.ids[(size_t)l * p.B + row] : 0;
+        for (int l = 0; l < LM; ++l)
+            if (l < L) id[l] = *reinterpret_cast<const int *>(at(p.ids + (size_t)l * p.B, row * 8u));   // low dword
     };
-    auto gather = [&](long long row, const int(&id)[kFusedMaxL], f32x4(&e)[kFusedMaxL]) {
+    auto gather = [&](const int(&id)[LM], f32x4(&e)[LM]) {
 #pragma unroll
-        for (int l = 0; l < kFusedMaxL; ++l)
-            e[l] = (l < L && row < p.B) ? *reinterpret_cast<const f32x4 *>(p.cb + ((size_t)l * K + id[l]) * D + 4 * ch) : zero4;
+        for (int l = 0; l < LM; ++l)
+            if (l < L) e[l] = ld4(p.cb + (size_t)l * K * D, (unsigned)id[l] * rowb + chb);
     };
+    bool ok_c = false, ok_n = false, ok_nn = false;
+    unsigned row_c = 0, row_n = 0, row_nn = 0;
+    int id_c[LM], id_n[LM], id_nn[LM];
+    f32x4 e_c[LM], e_n[LM], r0_c = zero4, r0_n = zero4, gs_c = zero4, gs_n = zero4;
+    float gl_c = 0.0f, gl_n = 0.0f;
+#pragma unroll
+    for (int l = 0; l < LM; ++l) { id_c[l] = id_n[l] = id_nn[l] = 0; e_c[l] = e_n[l] = zero4; }
+    if (row_role) {
+        row_c = row_of(0, ok_c);
+        row_n = row_of(1, ok_n);
+        load_ids(row_c, id_c);
+        r0_c = ld4(p.res0, row_c * rowb + chb);
+        if (TRAIN || p.g_embsum) gs_c = ld4(p.g_embsum, row_c * rowb + chb);
+        if (TRAIN || p.g_loss) gl_c = *reinterpret_cast<const float *>(at(p.g_loss, row_c * 4u));
+        load_ids(row_n, id_n);
+        gather(id_c, e_c);
+    }
 
-    long long row_c = row_of(0), row_n = row_of(1);
-    int id_c[kFusedMaxL], id_n[kFusedMaxL], id_nn[kFusedMaxL];
-    f32x4 e_c[kFusedMaxL], e_n[kFusedMaxL];
-    load_ids(row_c, id_c);
-    f32x4 r0_c = row_c < p.B ? ld4(p.res0, row_c) : zero4, r0_n;
-    f32x4 gs_c = (p.g_embsum && row_c < p.B) ? ld4(p.g_embsum, row_c) : zero4, gs_n;
-    float gl_c = (p.g_loss && row_c < p.B) ? p.g_loss[row_c] : 0.0f, gl_n;
-    load_ids(row_n, id_n);
-    gather(row_c, id_c, e_c);
+    // ---- state of the "owners" role -------------------------------------------------------------------------------------
+    const int ow = wave - (kFlatThreads / 64 - kFlatOwnerWaves);            // owner wave 0..7 (negative: a rows wave)
+    const int f = PAIR ? (lane & 31) : lane, half = PAIR ? (lane >> 5) : 0;
+    const int nown = PAIR ? 2 * kFlatOwnerWaves : kFlatOwnerWaves;
+    const int own0 = PAIR ? 2 * ow : ow;                                    // this wave's first (or only) owner
 
-    for (long long it = 0; it < n_rounds; ++it) {
-        const bool ok = row_c < p.B;
-        // ---- this round's rows: residual chain forward, then the levels backwards carrying G = dL/d res_l ------------
-        f32x4 r[kFusedMaxL];
-        r[0] = r0_c;
+    // step h: the rows waves stage block h, the owner waves add block h-1; the last step only drains
+    const long long last = p.g_cb ? n_steps : n_steps - 1;
+    for (long long h = 0; h <= last; ++h) {
+        if (row_role) {
+            if (h < n_steps) {
+                const bool ok = ok_c;
+                float *stage = stage0 + (size_t)(h & 1) * items * D;
+                int *keys = keys0 + (h & 1) * items;
+                const unsigned off_c = row_c * rowb + chb;
+                // ---- this step's rows: residual chain forward, then the levels backwards carrying G = dL/d res_l ---------
+                f32x4 r[LM];
+                r[0] = r0_c;
 #pragma unroll
-        for (int l = 0; l + 1 < kFusedMaxL; ++l) {
-            if (l + 1 < L) {
-                const f32x4 o = (MODE == RQHIP_MODE_EVAL) ? e_c[l] : r[l] + (e_c[l] - r[l]);   // level_output<MODE>
-                r[l + 1] = r[l] - o;
-            }
-        }
-        f32x4 G = zero4;
-#pragma unroll
-        for (int l = kFusedMaxL - 1; l >= 0; --l) {
-            if (l < L) {
-                f32x4 A = zero4, gr = zero4;
-                if (p.g_embs && ok) A = ld4(p.g_embs + (size_t)l * p.B * D, row_c);
-                if (p.g_resid && ok) gr = ld4(p.g_resid + (size_t)l * p.B * D, row_c);
-                if (p.g_embsum) A = A + gs_c;
-                A = A - G;
-                const f32x4 commit = ((2.0f * p.beta) * (r[l] - e_c[l])) * gl_c;
-                const f32x4 embg = (2.0f * (e_c[l] - r[l])) * gl_c;
-                f32x4 cbv;
-                if (MODE == RQHIP_MODE_EVAL) {
-                    cbv = A + embg;
-                    G = (gr + G) + commit;
-                } else {
-                    G = ((gr + G) + A) + commit;
-                    cbv = embg;
+                for (int l = 0; l + 1 < LM; ++l) {
+                    if (l + 1 < L) {
+                        const f32x4 o = (MODE == RQHIP_MODE_EVAL) ? e_c[l] : r[l] + (e_c[l] - r[l]);   // level_output<MODE>
+                        r[l + 1] = r[l] - o;
+                    }
                 }
-                if (p.g_cb && l >= p.l_begin && l < p.l_end && slot && !RQ_PROBE(4)) {   // (level test is uniform)
-                    const int li = l - p.l_begin;
-                    *reinterpret_cast<f32x4 *>(stage + ((size_t)li * R + rl) * D + 4 * ch) = cbv;
-                    if (ch == 0) keys[li * R + rl] = ok ? li * K + id_c[l] : -1;
+                f32x4 G = zero4;
+#pragma unroll
+                for (int l = LM - 1; l >= 0; --l) {
+                    if (l < L) {
+                        f32x4 A = zero4, gr = zero4;
+                        if (!TRAIN && p.g_embs) A = ld4(p.g_embs + (size_t)l * p.B * D, off_c);
+                        if (!TRAIN && p.g_resid) gr = ld4(p.g_resid + (size_t)l * p.B * D, off_c);
+                        if (TRAIN || p.g_embsum) A = A + gs_c;
+                        A = A - G;
+                        const f32x4 commit = ((2.0f * p.beta) * (r[l] - e_c[l])) * gl_c;
+                        const f32x4 embg = (2.0f * (e_c[l] - r[l])) * gl_c;
+                        f32x4 cbv;
+                        if (MODE == RQHIP_MODE_EVAL) {
+                            cbv = A + embg;
+                            G = (gr + G) + commit;
+                        } else {
+                            G = ((gr + G) + A) + commit;
+                            cbv = embg;
+                        }
+                        if (p.g_cb && l >= p.l_begin && l < p.l_end && slot && !RQ_PROBE(4)) {   // (level test is uniform)
+                            const int li = l - p.l_begin;
+                            *reinterpret_cast<f32x4 *>(stage + ((size_t)li * R + rl) * D + 4 * ch) = cbv;
+                            if (ch == 0) keys[li * R + rl] = ok ? li * K + id_c[l] : -1;
+                        }
+                    }
                 }
+                if (ok && p.g_res0 && p.write_rows)
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.g_res0) + off_c) = G;
+
+                // ---- next step's row data and the ids after that ----------------------------------------------------------
+                row_nn = row_of(h + 2, ok_nn);
+                const unsigned off_n = row_n * rowb + chb;
+                r0_n = ld4(p.res0, off_n);
+                if (TRAIN || p.g_embsum) gs_n = ld4(p.g_embsum, off_n);
+                if (TRAIN || p.g_loss) gl_n = *reinterpret_cast<const float *>(at(p.g_loss, row_n * 4u));
+                gather(id_n, e_n);
+                load_ids(row_nn, id_nn);
+                row_c = row_n; row_n = row_nn;
+                ok_c = ok_n; ok_n = ok_nn;
+                r0_c = r0_n; gs_c = gs_n; gl_c = gl_n;
+#pragma unroll
+                for (int l = 0; l < LM; ++l) { id_c[l] = id_n[l]; id_n[l] = id_nn[l]; e_c[l] = e_n[l]; }
             }
-        }
-        if (ok && p.g_res0 && p.write_rows) *reinterpret_cast<f32x4 *>(p.g_res0 + (size_t)row_c * D + 4 * ch) = G;
-
-        // ---- next round's row data and the ids after that: in flight during the accumulation --------------------------
-        const long long row_nn = row_of(it + 2);
-        r0_n = row_n < p.B ? ld4(p.res0, row_n) : zero4;
-        gs_n = (p.g_embsum && row_n < p.B) ? ld4(p.g_embsum, row_n) : zero4;
-        gl_n = (p.g_loss && row_n < p.B) ? p.g_loss[row_n] : 0.0f;
-        gather(row_n, id_n, e_n);
-        load_ids(row_nn, id_nn);
-
-        if (p.g_cb && !RQ_PROBE(4)) {
-            __syncthreads();
-            const int items = RQ_PROBE(2) ? 0 : nl * R;
-            // Owners: half-waves (D <= 32; 32 of them) or waves (16).  Everything below is per-lane VALU + LDS work: a
-            // first version picked the rows with scalar ballot / readlane logic and was bound by the CU's one scalar
-            // unit (4.2 us per 128-row round); a second walked per-batch bit masks and paid three dependent LDS
-            // latencies per batch of 64 rows (2.8 us).  Now each wave first lists its owners' rows of the whole round
-            // (one pass over the keys), then adds them from the list with the next pair prefetched.
-            const int f = PAIR ? (lane & 31) : lane, half = PAIR ? (lane >> 5) : 0;
-            const int nown = PAIR ? 2 * kFlatWaves : kFlatWaves;
-            const int own0 = PAIR ? 2 * wave : wave;                        // this wave's first (or only) owner
-            unsigned *lists = reinterpret_cast<unsigned *>(keys + (size_t)nl * R);
+        } else if (h >= 1 && p.g_cb && !RQ_PROBE(4) && ow >= 0 && (PAIR || ow < nown)) {
+            // A first version picked the rows with scalar ballot / readlane logic and was bound by the CU's one scalar
+            // unit (4.2 us per 128 rows); a second walked per-batch bit masks and paid three dependent LDS latencies per
+            // batch of 64 rows (2.8 us).  Now each wave first lists its owners' rows of the whole step (one pass over
+            // the keys), then adds them from the list with the next pair prefetched.
+            const float *stage = stage0 + (size_t)((h - 1) & 1) * items * D;
+            const int *keys = keys0 + ((h - 1) & 1) * items;
             const unsigned *mylist = lists + (own0 + half) * kListStride;
+            const int n_items = RQ_PROBE(2) ? 0 : items;
             for (int lo = 0;; lo += kListCap) {
                 // build: every lane looks at one staged row per batch; rows of this wave's owners get their rank
-                // (rows before them in the round with the same owner) and go to slot rank - lo of the owner's list
+                // (rows before them in the step with the same owner) and go to slot rank - lo of the owner's list
                 int cnt0 = 0, cnt1 = 0;
-                for (int base = 0; base < items; base += 64) {
+                for (int base = 0; base < n_items; base += 64) {
                     const int item = base + lane;
-                    const int mykey = item < items ? keys[item] : -1;
+                    const int mykey = item < n_items ? keys[item] : -1;
                     const int own = mykey & (nown - 1);
                     const bool mine0 = mykey >= 0 && own == own0;
                     const bool mine1 = PAIR && mykey >= 0 && own == own0 + 1;
@@ -528,17 +570,11 @@ __global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const Rq
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if ((cnt0 > cnt1 ? cnt0 : cnt1) <= lo + kListCap) break;
             }
-            __syncthreads();
         }
-
-        row_c = row_n; row_n = row_nn;
-        r0_c = r0_n; gs_c = gs_n; gl_c = gl_n;
-#pragma unroll
-        for (int l = 0; l < kFusedMaxL; ++l) { id_c[l] = id_n[l]; id_n[l] = id_nn[l]; e_c[l] = e_n[l]; }
+        if (p.g_cb) __syncthreads();
     }
 
     if (p.g_cb) {
-        __syncthreads();
         float *out = partial + (size_t)blockIdx.x * LKD_total;
         for (int e = threadIdx.x * 4; e < (RQ_PROBE(8) ? 0 : tbl); e += kFlatThreads * 4)
             *reinterpret_cast<f32x4 *>(out + e) = *reinterpret_cast<const f32x4 *>(acc + e);
@@ -627,10 +663,14 @@ static int fused_levels_per_pass(int D, int K, int L) {
 
 // flat kernel (EVAL / STE): rows per workgroup and round, LDS per level of the launch, launch geometry
 static bool flat_shape_ok(int D, int L) { return D % 4 == 0 && D <= kFlatMaxD && L <= kFusedMaxL; }
-static int flat_rows(int D) { return kFlatThreads / (D / 4); }
-static size_t flat_level_bytes(int D, int K) {
+// (the flat kernel addresses rows with 32-bit byte offsets)
+static bool flat_offsets_ok(long long B, int D) {
+    return (unsigned long long)B * 8ull <= 0xffffffffull && (unsigned long long)B * D * 4ull <= 0xffffffffull;
+}
+static int flat_rows(int D) { return kFlatRowThreads / (D / 4); }
+static size_t flat_level_bytes(int D, int K) {   // one level's table + its share of the two stage buffers and key arrays
     const size_t R = flat_rows(D);
-    return (size_t)K * D * sizeof(float) + R * D * sizeof(float) + R * sizeof(int);
+    return (size_t)K * D * sizeof(float) + 2 * (R * D * sizeof(float) + R * sizeof(int));
 }
 static bool flat_fits(int D, int K, int L) {
     return flat_shape_ok(D, L) && flat_level_bytes(D, K) + kFlatListBytes <= kFusedLdsBudget;
@@ -687,7 +727,7 @@ using namespace rqhip;
 extern "C" int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int mode, int *n_wg, int *units_per_wg,
                                       int *unit_rows) {
     const bool ok = B > 0 && D >= 1 && K >= 1 && L >= 1;
-    const bool flat = ok && mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L);
+    const bool flat = ok && mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L) && flat_offsets_ok(B, D);
     const bool fused = ok && !flat && fused_fits(D, K, L);
     if (n_wg) *n_wg = flat ? flat_wgs(B, D) : fused ? fused_wgs(B) : 0;
     if (units_per_wg) *units_per_wg = flat ? 1 : fused ? kFusedWaves : 0;
@@ -742,8 +782,8 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     p.probe = getenv("RQ_BWD_PROBE") ? atoi(getenv("RQ_BWD_PROBE")) : 0;
 #endif
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L) && al16(res0) && al16(codebooks) && al16(g_embs) &&
-        al16(g_embsum) && al16(g_resid) && al16(g_res0) && al16(workspace)) {
+    if (mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L) && flat_offsets_ok(B, D) && al16(res0) && al16(codebooks) &&
+        al16(g_embs) && al16(g_embsum) && al16(g_resid) && al16(g_res0) && al16(workspace)) {
         const int R = flat_rows(D), LPR = D / 4;
         const int G = flat_wgs(B, D);
         float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
@@ -762,13 +802,19 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
                 RQ_CHECK_LAUNCH("rq_backward_flat_kernel");
                 return 0;
             };
+            // the training step's shape of upstream gradients and the two level counts of the named configurations get
+            // their own instantiations; everything else runs the generic one
+            const bool train = g_embsum && g_loss && !g_embs && !g_resid;
+            const int nlv = (train && (L == 3 || L == 4)) ? L : 0;
             int rcf;
+#define RQ_FLAT_GO(M, P)                                                                                              \
+    (nlv == 3 ? go(rq_backward_flat_kernel<M, P, 3, true>)                                                            \
+              : nlv == 4 ? go(rq_backward_flat_kernel<M, P, 4, true>) : go(rq_backward_flat_kernel<M, P, 0, false>))
             if (mode == RQHIP_MODE_EVAL)
-                rcf = D <= 32 ? go(rq_backward_flat_kernel<RQHIP_MODE_EVAL, true>)
-                              : go(rq_backward_flat_kernel<RQHIP_MODE_EVAL, false>);
+                rcf = D <= 32 ? RQ_FLAT_GO(RQHIP_MODE_EVAL, true) : RQ_FLAT_GO(RQHIP_MODE_EVAL, false);
             else
-                rcf = D <= 32 ? go(rq_backward_flat_kernel<RQHIP_MODE_STE, true>)
-                              : go(rq_backward_flat_kernel<RQHIP_MODE_STE, false>);
+                rcf = D <= 32 ? RQ_FLAT_GO(RQHIP_MODE_STE, true) : RQ_FLAT_GO(RQHIP_MODE_STE, false);
+#undef RQ_FLAT_GO
             if (rcf) return rcf;
             if (!g_codebooks) break;  // nothing to scatter: the first launch has written g_res0
             hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD,

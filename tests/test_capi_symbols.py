@@ -66,6 +66,6 @@ def test_workspace_queries():
     l = _lib.lib()
     assert l.rqhip_rq_forward_workspace_bytes(3, 256) == (3 * 256 + 3) * 4
     assert l.rqhip_rq_forward_workspace_bytes(2, 100) == (2 * 128 + 2) * 4
-    # [L,B,D] row scratch + one [L,K,D] partial table per workgroup of the widest launch (8 x 128-row units here)
-    assert l.rqhip_rq_backward_workspace_bytes(1000, 32, 3, 256) == 3 * 1000 * 32 * 4 + 8 * 3 * 256 * 32 * 4
+    # [L,B,D] row scratch + one [L,K,D] partial table per workgroup of the widest launch (16 x 64-row units here)
+    assert l.rqhip_rq_backward_workspace_bytes(1000, 32, 3, 256) == 3 * 1000 * 32 * 4 + 16 * 3 * 256 * 32 * 4
     assert l.rqhip_dedup_workspace_bytes(1000) >= 2048 * 4 + 4 * 1000 * 4
