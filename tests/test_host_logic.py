@@ -254,3 +254,22 @@ def test_bench_relaunches_itself_under_torchrun_for_multi_gpu(monkeypatch):
     assert a[-6:] == ["--gpus", "4", "--config", "c4", "--steps", "2"] and a[-7].endswith("bench.py")
     # and inside a torchrun environment it does not relaunch: the world size must simply match --gpus
     assert bench.CONFIGS["c4"]["rows"] == 1_250_000 and bench.CONFIGS["c4"]["codes"] == 1024
+
+
+def test_loss_scale_hint_nests_and_restores():
+    """rqhip.autograd.loss_scale: the hint for the speculative reconstruction-loss gradient is a plain nesting context
+    manager -- restored on exit and on exceptions (a stale value would only cost speed, but it must not leak)."""
+    from rqhip import autograd as ag
+    assert ag._LOSS_SCALE == 1.0
+    with ag.loss_scale(0.25):
+        assert ag._LOSS_SCALE == 0.25
+        with ag.loss_scale(0.5):
+            assert ag._LOSS_SCALE == 0.5
+        assert ag._LOSS_SCALE == 0.25
+    assert ag._LOSS_SCALE == 1.0
+    try:
+        with ag.loss_scale(0.1):
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert ag._LOSS_SCALE == 1.0

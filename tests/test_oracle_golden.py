@@ -115,6 +115,30 @@ def test_rq_stack_codebook_gradients(name):
         _rel_close(g_cb[l], g[f"train_grad::layers.{l}.embedding.weight"], rtol=1e-4, atol=1e-7)
 
 
+def test_ordered_codebook_gradient_is_a_reordering_of_the_plain_one():
+    """rqo_rq_backward_ordered (the restatement of the HIP kernels' fixed summation order, parameterised by the geometry
+    rqhip_rq_backward_plan reports): one workgroup with one whole-batch unit IS the plain ascending-row sum, any other
+    geometry differs from it by fp32 rounding only, g_res0 never changes, and the result is a function of the geometry."""
+    rng = np.random.default_rng(3)
+    B, D, K, L = 1000, 32, 64, 3
+    x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, D)) * 0.4).astype(np.float32)
+    ids = o.rq_forward(x, cbs, o.MODE_STE, 0.25)["ids"]
+    g = dict(g_embsum=(rng.standard_normal((B, D)) / B).astype(np.float32), g_loss=rng.random(B).astype(np.float32))
+    r_res0, r_cb = o.rq_backward(x, cbs, o.MODE_STE, 0.25, ids, **g)
+    one_res0, one_cb = o.rq_backward(x, cbs, o.MODE_STE, 0.25, ids, order=(1, 1, B), **g)
+    assert np.array_equal(one_res0, r_res0) and np.array_equal(one_cb, r_cb)
+    seen = []
+    for order in ((4, 8, 32), (16, 1, 64), (7, 1, 128), (256, 1, 64)):
+        o_res0, o_cb = o.rq_backward(x, cbs, o.MODE_STE, 0.25, ids, order=order, **g)
+        assert np.array_equal(o_res0, r_res0)
+        np.testing.assert_allclose(o_cb, r_cb, rtol=1e-5, atol=1e-6 * float(np.abs(r_cb).max()))
+        again = o.rq_backward(x, cbs, o.MODE_STE, 0.25, ids, order=order, **g)[1]
+        assert np.array_equal(again, o_cb)
+        seen.append(o_cb)
+    assert any(not np.array_equal(seen[0], s) for s in seen[1:])   # the order matters at the last bit
+
+
 @pytest.mark.parametrize("name", _names("kmeans_*.npz"))
 def test_kmeans_matches_reference(name):
     g = load_golden(name)
