@@ -161,12 +161,19 @@ def parity_gate(device, tag):
     out["kernel_level"] = parity.summary(cmp, {"input": "regenerable latents (bits verified)" if ok_bits else
                                                "regenerable latents (BITS DIFFER FROM FIXTURE)",
                                                "loss_max_abs_err": float(f"{lerr:.3e}")})
+    # (1a) the product launch (no margins: for D = 32 the filtered bf16-split scan with exact re-checks) must return the
+    # very ids and losses of the all-fp32 margin kernel above, on every row and on the hard rows below
+    kp = ops.rq_forward(torch.from_numpy(z).to(device), cbs, ops.MODE_EVAL, beta, want_embs=False, want_residuals=False)
+    same = bool(torch.equal(kp.ids, k.ids) and torch.equal(kp.loss, k.loss))
     # (1b) the reference's own encoder-output bits for its 2048 closest calls
     h = ops.rq_forward(torch.from_numpy(fx["hard_res0"]).to(device), cbs, ops.MODE_EVAL, beta, want_margin=True,
                        want_embs=False, want_residuals=False)
     href = parity.reference_ids(fx, False)[fx["hard_rows"]]
     hcmp = parity.compare_ids(h.ids.t().cpu().numpy(), href, h.tie_margin.cpu().numpy(), parity.TAU_KERNEL)
     out["kernel_level_hard_rows"] = parity.summary(hcmp, {"input": "reference res0 bits of the 2048 smallest-margin rows"})
+    hp = ops.rq_forward(torch.from_numpy(fx["hard_res0"]).to(device), cbs, ops.MODE_EVAL, beta, want_embs=False,
+                        want_residuals=False)
+    same = same and bool(torch.equal(hp.ids, h.ids) and torch.equal(hp.loss, h.loss))
 
     # (2) end to end from the 768-d items through the GPU encoder GEMMs (res0 differs from MKL's in the last bits)
     model = parity.build_fixture_model(fx, device)
@@ -177,6 +184,8 @@ def parity_gate(device, tag):
         model.train(training)
         with torch.no_grad():
             r = ops.rq_forward(model.encode(x), cbs, mode, beta, want_margin=True, want_embs=False, want_residuals=False)
+            rp = ops.rq_forward(model.encode(x), cbs, mode, beta, want_embs=False, want_residuals=False)   # product launch
+        same = same and bool(torch.equal(rp.ids, r.ids) and torch.equal(rp.loss, r.loss))
         refi = parity.reference_ids(fx, training)
         c = parity.compare_ids(r.ids.t().cpu().numpy(), refi, r.tie_margin.cpu().numpy(), parity.TAU_E2E)
         p = "train" if training else "eval"
@@ -194,6 +203,7 @@ def parity_gate(device, tag):
         f"{abs(float(losses.reconstruction_loss) - float(fx['train_reconstruction_loss'])):.3e}")
     e2e["quantize_loss_max_abs_err"] = float(f"{worst_loss:.3e}")
     out["end_to_end"] = e2e
+    out["product_kernel_equals_margin_kernel"] = same   # ids and losses, bit for bit, kernel level + hard rows + end to end
     # headline fields
     out["ids_exact_rate"] = min(e2e["eval"]["ids_exact_rate"], e2e["train"]["ids_exact_rate"])
     out["mismatches"] = e2e["eval"]["mismatches"] + e2e["train"]["mismatches"]
@@ -201,7 +211,7 @@ def parity_gate(device, tag):
                                          and cmp["all_mismatches_flagged"] and hcmp["all_mismatches_flagged"])
     out["loss_max_abs_err"] = max(worst_loss, lerr, e2e["train_step_loss_abs_err"])
     out["pass"] = bool(out["all_mismatches_flagged"] and out["loss_max_abs_err"] <= 1e-5
-                       and cmp["mismatches"] <= cmp["rows_flagged"])
+                       and cmp["mismatches"] <= cmp["rows_flagged"] and same)
     del model
     return out
 

@@ -198,6 +198,72 @@ __device__ __forceinline__ void stage_codes(float *buf0, int buf_floats, int nbu
     }
 }
 
+// ---- bf16-split image for the filtered scan (FILT kernels, D = 32) ---------------------------------------------
+// Only the ARGMIN of the distances is an output; ids, the gathered codeword and the loss are computed from it exactly.
+// The FILT kernels therefore scan with approximate distances -- x = xh + xl + (rest), c = ch + cl + (rest) in bf16,
+// x.c ~ xh.ch + xh.cl + xl.ch as three chains of v_mfma_f32_32x32x16_bf16 (fp32 accumulation; products of bf16 are
+// exact in fp32) on the matrix cores proper, which run 5x faster than the f32-input form and beside the VALU epilogue
+// instead of sharing its datapath -- and hand every row whose two smallest approximate distances are closer than a
+// bound on the approximation error to the exact scan below (slow_argmin_row, the oracle's fp32 chain).  Same ids, bit
+// for bit; see rq_tile for the bound.
+// buffer = [image: 8 blocks of Kc 16-byte elements][csq: Kc floats]  (as large as the fp32 image)
+//   block (plane * 2 + s) * 2 + h, element c = 8 bf16: j-th = plane (hi / lo) of C[kbase + c][d = 2 (8 s + j) + h]
+// i.e. lane (il, h) finds, for K-step s, the same features 2 kk + h, kk = 8 s + j, that its row registers r[kk] hold.
+typedef __bf16 rq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rq_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void bf16_split(float v, __bf16 &hi, __bf16 &lo) {
+    hi = (__bf16)v;                    // round to nearest even
+    lo = (__bf16)(v - (float)hi);      // exact difference, rounded again: |v - hi - lo| <= 2^-18 |v|
+}
+
+template <int NT>
+__device__ __forceinline__ void stage_codes_bf16(float *buf0, int buf_floats, int nbuf, const float *__restrict__ cb0,
+                                                 const float *__restrict__ csq0, int csq_stride, int kbase, int Kc, int K) {
+    constexpr int D = 32, d4n = D / 4, cstep = NT / d4n;
+    const int tid = threadIdx.x;
+    const int d4 = tid & (d4n - 1);
+    const int s_blk = d4 >> 2, j0 = 2 * (d4 & 3);
+    int c = tid / d4n, bi = 0;
+    while (c >= Kc) { c -= Kc; ++bi; }
+    while (bi < nbuf) {
+        f32x4 v[kStageBatch];
+        int cc[kStageBatch], bb[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) {
+            cc[u] = c; bb[u] = bi;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int k = kbase + c;
+            if (bi < nbuf && k < K) v[u] = *reinterpret_cast<const f32x4 *>(cb0 + (bi * K + k) * D + 4 * d4);
+            c += cstep;
+            while (c >= Kc && bi < nbuf) { c -= Kc; ++bi; }
+        }
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) {
+            if (bb[u] < nbuf) {
+                __bf16 *img = reinterpret_cast<__bf16 *>(buf0 + bb[u] * buf_floats);
+                __bf16 hx, lx, hy, ly, hz, lz, hw, lw;
+                bf16_split(v[u].x, hx, lx); bf16_split(v[u].y, hy, ly);
+                bf16_split(v[u].z, hz, lz); bf16_split(v[u].w, hw, lw);
+                auto at = [&](int plane, int h) { return img + ((size_t)(((plane * 2 + s_blk) * 2 + h) * Kc + cc[u])) * 8 + j0; };
+                *reinterpret_cast<rq_bf16x2 *>(at(0, 0)) = rq_bf16x2{hx, hz};   // features 4 d4, 4 d4 + 2 (h = 0)
+                *reinterpret_cast<rq_bf16x2 *>(at(0, 1)) = rq_bf16x2{hy, hw};   // features 4 d4 + 1, 4 d4 + 3 (h = 1)
+                *reinterpret_cast<rq_bf16x2 *>(at(1, 0)) = rq_bf16x2{lx, lz};
+                *reinterpret_cast<rq_bf16x2 *>(at(1, 1)) = rq_bf16x2{ly, lw};
+            }
+        }
+    }
+    {
+        int c2 = tid, b2 = 0;
+        while (c2 >= Kc) { c2 -= Kc; ++b2; }
+        while (b2 < nbuf) {
+            buf0[b2 * buf_floats + 32 * Kc + c2] = (kbase + c2 < K) ? csq0[b2 * csq_stride + kbase + c2] : __builtin_inff();
+            c2 += NT;
+            while (c2 >= Kc && b2 < nbuf) { c2 -= Kc; ++b2; }
+        }
+    }
+}
+
 // ---- exact torch.min semantics for rows whose distances may be non-finite (rare) ----------------------
 // Wave-cooperative: every lane scans codes k = lane, lane+64, ...; result = index of the first NaN
 // distance if any, else the first index of the minimum (quantize.py:128 / ATen min kernel).
@@ -223,6 +289,57 @@ __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, 
             if (2 * kk + 1 < D) acc = __builtin_fmaf(x1[kk], c[2 * kk + 1], acc);
         }
         const float t = xsq_j + csq_l[k];
+        const float dist = t - 2.0f * acc;
+        if (dist != dist) {
+            nanidx = min(nanidx, k);
+        } else if (dist < lbest || (dist == lbest && k < lidx)) {
+            lbest = dist;
+            lidx = k;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int on = __shfl_xor(nanidx, m, 64);
+        const float ob = __shfl_xor(lbest, m, 64);
+        const int oi = __shfl_xor(lidx, m, 64);
+        nanidx = min(nanidx, on);
+        if (ob < lbest || (ob == lbest && oi < lidx)) {
+            lbest = ob;
+            lidx = oi;
+        }
+    }
+    return nanidx != 0x7fffffff ? nanidx : lidx;
+}
+
+// The same scan for D = 32 with every code row fetched as eight 16-byte loads (the dword version above is latency-bound:
+// 32 dependent-issue loads per code).  The filtered kernels call it for ~0.4 % of the rows, so it has to be cheap; the
+// FMA chain runs over d = 0, 1, 2, ... exactly as above.
+__device__ __forceinline__ int slow_argmin_row32(const float (&r)[16], int j, float xsq_j, const float *__restrict__ cb_l,
+                                                 const float *__restrict__ csq_l, int K) {
+    const int lane = threadIdx.x & 63;
+    float x0[16], x1[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        x0[kk] = __shfl(r[kk], j, 64);
+        x1[kk] = __shfl(r[kk], j + 32, 64);
+    }
+    int nanidx = 0x7fffffff, lidx = 0x7fffffff;
+    float lbest = __builtin_inff();
+    for (int k = lane; k < K; k += 64) {
+        const f32x4 *c = reinterpret_cast<const f32x4 *>(cb_l + (size_t)k * 32);
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = c[q];
+        const float cs = csq_l[k];
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc = __builtin_fmaf(x0[2 * q], v[q].x, acc);
+            acc = __builtin_fmaf(x1[2 * q], v[q].y, acc);
+            acc = __builtin_fmaf(x0[2 * q + 1], v[q].z, acc);
+            acc = __builtin_fmaf(x1[2 * q + 1], v[q].w, acc);
+        }
+        const float t = xsq_j + cs;
         const float dist = t - 2.0f * acc;
         if (dist != dist) {
             nanidx = min(nanidx, k);
@@ -374,6 +491,78 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
     }
 }
 
+// The filtered scan of Kc staged codes (see stage_codes_bf16): same (best, index, runner-up) tournament as
+// scan_codes<16, true>, on distances whose dot product is the three-term bf16 split.
+__device__ __forceinline__ void scan_codes_bf16(const rq_bf16x8 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
+                                                int kbase, int il, int h, const rq_bf16x8 (&xh)[2],
+                                                const rq_bf16x8 (&xl)[2], float xsq, float &best, int &bidx,
+                                                float &second, int t_begin = 0, int t_step = 1) {
+    const int ntiles = Kc / 32;
+    const f32x2 xsq2 = {xsq, xsq};
+    auto lda = [&](int t, int blk) { return img[(size_t)(blk * 2 + h) * Kc + t * 32 + il]; };   // blk = plane * 2 + s
+    const int t0 = t_begin < ntiles ? t_begin : 0;
+    rq_bf16x8 a0 = lda(t0, 0), a1 = lda(t0, 1), a2 = lda(t0, 2), a3 = lda(t0, 3);
+    for (int t = t_begin; t < ntiles; t += t_step) {
+        const int tn = (t + t_step < ntiles) ? t + t_step : t;
+        const float *cq = csq_s + t * 32 + 4 * h;
+        f32x4 c4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c4[g] = *reinterpret_cast<const f32x4 *>(cq + 8 * g);
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xh[0], acc, 0, 0, 0);   // ch . xh
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xh[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xh[0], acc, 0, 0, 0);   // cl . xh
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xh[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xl[0], acc, 0, 0, 0);   // ch . xl
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xl[1], acc, 0, 0, 0);
+        // the next tile's code operands, into the same registers: in flight during the VALU epilogue below
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = lda(tn, 0); a1 = lda(tn, 1); a2 = lda(tn, 2); a3 = lda(tn, 3);
+        f32x2 dp[8];
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr)
+            dp[pr] = rq_pk_add(xsq2, f32x2{c4[pr >> 1][2 * (pr & 1)], c4[pr >> 1][2 * (pr & 1) + 1]});
+        float d[16];
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const f32x2 v = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, f32x2{acc[2 * pr], acc[2 * pr + 1]}, dp[pr]);
+            d[2 * pr] = v.x;
+            d[2 * pr + 1] = v.y;
+        }
+        // (min, runner-up) tree and top-down walk for the index: see scan_codes
+        float lo1[8], hi1[8], lo2[4], hi2[4], hi3a, hi3b, t2, a07, b07, tmin;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            lo1[i] = rq_min(d[2 * i], d[2 * i + 1]);
+            hi1[i] = rq_max(d[2 * i], d[2 * i + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rq_merge2(lo1[2 * i], hi1[2 * i], lo1[2 * i + 1], hi1[2 * i + 1], lo2[i], hi2[i]);
+        rq_merge2(lo2[0], hi2[0], lo2[1], hi2[1], a07, hi3a);
+        rq_merge2(lo2[2], hi2[2], lo2[3], hi2[3], b07, hi3b);
+        rq_merge2(a07, hi3a, b07, hi3b, tmin, t2);
+        const float a01 = lo1[0], a45 = lo1[2], b01 = lo1[4], b45 = lo1[6];
+        const float a03 = lo2[0], a47 = lo2[1], b03 = lo2[2], b47 = lo2[3];
+        (void)a47; (void)b47;
+        second = rq_min3(second, t2, rq_max(best, tmin));
+        const bool c3 = a07 != tmin;
+        const float q03 = c3 ? b03 : a03;
+        const bool c2 = q03 != tmin;
+        const float s01 = c3 ? b01 : a01, s45 = c3 ? b45 : a45;
+        const float p01 = c2 ? s45 : s01;
+        const bool c1 = p01 != tmin;
+        const float u0a = c3 ? d[8] : d[0], u2a = c3 ? d[10] : d[2], u4a = c3 ? d[12] : d[4], u6a = c3 ? d[14] : d[6];
+        const float u0 = c2 ? u4a : u0a, u2 = c2 ? u6a : u2a;
+        const float e0 = c1 ? u2 : u0;
+        const bool c0 = e0 != tmin;
+        const int slot = (c3 ? 16 : 0) | (c2 ? 8 : 0) | (c1 ? 2 : 0) | (c0 ? 1 : 0);
+        const int cand = kbase + t * 32 + 4 * h + slot;
+        const bool better = tmin < best;
+        best = better ? tmin : best;
+        bidx = better ? cand : bidx;
+    }
+}
+
 // One 32-row tile through all L levels.
 //   COOP = false: the calling wave owns the tile and scans every staged code itself.
 //   COOP = true : the first kCoopWaves (4: one per SIMD) waves of the workgroup work on the SAME tile: wave w scans code
@@ -385,10 +574,14 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
 //                 would leave most SIMDs empty, and (b) for the partly filled last round of a big batch, whose
 //                 tiles would otherwise each put a whole extra tile on one SIMD (+17 us for 53 of 3125 tiles).
 // FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
-template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN>
+// FILT (KSTEPS = 16, FULLD): the scan runs on the bf16-split image (stage_codes_bf16 / scan_codes_bf16) and rows that are
+//       too close to call go through the exact scan; never together with MARGIN (the margins are exact quantities).
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN, bool FILT>
 __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
                                         long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase) {
     constexpr int KQ = KSTEPS / 4;
+    constexpr bool TRACK2 = MARGIN || FILT;   // the runner-up distance is tracked
+    static_assert(!FILT || (KSTEPS == 16 && FULLD && !MARGIN), "filtered scan: D = 32 only, no margins");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int il = lane & 31, h = lane >> 5;
     const int K = p.K, Kc = p.Kc, L = p.L;
@@ -419,19 +612,41 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
 
         float best = __builtin_inff(), second = __builtin_inff();
         int bidx = 0x7fffffff;
+        // filtered scan: this level's input rows as bf16 hi / lo planes, K-step s = features 2 (8 s + j) + h
+        rq_bf16x8 xh[2], xl[2];
+        if constexpr (FILT) {
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 hi, lo;
+                    bf16_split(r[8 * sx + j], hi, lo);
+                    xh[sx][j] = hi;
+                    xl[sx][j] = lo;
+                }
+        }
 
         const float *buf = smem + (p.resident ? l * buf_floats : 0);
         for (int ch = 0; ch < p.nchunks; ++ch) {
             const int kbase = ch * Kc;
             if (!p.resident) {
                 __syncthreads();  // previous chunk fully consumed
-                stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
-                                        kbase, Kc, K, D);
+                if constexpr (FILT)
+                    stage_codes_bf16<NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
+                                         kbase, Kc, K);
+                else
+                    stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
+                                            kbase, Kc, K, D);
                 __syncthreads();
             }
-            if (active)
-                scan_codes<KSTEPS, MARGIN>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, r,
-                                           xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
+            if (active) {
+                if constexpr (FILT)
+                    scan_codes_bf16(reinterpret_cast<const rq_bf16x8 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, xh, xl,
+                                    xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
+                else
+                    scan_codes<KSTEPS, MARGIN>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h,
+                                               r, xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
+            }
         }
 
         RQ_STAMP(3 + 8 * l);
@@ -440,7 +655,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         if (active) {
             const float ob = shfl_xor32(best);
             const int oi = shfl_xor32(bidx);
-            if (MARGIN) second = rq_min3(second, shfl_xor32(second), rq_max(best, ob));
+            if (TRACK2) second = rq_min3(second, shfl_xor32(second), rq_max(best, ob));
             if (ob < best || (ob == best && oi < bidx)) {
                 best = ob;
                 bidx = oi;
@@ -458,7 +673,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             if (h == 0) {
                 cv[wave * 32 + il] = best;
                 ci[wave * 32 + il] = bidx;
-                if (MARGIN) c2[wave * 32 + il] = second;
+                if (TRACK2) c2[wave * 32 + il] = second;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             // (counters are never reset: the r-th reuse of a slot waits for kCoopWaves * (r + 1))
@@ -474,7 +689,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             for (int w = 0; w < kCoopWaves; ++w) {
                 const float ov = cv[w * 32 + il];
                 const int oi = ci[w * 32 + il];
-                if (MARGIN) second = rq_min3(second, c2[w * 32 + il], rq_max(best, ov));
+                if (TRACK2) second = rq_min3(second, c2[w * 32 + il], rq_max(best, ov));
                 if (ov < best || (ov == best && oi < bidx)) {
                     best = ov;
                     bidx = oi;
@@ -487,7 +702,23 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             // rows whose distances can be Inf/NaN take torch's exact scan
             // fast path only when no distance term can overflow (then fma(-2,acc,tt) == tt - 2*acc exactly)
             const float guard = xsq + csqmax_l;
-            const bool bad = !(guard < 1.0e38f);
+            bool bad = !(guard < 1.0e38f);
+            if constexpr (FILT) {
+                // Too close to call?  |d~ - d| for any code, d the oracle's fp32 distance and d~ the scanned one, is at
+                // most 2 |x.c - (xh.ch + xh.cl + xl.ch)| + rounding: the dropped terms are <= 3 * 2^-18 sum|x_d c_d|, the
+                // fp32 accumulation of 96 exact products <= ~2^-16.4 sum|x_d c_d|, the oracle's own chain 2^-19; with
+                // sum|x_d c_d| <= |x| |c| that is < 2^-14.5 |x| |c| (measured maximum on config-2-like data: 2^-16.3,
+                // tools/bf16_filter_study.py).  The argmin of d~ is the argmin of d whenever the two smallest d~ differ
+                // by more than twice that; the test uses 2^-12 |x| max|c| (2.8 times the bound, 20 times the measured maximum) and also sends rows of
+                // vanishing magnitude (bf16 denormals may be flushed) and any NaN to the exact scan.
+                const float scale2 = xsq * csqmax_l;
+                const float T = 2.4414062e-4f * __builtin_sqrtf(scale2);   // 2^-12
+#ifndef RQ_FILT_NOSLOW   // (developer timing build, tools/ab_build.sh: how fast is the scan without its exact re-checks?)
+                bad = bad || !((second - best) > T) || !(scale2 > 1.0e-30f);
+#else
+                (void)T;
+#endif
+            }
             unsigned long long badmask = __ballot(bad) & 0xffffffffull;
             if (badmask) {
                 const float *cb_l = p.cb + (size_t)l * K * D;
@@ -496,7 +727,9 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                     const int j = __builtin_ctzll(badmask);
                     badmask &= badmask - 1;
                     const float xj = __shfl(xsq, j, 64);
-                    const int res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
+                    int res;
+                    if constexpr (FILT) res = slow_argmin_row32(r, j, xj, cb_l, csq_l, K);
+                    else res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
                     if (il == j) bidx = res;
                 }
             }
@@ -512,7 +745,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             // codeword gather (quantize.py:101-102) for this lane's feature parity: from the staged LDS image
             // when the whole level is resident, else from global memory (L2)
             float e[KSTEPS];
-            if (p.resident) {
+            if (p.resident && !FILT) {
                 const f32x4 *img = reinterpret_cast<const f32x4 *>(buf) + h * Kc + bidx;
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
@@ -593,7 +826,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
     RQ_STAMP(101);
 }
 
-template <int KSTEPS, int MODE, bool FULLD, int NT, bool MARGIN>
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool MARGIN, bool FILT = false>
 __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *smem = reinterpret_cast<float *>(smem_raw);
@@ -650,7 +883,10 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
     if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 2 * kCoopCandFloats)[tid] = 0;
     RQ_STAMP(200);
-    if (p.resident) stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
+    if (p.resident) {
+        if constexpr (FILT) stage_codes_bf16<NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K);
+        else stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
+    }
     RQ_STAMP(201);
     __syncthreads();
     RQ_STAMP(202);
@@ -666,7 +902,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
         float r[KSTEPS];
         unpack_rows(rn, r);
         if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
-        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
+        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN, FILT>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
         RQ_TRACE(trace_slot);
         ++trace_slot;
     }
@@ -679,7 +915,7 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
             float raw[KSTEPS], r[KSTEPS];
             load_rows(tile, raw);
             unpack_rows(raw, r);
-            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
+            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN, FILT>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
             phase += L;
             RQ_TRACE(trace_slot);
             ++trace_slot;
@@ -725,6 +961,18 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool full = p.D == 2 * KSTEPS && al16(p.res0) && al16(p.embs) && al16(p.residuals) && al16(p.emb_sum);
     const bool margin = p.tie_margin != nullptr;
+    // D = 32, aligned rows, no margins wanted: the filtered scan (bf16-split matrix products + exact scan of the rows that
+    // are too close to call).  RQ_NO_FILTER=1 keeps the all-fp32 scan (developer A/B switch, read once).
+    static const bool use_filter = getenv("RQ_NO_FILTER") == nullptr;
+    if constexpr (KSTEPS == 16) {
+        if (full && !margin && use_filter) {
+            switch (mode) {
+                case RQHIP_MODE_EVAL: return go(rq_forward_kernel<16, RQHIP_MODE_EVAL, true, NT, false, true>);
+                case RQHIP_MODE_STE: return go(rq_forward_kernel<16, RQHIP_MODE_STE, true, NT, false, true>);
+                case RQHIP_MODE_ROTATION: return go(rq_forward_kernel<16, RQHIP_MODE_ROTATION, true, NT, false, true>);
+            }
+        }
+    }
 #define RQ_GO(MODE_)                                                                                              \
     return margin ? (full ? go(rq_forward_kernel<KSTEPS, MODE_, true, NT, true>)                                  \
                           : go(rq_forward_kernel<KSTEPS, MODE_, false, NT, true>))                                \

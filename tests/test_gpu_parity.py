@@ -161,6 +161,53 @@ def test_forward_full_size_properties(B, D, K, L, mode):
     assert torch.equal(plain.ids.cpu(), ids) and torch.equal(plain.loss.cpu(), out.loss.cpu())
 
 
+@pytest.mark.parametrize("flavour", ["random", "clustered", "near_duplicate_codes", "tiny_scale", "mixed_scale"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_filtered_scan_returns_the_fp32_scan(flavour, mode):
+    """D = 32 launches without margins scan with bf16-split matrix products and re-check, exactly, every row whose two
+    smallest approximate distances are closer than the error bound (csrc/rq_forward.hip, FILT).  The all-fp32 kernel
+    (selected by asking for margins, itself bit-exact vs the oracle in the tests above) must be reproduced bit for bit
+    -- ids, losses, sums -- on many rows, including data built to sit on the decision boundaries."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(100 + mode)
+    B, D, K, L = 300_000, 32, 256, 3
+    if flavour == "random":
+        x = torch.randn(B, D, generator=g) * 0.5
+        cb = torch.randn(L, K, D, generator=g) * 0.3
+    elif flavour == "clustered":          # codebook = perturbed data points: many rows close to two codes
+        x = torch.randn(B, D, generator=g) * 0.5
+        cb = torch.stack([x[torch.randperm(B, generator=g)[:K]] / (l + 1) + 0.02 * torch.randn(K, D, generator=g)
+                          for l in range(L)])
+    elif flavour == "near_duplicate_codes":   # every code has a twin a few ulps away: every row is a near tie
+        x = torch.randn(B, D, generator=g) * 0.5
+        half = torch.randn(L, K // 2, D, generator=g) * 0.3
+        twin = half * (1.0 + 3e-7 * torch.randn(L, K // 2, D, generator=g))
+        cb = torch.cat([half, twin], dim=1)
+        B = 40_000                          # (all rows take the exact path)
+        x = x[:B]
+    elif flavour == "tiny_scale":           # |x|^2 max|c|^2 underflows: the bound is meaningless, every row goes exact
+        B = 40_000
+        x = torch.randn(B, D, generator=g) * 1e-18
+        cb = torch.randn(L, K, D, generator=g) * 1e-18
+    else:                                   # rows and codes spread over twelve orders of magnitude
+        B = 40_000
+        x = torch.randn(B, D, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (B, 1), generator=g).float())
+        cb = torch.randn(L, K, D, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (L, K, 1), generator=g).float())
+    x, cb = x.cuda().contiguous(), cb.cuda().contiguous()
+    ref = ops.rq_forward(x, cb, mode, 0.25, want_margin=True, want_embs=False, want_residuals=False)
+    got = ops.rq_forward(x, cb, mode, 0.25, want_embs=False, want_residuals=False)
+    assert torch.equal(got.ids, ref.ids), int((got.ids != ref.ids).sum())
+    assert torch.equal(got.loss.view(torch.int32), ref.loss.view(torch.int32))
+    assert torch.equal(got.emb_sum.view(torch.int32), ref.emb_sum.view(torch.int32))
+    # the K = 1024, four-level shape of configuration 4 (staged in chunks, workgroup-wide barriers around the re-checks)
+    if flavour in ("random", "clustered") and mode == 1:
+        cb4 = (torch.randn(4, 1024, D, generator=g) * 0.3).cuda()
+        x4 = x[:125_000]
+        ref = ops.rq_forward(x4, cb4, mode, 0.25, want_margin=True, want_embs=False, want_residuals=False)
+        got = ops.rq_forward(x4, cb4, mode, 0.25, want_embs=False, want_residuals=False)
+        assert torch.equal(got.ids, ref.ids) and torch.equal(got.loss.view(torch.int32), ref.loss.view(torch.int32))
+
+
 # ---------------------------------------------------------------- backward ---------------------------
 
 def _bwd_order(B, D, L, K, mode):
