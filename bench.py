@@ -50,6 +50,7 @@ CONFIGS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA == fp32 vector peak
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (v_mfma_f32_32x32x16_bf16), same guide
 
 
 def _free_port() -> int:
@@ -380,11 +381,21 @@ def main():
             "config": {"workload": workload, "name": args.config, "rows_per_gpu_per_step": B, "micro_batch_rows": micro,
                        "levels": LEVELS, "codebook_size": CODES, "embed_dim": EMBED,
                        "parallelism": f"row-shard x{world}, 1 flat grad all-reduce per step (RCCL)"},
-            "roofline": {"kernel": f"rq_forward_kernel<16,STE> ({LEVELS}x{CODES}, {Bm} rows/launch)", "bound": "mfma",
+            "roofline": {"kernel": f"rq_forward_kernel<16,STE,filtered> ({LEVELS}x{CODES}, {Bm} rows/launch)", "bound": "mfma",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "launch_ms_mean": round(mean_ms, 5),
                          "launches": len(kernel_ms), "flops_per_row": flops_per_row,
+                         "scan": {"arithmetic": "distances from a 3-term bf16 split of the fp32 operands on "
+                                                "v_mfma_f32_32x32x16_bf16 (fp32 accumulate), exact fp32 FMA-chain re-check of "
+                                                "every row whose two smallest approximate distances are within the error bound; "
+                                                "ids, losses and outputs bit-identical to the all-fp32 kernel "
+                                                "(parity.product_kernel_equals_margin_kernel); `achieved` and `frac` price the "
+                                                "ALGORITHMIC fp32 FLOPs against the fp32 MFMA peak",
+                                  "issued_bf16_tflops": round(3 * LEVELS * 2 * EMBED * CODES * Bm / (mean_ms * 1e-3) / 1e12, 2),
+                                  "frac_of_bf16_peak": round(3 * LEVELS * 2 * EMBED * CODES * Bm / (mean_ms * 1e-3) / 1e12
+                                                             / PEAK_BF16_MFMA_TFLOPS, 4),
+                                  "all_fp32_kernel": "RQ_NO_FILTER=1 (0.48 of the fp32 peak at this size)"},
                          "hbm_view": {"algorithmic_bytes_per_row": bytes_per_row,
                                       "achieved_GBps": round(bytes_per_row * Bm / (mean_ms * 1e-3) / 1e9, 1),
                                       "peak_GBps": PEAK_HBM_GBPS},
