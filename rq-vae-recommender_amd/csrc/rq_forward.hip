@@ -28,6 +28,10 @@
 //     their argmin candidates through LDS -- for small batches (<= 4 row tiles per CU) and for the partly filled
 //     last round of a big batch.
 //
+//   * filtered scan (FILT, D = 32 without margins): the distances of the scan come from a 3-term bf16 split of the fp32
+//     operands on v_mfma_f32_32x32x16_bf16; rows whose two smallest approximate distances are within the error bound
+//     are re-scanned exactly.  Same ids as the fp32 scan, bit for bit (see stage_codes_bf16 / rq_tile).
+//
 // Arithmetic is bit-identical to oracle/rq_oracle.c (tests/test_gpu_parity.py).
 #include "rqhip_common.h"
 #include <stdlib.h>
