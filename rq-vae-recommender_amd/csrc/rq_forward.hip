@@ -713,10 +713,14 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 // fp32 accumulation of 96 exact products <= ~2^-16.4 sum|x_d c_d|, the oracle's own chain 2^-19; with
                 // sum|x_d c_d| <= |x| |c| that is < 2^-14.5 |x| |c| (measured maximum on config-2-like data: 2^-16.3,
                 // tools/bf16_filter_study.py).  The argmin of d~ is the argmin of d whenever the two smallest d~ differ
-                // by more than twice that; the test uses 2^-12 |x| max|c| (2.8 times the bound, 20 times the measured maximum) and also sends rows of
+                // by more than twice that (plus one ulp of d); the test uses 2^-12 |x| max|c| (2.8 times the bound, 20 times the measured
+                // maximum) + 2^-20 (|x|^2 + max|c|^2) and also sends rows of
                 // vanishing magnitude (bf16 denormals may be flushed) and any NaN to the exact scan.
                 const float scale2 = xsq * csqmax_l;
-                const float T = 2.4414062e-4f * __builtin_sqrtf(scale2);   // 2^-12
+                // (second term: the final rounding of d and d~ themselves, half an ulp of |d| <= 2 (|x|^2 + max|c|^2) each
+                // -- it dominates when the row is much larger than every code or the reverse, where neighbouring codes'
+                // distances differ by a few ulps only)
+                const float T = 2.4414062e-4f * __builtin_sqrtf(scale2) + 9.5367432e-7f * guard;   // 2^-12, 2^-20
 #ifndef RQ_FILT_NOSLOW   // (developer timing build, tools/ab_build.sh: how fast is the scan without its exact re-checks?)
                 bad = bad || !((second - best) > T) || !(scale2 > 1.0e-30f);
 #else

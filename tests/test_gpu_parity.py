@@ -161,7 +161,8 @@ def test_forward_full_size_properties(B, D, K, L, mode):
     assert torch.equal(plain.ids.cpu(), ids) and torch.equal(plain.loss.cpu(), out.loss.cpu())
 
 
-@pytest.mark.parametrize("flavour", ["random", "clustered", "near_duplicate_codes", "tiny_scale", "mixed_scale"])
+@pytest.mark.parametrize("flavour", ["random", "clustered", "near_duplicate_codes", "tiny_scale", "mixed_scale",
+                                     "rows_dwarf_codes", "codes_dwarf_rows"])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_filtered_scan_returns_the_fp32_scan(flavour, mode):
     """D = 32 launches without margins scan with bf16-split matrix products and re-check, exactly, every row whose two
@@ -189,6 +190,13 @@ def test_filtered_scan_returns_the_fp32_scan(flavour, mode):
         B = 40_000
         x = torch.randn(B, D, generator=g) * 1e-18
         cb = torch.randn(L, K, D, generator=g) * 1e-18
+    elif flavour in ("rows_dwarf_codes", "codes_dwarf_rows"):
+        # |x| >> every |c| (or the reverse): all distances of a row agree in their leading digits, neighbouring codes
+        # differ by a few ulps of the distance itself -- the fp32 rounding of d decides, not the dot-product error
+        B = 100_000
+        big, small = (1.0e5, 1.0) if flavour == "rows_dwarf_codes" else (1.0, 1.0e5)
+        x = torch.randn(B, D, generator=g) * big
+        cb = torch.randn(L, K, D, generator=g) * small
     else:                                   # rows and codes spread over twelve orders of magnitude
         B = 40_000
         x = torch.randn(B, D, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (B, 1), generator=g).float())
