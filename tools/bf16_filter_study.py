@@ -55,3 +55,24 @@ for e in (-13,-12.5,-12,-11.5,-11,-10.5):
     flagged=gap<=T
     bad=((ids!=ida)&~flagged).sum()
     print(f"T=2^{e} sqrt(xsq csqmax): flagged {flagged.mean()*100:.3f}% rows, unflagged mismatches {bad}")
+
+# ---- second regime: rows much larger than every code (or the reverse) ------------------------------------------------
+# All distances of a row share their leading digits; the final rounding of d (half an ulp of ~|x|^2) decides between
+# neighbouring codes, so the threshold needs its 2^-20 (|x|^2 + max|c|^2) term.
+print("\nrows 1e5 x larger than the codes:")
+xb = (rng.standard_normal((B, D)) * 1e5).astype(np.float32)
+cbb = rng.standard_normal((K, D)).astype(np.float32)
+xhb = bf16(xb); xlb = bf16((xb - xhb).astype(np.float32))
+chb = bf16(cbb); clb = bf16((cbb - chb).astype(np.float32))
+x, cb, xh, xl, ch, cl = xb, cbb, xhb, xlb, chb, clb      # (acc_blocks / chain read the module-level operands)
+dot = chain(x, cb)
+dt = acc_blocks([(xh, ch), (xh, cl), (xl, ch)])
+xsq = (x.astype(np.float64) ** 2).sum(1).astype(np.float32); csq = (cb.astype(np.float64) ** 2).sum(1).astype(np.float32)
+tt = (xsq[:, None] + csq[None, :]).astype(np.float32)
+d_or = (tt - 2 * dot).astype(np.float32); d_ap = (tt - 2 * dt).astype(np.float32)
+ids, ida = d_or.argmin(1), d_ap.argmin(1)
+s = np.sort(d_ap, axis=1); gap = s[:, 1] - s[:, 0]
+T1 = 2.0 ** -12 * np.sqrt(xsq * csq.max()); T2 = T1 + 2.0 ** -20 * (xsq + csq.max())
+mis = ids != ida
+print(f"argmin mismatches without guard: {mis.sum()}; unflagged with the dot-product term alone: {(mis & (gap > T1)).sum()}; "
+      f"with both terms: {(mis & (gap > T2)).sum()} (flagged {100 * (gap <= T2).mean():.1f}% of the rows)")
