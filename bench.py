@@ -24,7 +24,7 @@ Extra objects on the JSON line:
                   `step_frac_of_fp32_peak` prices the WHOLE step (MLP GEMMs included) against the same peak.
   parity       -- untimed gate against reference-generated ids (tests/golden/parity_<config>.npz): exact-match rate
                   of the HIP ids vs the reference on every fixture row, end to end from the 768-d items and at kernel
-                  level, with the tie policy of rqhip/parity.py (every mismatch must be a flagged near-tie).
+                  level, with the tie policy of tests/parity_gate.py (every mismatch must be a flagged near-tie).
   cpu_baseline -- the same training step as a torch-CPU port of the reference's tensor program
                   (oracle/torch_port.py) on this box's host cores, best over thread counts, bounded sample; rank 0,
                   N = 1 only.  The reference's own modules timed on the build container: BASELINE.md section 2.
@@ -140,13 +140,15 @@ def parity_gate(device, tag):
     """HIP ids vs the reference's on every fixture row (untimed).  Returns the `parity` object of the bench line."""
     import numpy as np
     import torch
-    from rqhip import ops, parity
+    from rqhip import ops
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_gate as parity
     fx = parity.load_fixture(tag)
     beta = float(fx["beta"])
     cbs = torch.from_numpy(fx["codebooks"]).to(device)
     out = {"fixture": f"tests/golden/parity_{tag}.npz (reference run by oracle/gen_parity_fixtures.py)",
            "tie_policy": "a row may differ from the reference only where the kernel's tie_margin at the first differing "
-                         "level is below tau (rqhip/parity.py); such rows are adjudicated in fp64"}
+                         "level is below tau (tests/parity_gate.py); such rows are adjudicated in fp64"}
 
     # (1) kernel level, identical input bits: regenerable latents, all rows (the reference's level loop ran on them)
     z = parity.regenerable_latents(int(fx["z_ids_eval"].shape[0]), float(fx["z_scale"]), int(fx["z_seed"]))

@@ -132,7 +132,7 @@ class Quantize(nn.Module):
         is the reference's expression in PyTorch-ROCm ops, differentiated by autograd.
         Near-tie caveat: the kernel ranks by (|xn|^2 + |cn_k|^2) - 2 xn.cn_k, where |cn_k|^2 is 1 up to an ulp PER CODE,
         while the reference ranks by -(xn.cn_k) alone; two codes whose cosines differ by less than ~1e-7 can therefore
-        be ordered differently (the same class of sub-ulp ties as rqhip/parity.py describes for the L2 path).
+        be ordered differently (the same class of sub-ulp ties as tests/parity_gate.py describes for the L2 path).
         GUMBEL_SOFTMAX with COSINE has no accelerated path and raises NotImplementedError."""
         if self.training and self.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
             raise NotImplementedError("COSINE distance with GUMBEL_SOFTMAX has no accelerated path")

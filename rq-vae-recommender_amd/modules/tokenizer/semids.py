@@ -61,7 +61,7 @@ class SemanticIdTokenizer(nn.Module):
         (train_rqvae.py:272-275): a rank-0-only call must not enter a collective.  `sharded=True` is the explicit
         multi-GPU form -- EVERY rank must call it: rows are split across ranks, tokenised, and the id table is
         all-gathered (ids are a function of each row alone, except that a different GEMM row count can flip a
-        near-tie; rqhip/parity.py describes the tie policy)."""
+        near-tie; tests/parity_gate.py describes the tie policy)."""
         device = self.rq_vae.device
         n = len(movie_dataset)
         lo, hi = rqdist.shard_bounds(n) if sharded else (0, n)

@@ -6,7 +6,8 @@ bench.py's untimed parity gate need: regenerating the fixture's inputs bit for b
 and the tie policy -- a row may differ from the reference only where the kernel's own `tie_margin` output
 (include/rqhip.h) flags the level of first divergence as a near-tie; such rows are adjudicated in fp64.
 
-Nothing here touches oracle/: it compares HIP outputs with committed reference outputs.
+Test infrastructure (lives under tests/, imported by the tests and by bench.py's untimed gate; the product package
+never imports it).  Nothing here touches oracle/: it compares HIP outputs with committed reference outputs.
 """
 from __future__ import annotations
 
@@ -21,8 +22,7 @@ INPUT_DIM, HIDDEN, EMBED = 768, [512, 256, 128], 32
 TAU_KERNEL = 1e-6   # identical inputs: only the summation order of quantize.py:113-117 differs (few ulp)
 TAU_E2E = 2e-5      # inputs differ too: the encoder GEMMs (hipBLASLt vs MKL) perturb res0 by ~1e-6 relative
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests",
-                          "golden")
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def sha(a) -> str:

@@ -16,7 +16,8 @@ import pytest
 import torch
 
 from oracle import rq_oracle as o
-from rqhip import ops, parity
+from rqhip import ops
+import parity_gate as parity
 
 pytestmark = pytest.mark.gpu
 

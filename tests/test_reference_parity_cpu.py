@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import rq_oracle as o
-from rqhip import parity
+import parity_gate as parity
 
 
 @pytest.fixture(scope="module", params=["c2", "c4"])
