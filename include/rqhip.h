@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 201 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin */
+#define RQHIP_VERSION 300 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex */
 
 #define RQHIP_OK 0
 #define RQHIP_EARG (-1)         /* bad pointer / size / mode */
@@ -84,6 +84,36 @@ int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks
                      int mode, float beta, int64_t *ids, float *embs, float *residuals,
                      float *emb_sum, float *loss, float *embs_norm, float *tie_margin, void *workspace,
                      size_t workspace_bytes, rqhip_stream_t stream);
+/* The same call with explicit kernel-selection flags (bench.py's A/B lines and the tests; rqhip_rq_forward passes 0).
+ * Every selection returns the same bits -- ids, embeddings, losses -- only the time differs:
+ *   RQHIP_FWD_SCAN_FP32    distances on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, the oracle's FMA chain) even where
+ *                          the filtered scan applies (D = 32 / 64, 16-byte aligned rows, no tie_margin): the default
+ *                          there scans bf16-split scores on the bf16 matrix cores and re-decides exactly every row whose
+ *                          two best scores are closer than the proven error bound (rqhip_filter_bound)
+ *   RQHIP_FWD_SCAN_VALU    distances with packed fp32 FMAs on the vector ALU, codes broadcast from LDS, no matrix
+ *                          instruction at all (D = 32, 16-byte aligned rows, K <= 1024, no tie_margin; otherwise
+ *                          RQHIP_EUNSUPPORTED) -- the LDS/VALU form BASELINE.json's north_star asks the MFMA form to be
+ *                          measured against
+ *   RQHIP_FWD_NO_COOP_TAIL the partly filled last round of row tiles runs as ordinary tiles (A/B of the cooperative tail)
+ */
+#define RQHIP_FWD_SCAN_FP32 0x1u
+#define RQHIP_FWD_SCAN_VALU 0x2u
+#define RQHIP_FWD_NO_COOP_TAIL 0x10u
+int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                        int mode, float beta, int64_t *ids, float *embs, float *residuals,
+                        float *emb_sum, float *loss, float *embs_norm, float *tie_margin, void *workspace,
+                        size_t workspace_bytes, unsigned flags, rqhip_stream_t stream);
+/* The filtered scan's too-close-to-call threshold, distance units: a row is re-decided exactly unless the gap between its
+ * two smallest approximate distances exceeds  c1 * |x| * max_k|c_k| + c2 * (|x|^2 + max_k|c_k|^2).  Host-side accessor (no
+ * GPU needed): tests/test_filter_bound.py checks the constants against the error bound derived in DESIGN.md section 4.1. */
+void rqhip_filter_bound(float *c1, float *c2);
+/* Test hook for that bound: scores[b,k] = the approximate score x_b.c_k - |c_k|^2/2 exactly as the filtered scan's
+ * matrix-instruction chain produces it (same staging, same split, same instruction order), D = 32 / 64, x [B,D],
+ * codebook [K,D], scores [B,K].  tests/test_gpu_filter_bound.py compares it with the real-arithmetic score on adversarial
+ * operands: the hardware's accumulation error must stay inside the share of the bound assigned to it.
+ * workspace: rqhip_rq_forward_workspace_bytes(1, K). */
+int rqhip_filter_scores(const float *x, int64_t B, int D, const float *codebook, int K, float *scores,
+                        void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Residual quantisation, backward: what torch.autograd computes through the code above

@@ -90,7 +90,29 @@ struct RqFwdParams {
     int resident;         // all levels staged once
     long long coop_first; // first row tile of the cooperative tail (== n_tiles when there is none)
     float beta;
+    // filtered scan: per-group score maxima in LDS (GroupMax): tiles per group, groups per level, bf16 storage
+    int tpg, ngroups, gm16;
 };
+
+// rows of a tile as lane (il, h) fetches them: full-width kernels take their half of the row as float4s ("raw", see
+// rows_to_pairs), the others their features d = 2 kk + h one by one
+template <int KSTEPS, bool FULLD>
+__device__ __forceinline__ void load_tile_rows(const RqFwdParams &p, long long tile, int il, int h, int D, float (&v)[KSTEPS]) {
+    const long long row = tile * 32 + il;
+    const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
+    if (FULLD) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.res0 + (size_t)rowc * D + h * KSTEPS);
+#pragma unroll
+        for (int j = 0; j < KSTEPS / 4; ++j) {
+            const f32x4 q = src[j];
+            v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    } else {
+        const float *src = p.res0 + (size_t)rowc * D + h;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) v[kk] = (2 * kk + h < D) ? src[2 * kk] : 0.0f;
+    }
+}
 
 // ---- codebook squared norms (quantize.py:115), once per call -------------------------------------
 // csq[l,k] = sumsq2(C[l,k,:]); csqmax[l] = max_k csq[l,k] (NaN if any is NaN).  grid = L, block = 256.
@@ -202,29 +224,60 @@ __device__ __forceinline__ void stage_codes(float *buf0, int buf_floats, int nbu
     }
 }
 
-// ---- bf16-split image for the filtered scan (FILT kernels, D = 32) ---------------------------------------------
+// ---- bf16-split image for the filtered scan (FILT kernels, D = 32 and 64) ---------------------------------------
 // Only the ARGMIN of the distances is an output; ids, the gathered codeword and the loss are computed from it exactly.
-// The FILT kernels therefore scan with approximate distances -- x = xh + xl + (rest), c = ch + cl + (rest) in bf16,
-// x.c ~ xh.ch + xh.cl + xl.ch as three chains of v_mfma_f32_32x32x16_bf16 (fp32 accumulation; products of bf16 are
-// exact in fp32) on the matrix cores proper, which run 5x faster than the f32-input form and beside the VALU epilogue
-// instead of sharing its datapath -- and hand every row whose two smallest approximate distances are closer than a
-// bound on the approximation error to the exact scan below (slow_argmin_row, the oracle's fp32 chain).  Same ids, bit
-// for bit; see rq_tile for the bound.
-// buffer = [image: 8 blocks of Kc 16-byte elements][csq: Kc floats]  (as large as the fp32 image)
-//   block (plane * 2 + s) * 2 + h, element c = 8 bf16: j-th = plane (hi / lo) of C[kbase + c][d = 2 (8 s + j) + h]
-// i.e. lane (il, h) finds, for K-step s, the same features 2 kk + h, kk = 8 s + j, that its row registers r[kk] hold.
+// The FILT kernels therefore scan with an approximate score and prove, row by row, that the approximation cannot have
+// changed the answer.  score_k = x.c_k - |c_k|^2 / 2  (so  d_k = |x|^2 - 2 score_k : the argmin of the distance is the
+// argmax of the score), accumulated entirely on the bf16 matrix cores:
+//     x = xh + xl + rho_x,  c = ch + cl + rho_c  (bf16 pieces)      x.c ~ xh.ch + xh.cl + xl.ch
+//     -|c|^2/2 = qh + qm + ql  EXACTLY (three bf16 pieces of the fp32 value the oracle's csq holds)
+// as 3 D/16 + 1 chained v_mfma_f32_32x32x16_bf16 per 32 codes x 32 rows (fp32 accumulation; products of two bf16 are
+// exact in fp32): no VALU arithmetic at all between the matrix pipe and the (max, runner-up, index) tournament.  The XDL
+// cores run beside the VALU instead of sharing its datapath as the fp32 MFMA does, and cost 32 cycles each instead of 64.
+// Rows whose best and runner-up scores are closer than the bound `filt_threshold` (below; derivation in DESIGN.md
+// section 4.1, pinned by tests/test_filter_bound.py) are re-decided exactly by `exact_argmin_groups`.
+//
+// buffer = [image: 4 S blocks of Kc 16-byte elements, S = D/16][q: Kc 8-byte elements]
+//   block (plane * S + s) * 2 + h, element c = 8 bf16: j-th = plane (hi / lo) of C[kbase + c][d = 2 (8 s + j) + h]
+//   i.e. lane (il, h) finds, for K-step s, the same features 2 kk + h, kk = 8 s + j, that its row registers r[kk] hold;
+//   q element c = {qh, qm, ql, 0}: the A operand (k slots 0..3 of lane (c, 0)) of the last matrix instruction, whose B
+//   operand is 1 in k slots 0..2 and 0 elsewhere.  Codes beyond K get q = -3e38: they never win a finite row.
 typedef __bf16 rq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rq_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 rq_bf16x2 __attribute__((ext_vector_type(2)));
 
+// v = hi + lo + rho with hi = bf16(v) (round to nearest even), lo = bf16(v - hi) (the difference is exact in fp32):
+// |lo| <= 2^-8 |v|, |rho| <= 2^-17 |v|  (bf16 keeps 8 significant bits: unit round-off 2^-8, half an ulp of lo is 2^-17 |v|)
 __device__ __forceinline__ void bf16_split(float v, __bf16 &hi, __bf16 &lo) {
-    hi = (__bf16)v;                    // round to nearest even
-    lo = (__bf16)(v - (float)hi);      // exact difference, rounded again: |v - hi - lo| <= 2^-18 |v|
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+// two values at once: one v_cvt_pk_bf16_f32 per plane
+__device__ __forceinline__ void bf16_split2(float a, float b, rq_bf16x2 &hi, rq_bf16x2 &lo) {
+    hi = __builtin_convertvector(f32x2{a, b}, rq_bf16x2);
+    const unsigned u = __builtin_bit_cast(unsigned, hi);
+    const float ha = __builtin_bit_cast(float, u << 16), hb = __builtin_bit_cast(float, u & 0xffff0000u);
+    lo = __builtin_convertvector(f32x2{a - ha, b - hb}, rq_bf16x2);
 }
 
-template <int NT>
+// The too-close-to-call threshold of the filtered scan, in SCORE units (half the distance gap): a row is re-decided
+// exactly unless best - runner_up > filt_threshold.  kFiltC1 / kFiltC2 are exported through rqhip_filter_bound() and
+// checked against the derivation by tests/test_filter_bound.py:
+//   |score~_k - (x.c_k - csq_k/2)| <= [2^-15 (dropped split terms) + 99 * 2^-23 * 1.016 (accumulation)] |x||c_k|
+//                                     + 3 * 2^-24 csq_k (the three q pieces enter last)
+//   |d_k - (xsq + csq_k - 2 x.c_k)| <= 2^-18 |x||c_k| + 3 * 2^-24 (xsq + csq_k)          (the oracle's own roundings)
+//   two codes, distance units:  gap needed  <= 1.773e-4 |x| max|c| + 1.08e-6 (xsq + max csq)
+//   threshold used (distance units)          2^-12    |x| max|c| + 2^-19   (xsq + max csq)     headroom 1.38 / 1.77
+constexpr float kFiltC1 = 2.44140625e-4f;       // 2^-12, distance units
+constexpr float kFiltC2 = 1.9073486328125e-6f;  // 2^-19
+__device__ __forceinline__ float filt_threshold(float xsq, float csqmax) {
+    return (0.5f * kFiltC1) * __builtin_sqrtf(xsq * csqmax) + (0.5f * kFiltC2) * (xsq + csqmax);
+}
+
+template <int KSTEPS, int NT>
 __device__ __forceinline__ void stage_codes_bf16(float *buf0, int buf_floats, int nbuf, const float *__restrict__ cb0,
                                                  const float *__restrict__ csq0, int csq_stride, int kbase, int Kc, int K) {
-    constexpr int D = 32, d4n = D / 4, cstep = NT / d4n;
+    constexpr int D = 2 * KSTEPS, S = KSTEPS / 8, d4n = D / 4, cstep = NT / d4n;
     const int tid = threadIdx.x;
     const int d4 = tid & (d4n - 1);
     const int s_blk = d4 >> 2, j0 = 2 * (d4 & 3);
@@ -246,14 +299,14 @@ __device__ __forceinline__ void stage_codes_bf16(float *buf0, int buf_floats, in
         for (int u = 0; u < kStageBatch; ++u) {
             if (bb[u] < nbuf) {
                 __bf16 *img = reinterpret_cast<__bf16 *>(buf0 + bb[u] * buf_floats);
-                __bf16 hx, lx, hy, ly, hz, lz, hw, lw;
-                bf16_split(v[u].x, hx, lx); bf16_split(v[u].y, hy, ly);
-                bf16_split(v[u].z, hz, lz); bf16_split(v[u].w, hw, lw);
-                auto at = [&](int plane, int h) { return img + ((size_t)(((plane * 2 + s_blk) * 2 + h) * Kc + cc[u])) * 8 + j0; };
-                *reinterpret_cast<rq_bf16x2 *>(at(0, 0)) = rq_bf16x2{hx, hz};   // features 4 d4, 4 d4 + 2 (h = 0)
-                *reinterpret_cast<rq_bf16x2 *>(at(0, 1)) = rq_bf16x2{hy, hw};   // features 4 d4 + 1, 4 d4 + 3 (h = 1)
-                *reinterpret_cast<rq_bf16x2 *>(at(1, 0)) = rq_bf16x2{lx, lz};
-                *reinterpret_cast<rq_bf16x2 *>(at(1, 1)) = rq_bf16x2{ly, lw};
+                rq_bf16x2 hxz, lxz, hyw, lyw;
+                bf16_split2(v[u].x, v[u].z, hxz, lxz);   // features 4 d4, 4 d4 + 2 (h = 0)
+                bf16_split2(v[u].y, v[u].w, hyw, lyw);   // features 4 d4 + 1, 4 d4 + 3 (h = 1)
+                auto at = [&](int plane, int h) { return img + ((size_t)(((plane * S + s_blk) * 2 + h) * Kc + cc[u])) * 8 + j0; };
+                *reinterpret_cast<rq_bf16x2 *>(at(0, 0)) = hxz;
+                *reinterpret_cast<rq_bf16x2 *>(at(0, 1)) = hyw;
+                *reinterpret_cast<rq_bf16x2 *>(at(1, 0)) = lxz;
+                *reinterpret_cast<rq_bf16x2 *>(at(1, 1)) = lyw;
             }
         }
     }
@@ -261,7 +314,12 @@ __device__ __forceinline__ void stage_codes_bf16(float *buf0, int buf_floats, in
         int c2 = tid, b2 = 0;
         while (c2 >= Kc) { c2 -= Kc; ++b2; }
         while (b2 < nbuf) {
-            buf0[b2 * buf_floats + 32 * Kc + c2] = (kbase + c2 < K) ? csq0[b2 * csq_stride + kbase + c2] : __builtin_inff();
+            const float q = (kbase + c2 < K) ? -0.5f * csq0[b2 * csq_stride + kbase + c2] : -3.0e38f;
+            const __bf16 qh = (__bf16)q;
+            const float r1 = q - (float)qh;          // exact
+            const __bf16 qm = (__bf16)r1;
+            const __bf16 ql = (__bf16)(r1 - (float)qm);   // exact again; the remainder fits 8 bits: qh + qm + ql == q
+            *reinterpret_cast<rq_bf16x4 *>(buf0 + b2 * buf_floats + 2 * KSTEPS * Kc + 2 * c2) = rq_bf16x4{qh, qm, ql, (__bf16)0.0f};
             c2 += NT;
             while (c2 >= Kc && b2 < nbuf) { c2 -= Kc; ++b2; }
         }
@@ -315,41 +373,64 @@ __device__ __forceinline__ int slow_argmin_row(const float (&r)[KSTEPS], int j, 
     return nanidx != 0x7fffffff ? nanidx : lidx;
 }
 
-// The same scan for D = 32 with every code row fetched as eight 16-byte loads (the dword version above is latency-bound:
-// 32 dependent-issue loads per code).  The filtered kernels call it for ~0.4 % of the rows, so it has to be cheap; the
-// FMA chain runs over d = 0, 1, 2, ... exactly as above.
-__device__ __forceinline__ int slow_argmin_row32(const float (&r)[16], int j, float xsq_j, const float *__restrict__ cb_l,
-                                                 const float *__restrict__ csq_l, int K) {
+// The exact decision of the filtered kernels (full-width rows, D = 2 KSTEPS): the oracle's distance -- one fp32 FMA chain
+// over d = 0, 1, 2, ..., (xsq + csq) - 2 dot -- for the codes of the groups named by `gmask` (group g = codes
+// [g gsz, (g + 1) gsz), gsz a multiple of 32), torch.min's rule over them: the first NaN distance if any, else the first
+// index of the minimum (quantize.py:128).  Wave-cooperative: row j's features are broadcast through scalar registers
+// (v_readlane), every lane takes one code per pass (its row as 16-byte loads from L2), two 32-code half-groups per
+// pass.  With gmask = all groups this is the full exact scan (rows that may hold Inf / NaN, cooperative tiles).
+template <int KSTEPS>
+__device__ __forceinline__ int exact_argmin_groups(const float (&r)[KSTEPS], int j, float xsq_j, unsigned gmask, int gsz,
+                                                   const float *__restrict__ cb_l, const float *__restrict__ csq_l, int K) {
+    constexpr int D = 2 * KSTEPS;
     const int lane = threadIdx.x & 63;
-    float x0[16], x1[16];
+    float x0[KSTEPS], x1[KSTEPS];   // wave-uniform: features 2 kk and 2 kk + 1 of row j
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        x0[kk] = __shfl(r[kk], j, 64);
-        x1[kk] = __shfl(r[kk], j + 32, 64);
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        x0[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[kk]), j));
+        x1[kk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[kk]), j + 32));
     }
     int nanidx = 0x7fffffff, lidx = 0x7fffffff;
     float lbest = __builtin_inff();
-    for (int k = lane; k < K; k += 64) {
-        const f32x4 *c = reinterpret_cast<const f32x4 *>(cb_l + (size_t)k * 32);
-        f32x4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = c[q];
-        const float cs = csq_l[k];
-        float acc = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            acc = __builtin_fmaf(x0[2 * q], v[q].x, acc);
-            acc = __builtin_fmaf(x1[2 * q], v[q].y, acc);
-            acc = __builtin_fmaf(x0[2 * q + 1], v[q].z, acc);
-            acc = __builtin_fmaf(x1[2 * q + 1], v[q].w, acc);
+    const int hpg = gsz >> 5;   // 32-code half-units per group
+    int g = 0, sub = hpg;
+    auto next_base = [&]() -> int {
+        if (sub >= hpg) {
+            if (!gmask) return -1;
+            g = __builtin_ctz(gmask);
+            gmask &= gmask - 1;
+            sub = 0;
         }
-        const float t = xsq_j + cs;
-        const float dist = t - 2.0f * acc;
-        if (dist != dist) {
-            nanidx = min(nanidx, k);
-        } else if (dist < lbest || (dist == lbest && k < lidx)) {
-            lbest = dist;
-            lidx = k;
+        return g * gsz + 32 * (sub++);
+    };
+    for (;;) {
+        const int b0 = next_base();
+        if (b0 < 0) break;
+        const int b1 = next_base();
+        const int base = lane < 32 ? b0 : b1;
+        const int k = base + (lane & 31);
+        if (base >= 0 && k < K) {
+            const f32x4 *c = reinterpret_cast<const f32x4 *>(cb_l + (size_t)k * D);
+            f32x4 v[KSTEPS / 2];
+#pragma unroll
+            for (int q = 0; q < KSTEPS / 2; ++q) v[q] = c[q];
+            const float cs = csq_l[k];
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < KSTEPS / 2; ++q) {
+                acc = __builtin_fmaf(x0[2 * q], v[q].x, acc);
+                acc = __builtin_fmaf(x1[2 * q], v[q].y, acc);
+                acc = __builtin_fmaf(x0[2 * q + 1], v[q].z, acc);
+                acc = __builtin_fmaf(x1[2 * q + 1], v[q].w, acc);
+            }
+            const float t = xsq_j + cs;
+            const float dist = t - 2.0f * acc;
+            if (dist != dist) {
+                nanidx = min(nanidx, k);
+            } else if (dist < lbest || (dist == lbest && k < lidx)) {
+                lbest = dist;
+                lidx = k;
+            }
         }
     }
 #pragma unroll
@@ -495,74 +576,141 @@ __device__ __forceinline__ void scan_codes(const f32x4 *__restrict__ img, const 
     }
 }
 
-// The filtered scan of Kc staged codes (see stage_codes_bf16): same (best, index, runner-up) tournament as
-// scan_codes<16, true>, on distances whose dot product is the three-term bf16 split.
-__device__ __forceinline__ void scan_codes_bf16(const rq_bf16x8 *__restrict__ img, const float *__restrict__ csq_s, int Kc,
-                                                int kbase, int il, int h, const rq_bf16x8 (&xh)[2],
-                                                const rq_bf16x8 (&xl)[2], float xsq, float &best, int &bidx,
-                                                float &second, int t_begin = 0, int t_step = 1) {
+__device__ __forceinline__ float rq_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (largest, runner-up) of the union of two sets given each set's (largest, runner-up); duplicates count
+__device__ __forceinline__ void rq_merge2max(float w1, float l1, float w2, float l2, float &w, float &l) {
+    w = rq_max(w1, w2);
+    l = rq_max3(rq_min(w1, w2), l1, l2);
+}
+
+// Running per-group maxima of a lane's scores, parked in LDS for the exact re-decision (gm[group][lane], one wave's
+// slice): `grun` collects the tiles of the current group, `gcnt` counts them, `g` is the group being filled.
+struct GroupMax {
+    float *slot;     // this lane's word of group 0; groups are 64 words apart
+    float grun;
+    int gcnt, g, tpg, as16;
+    __device__ __forceinline__ void flush() {
+        if (as16) {
+            // bf16 rounded towards +inf (the test `gm >= best - Th` must never miss a group)
+            const unsigned u = __builtin_bit_cast(unsigned, grun);
+            const unsigned up = (u + (((int)u >= 0) ? 0xffffu : 0u)) >> 16;
+            reinterpret_cast<unsigned short *>(slot)[(size_t)g * 64] = (unsigned short)up;
+        } else {
+            slot[(size_t)g * 64] = grun;
+        }
+        g = __builtin_amdgcn_readfirstlane(g + 1);   // (wave-uniform counters: keep them in scalar registers)
+        gcnt = 0;
+        grun = -__builtin_inff();
+    }
+    __device__ __forceinline__ void add(float tmax) {
+        grun = rq_max(grun, tmax);
+        gcnt = __builtin_amdgcn_readfirstlane(gcnt + 1);
+        if (gcnt == tpg) flush();
+    }
+    __device__ __forceinline__ float read(int gi) const {
+        if (as16) {
+            const unsigned v = reinterpret_cast<const unsigned short *>(slot)[(size_t)gi * 64];
+            return __builtin_bit_cast(float, v << 16);
+        }
+        return slot[(size_t)gi * 64];
+    }
+};
+
+// scores of 32 codes x 32 rows: the instruction chain the error bound (filt_threshold) is derived for -- the split
+// products first, the three pieces of -|c|^2/2 LAST (their rounding is then relative to the finished score only)
+template <int S>
+__device__ __forceinline__ f32x16 split_scores(const rq_bf16x8 (&a)[2 * S], const rq_bf16x8 &aq, const rq_bf16x8 (&xh)[S],
+                                               const rq_bf16x8 (&xl)[S], const rq_bf16x8 &ones) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], xh[s], acc, 0, 0, 0);       // ch . xh
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S + s], xh[s], acc, 0, 0, 0);   // cl . xh
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], xl[s], acc, 0, 0, 0);       // ch . xl
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, ones, acc, 0, 0, 0);                                       // - |c|^2 / 2
+}
+// B operand of the last instruction: 1 in k slots 0..2 (lanes h = 0 hold k = 0..7), 0 elsewhere
+__device__ __forceinline__ rq_bf16x8 split_ones(int h) {
+    const __bf16 one = (h == 0) ? (__bf16)1.0f : (__bf16)0.0f, zero = (__bf16)0.0f;
+    return rq_bf16x8{one, one, one, zero, zero, zero, zero, zero};
+}
+// a full-width row in pair layout (lane (il, h): r[kk] = feature 2 kk + h) as bf16 hi / lo planes, K-step s = kk in [8 s, 8 s + 8)
+template <int KSTEPS>
+__device__ __forceinline__ void split_row(const float (&r)[KSTEPS], rq_bf16x8 (&xh)[KSTEPS / 8], rq_bf16x8 (&xl)[KSTEPS / 8]) {
+#pragma unroll
+    for (int sx = 0; sx < KSTEPS / 8; ++sx)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            rq_bf16x2 hi, lo;
+            bf16_split2(r[8 * sx + j], r[8 * sx + j + 1], hi, lo);
+            xh[sx][j] = hi[0]; xh[sx][j + 1] = hi[1];
+            xl[sx][j] = lo[0]; xl[sx][j + 1] = lo[1];
+        }
+}
+
+// The filtered scan of Kc staged codes (see stage_codes_bf16): scores x.c - |c|^2/2 of 32 rows against 32 codes per
+// tile entirely on the bf16 matrix cores, then the (best, runner-up, index) tournament on the 16 scores of the lane --
+// the mirror image (max for min) of scan_codes<.., MARGIN = true>, without any arithmetic in front of it.
+template <int S, bool GROUPS>
+__device__ __forceinline__ void scan_codes_split(const rq_bf16x8 *__restrict__ img, const rq_bf16x4 *__restrict__ qimg, int Kc,
+                                                 int kbase, int il, int h, const rq_bf16x8 (&xh)[S], const rq_bf16x8 (&xl)[S],
+                                                 float &best, int &bidx, float &second, GroupMax &gm, int t_begin = 0,
+                                                 int t_step = 1) {
     const int ntiles = Kc / 32;
-    const f32x2 xsq2 = {xsq, xsq};
-    auto lda = [&](int t, int blk) { return img[(size_t)(blk * 2 + h) * Kc + t * 32 + il]; };   // blk = plane * 2 + s
+    auto lda = [&](int t, int blk) { return img[(size_t)(blk * 2 + h) * Kc + t * 32 + il]; };   // blk = plane * S + s
+    auto ldq = [&](int t) {
+        const rq_bf16x4 q = qimg[t * 32 + il];
+        return rq_bf16x8{q[0], q[1], q[2], q[3], (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+    };
+    const rq_bf16x8 ones = split_ones(h);
     const int t0 = t_begin < ntiles ? t_begin : 0;
-    rq_bf16x8 a0 = lda(t0, 0), a1 = lda(t0, 1), a2 = lda(t0, 2), a3 = lda(t0, 3);
+    rq_bf16x8 a[2 * S], aq;
+#pragma unroll
+    for (int b = 0; b < 2 * S; ++b) a[b] = lda(t0, b);
+    aq = ldq(t0);
     for (int t = t_begin; t < ntiles; t += t_step) {
         const int tn = (t + t_step < ntiles) ? t + t_step : t;
-        const float *cq = csq_s + t * 32 + 4 * h;
-        f32x4 c4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) c4[g] = *reinterpret_cast<const f32x4 *>(cq + 8 * g);
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xh[0], acc, 0, 0, 0);   // ch . xh
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xh[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xh[0], acc, 0, 0, 0);   // cl . xh
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xh[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xl[0], acc, 0, 0, 0);   // ch . xl
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xl[1], acc, 0, 0, 0);
+        const f32x16 acc = split_scores<S>(a, aq, xh, xl, ones);
         // the next tile's code operands, into the same registers: in flight during the VALU epilogue below
         __builtin_amdgcn_sched_barrier(0);
-        a0 = lda(tn, 0); a1 = lda(tn, 1); a2 = lda(tn, 2); a3 = lda(tn, 3);
-        f32x2 dp[8];
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr)
-            dp[pr] = rq_pk_add(xsq2, f32x2{c4[pr >> 1][2 * (pr & 1)], c4[pr >> 1][2 * (pr & 1) + 1]});
-        float d[16];
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {
-            const f32x2 v = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, f32x2{acc[2 * pr], acc[2 * pr + 1]}, dp[pr]);
-            d[2 * pr] = v.x;
-            d[2 * pr + 1] = v.y;
-        }
-        // (min, runner-up) tree and top-down walk for the index: see scan_codes
-        float lo1[8], hi1[8], lo2[4], hi2[4], hi3a, hi3b, t2, a07, b07, tmin;
+        for (int b = 0; b < 2 * S; ++b) a[b] = lda(tn, b);
+        aq = ldq(tn);
+        // acc[j]: code = 32 t + 8 (j>>2) + 4 h + (j&3), item = il.  (max, runner-up) tree and top-down walk for the index
+        float w1[8], l1[8], w2[4], l2[4], l3a, l3b, t2, a07, b07, tmax;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            lo1[i] = rq_min(d[2 * i], d[2 * i + 1]);
-            hi1[i] = rq_max(d[2 * i], d[2 * i + 1]);
+            w1[i] = rq_max(acc[2 * i], acc[2 * i + 1]);
+            l1[i] = rq_min(acc[2 * i], acc[2 * i + 1]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rq_merge2(lo1[2 * i], hi1[2 * i], lo1[2 * i + 1], hi1[2 * i + 1], lo2[i], hi2[i]);
-        rq_merge2(lo2[0], hi2[0], lo2[1], hi2[1], a07, hi3a);
-        rq_merge2(lo2[2], hi2[2], lo2[3], hi2[3], b07, hi3b);
-        rq_merge2(a07, hi3a, b07, hi3b, tmin, t2);
-        const float a01 = lo1[0], a45 = lo1[2], b01 = lo1[4], b45 = lo1[6];
-        const float a03 = lo2[0], a47 = lo2[1], b03 = lo2[2], b47 = lo2[3];
-        (void)a47; (void)b47;
-        second = rq_min3(second, t2, rq_max(best, tmin));
-        const bool c3 = a07 != tmin;
+        for (int i = 0; i < 4; ++i) rq_merge2max(w1[2 * i], l1[2 * i], w1[2 * i + 1], l1[2 * i + 1], w2[i], l2[i]);
+        rq_merge2max(w2[0], l2[0], w2[1], l2[1], a07, l3a);
+        rq_merge2max(w2[2], l2[2], w2[3], l2[3], b07, l3b);
+        rq_merge2max(a07, l3a, b07, l3b, tmax, t2);
+        const float a01 = w1[0], a45 = w1[2], b01 = w1[4], b45 = w1[6];
+        const float a03 = w2[0], b03 = w2[2];
+        second = rq_max3(second, t2, rq_min(best, tmax));
+        if (GROUPS) gm.add(tmax);
+        const bool c3 = a07 != tmax;
         const float q03 = c3 ? b03 : a03;
-        const bool c2 = q03 != tmin;
+        const bool c2 = q03 != tmax;
         const float s01 = c3 ? b01 : a01, s45 = c3 ? b45 : a45;
         const float p01 = c2 ? s45 : s01;
-        const bool c1 = p01 != tmin;
-        const float u0a = c3 ? d[8] : d[0], u2a = c3 ? d[10] : d[2], u4a = c3 ? d[12] : d[4], u6a = c3 ? d[14] : d[6];
+        const bool c1 = p01 != tmax;
+        const float u0a = c3 ? acc[8] : acc[0], u2a = c3 ? acc[10] : acc[2], u4a = c3 ? acc[12] : acc[4], u6a = c3 ? acc[14] : acc[6];
         const float u0 = c2 ? u4a : u0a, u2 = c2 ? u6a : u2a;
         const float e0 = c1 ? u2 : u0;
-        const bool c0 = e0 != tmin;
+        const bool c0 = e0 != tmax;
         const int slot = (c3 ? 16 : 0) | (c2 ? 8 : 0) | (c1 ? 2 : 0) | (c0 ? 1 : 0);
         const int cand = kbase + t * 32 + 4 * h + slot;
-        const bool better = tmin < best;
-        best = better ? tmin : best;
+        const bool better = tmax > best;
+        best = better ? tmax : best;
         bidx = better ? cand : bidx;
     }
 }
@@ -578,14 +726,23 @@ __device__ __forceinline__ void scan_codes_bf16(const rq_bf16x8 *__restrict__ im
 //                 would leave most SIMDs empty, and (b) for the partly filled last round of a big batch, whose
 //                 tiles would otherwise each put a whole extra tile on one SIMD (+17 us for 53 of 3125 tiles).
 // FULLD: D == 2*KSTEPS, no feature-tail predicates anywhere (the shipped widths 16/32/64 and 8, 128)
-// FILT (KSTEPS = 16, FULLD): the scan runs on the bf16-split image (stage_codes_bf16 / scan_codes_bf16) and rows that are
-//       too close to call go through the exact scan; never together with MARGIN (the margins are exact quantities).
-template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN, bool FILT>
+// FILT (KSTEPS = 16 / 32, FULLD): the scan runs on the bf16-split image (stage_codes_bf16 / scan_codes_split) and rows
+//       that are too close to call are re-decided exactly; never together with MARGIN (the margins are exact quantities).
+//       `best` / `second` then hold SCORES (larger is better), not distances.  next_tile >= 0: its rows are fetched into
+//       `rn` once the last level's scan is over (a prefetch issued before the tile would keep KSTEPS registers alive
+//       across every scan: the filtered kernel spilled 20 of them).
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN, bool FILT, int RES>
 __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
-                                        long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase) {
+                                        float *gm_s, long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase,
+                                        long long next_tile, float (&rn)[KSTEPS]) {
     constexpr int KQ = KSTEPS / 4;
-    constexpr bool TRACK2 = MARGIN || FILT;   // the runner-up distance is tracked
-    static_assert(!FILT || (KSTEPS == 16 && FULLD && !MARGIN), "filtered scan: D = 32 only, no margins");
+    constexpr int S = FILT ? KSTEPS / 8 : 1;   // 16-wide K steps of the bf16 matrix instruction
+    constexpr bool TRACK2 = MARGIN || FILT;   // the runner-up is tracked
+    // RES: 1 = all levels staged once, 0 = one chunk of one level at a time, -1 = decided per launch (p.resident).  The
+    // filtered kernels fix it at compile time: the two forms share little, and the staging addresses of the form that is
+    // not running cost registers.
+    const bool resident = RES < 0 ? (p.resident != 0) : (RES == 1);
+    static_assert(!FILT || ((KSTEPS == 16 || KSTEPS == 32) && FULLD && !MARGIN), "filtered scan: D = 32 / 64, no margins");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int il = lane & 31, h = lane >> 5;
     const int K = p.K, Kc = p.Kc, L = p.L;
@@ -599,12 +756,8 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) es[kk] = 0.0f;
     float lsum = 0.0f;
-    // running output pointers of this lane (advanced per level: no 64-bit multiplies inside the level loop)
-    int64_t *ids_ptr = p.ids + row;
-    float *norm_ptr = p.embs_norm ? p.embs_norm + (size_t)row * L : nullptr;
-    // (full-width kernels store float4 row chunks: pointer to the row; otherwise to this lane's first feature)
-    float *embs_ptr = p.embs ? p.embs + (size_t)row * D + (FULLD ? 0 : h) : nullptr;
-    float *resid_ptr = p.residuals ? p.residuals + (size_t)row * D + (FULLD ? 0 : h) : nullptr;
+    // (output addresses are formed where they are used, once per level: running per-lane pointers cost ten registers
+    // that are alive across every scan)
     RQ_STAMP(1);
 
     for (int l = 0; l < L; ++l) {
@@ -614,30 +767,28 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         // |x|^2 (quantize.py:114): parity accumulators, multiply and add separately rounded
         const float xsq = pair_sumsq<KSTEPS>(r);
 
-        float best = __builtin_inff(), second = __builtin_inff();
+        float best = FILT ? -__builtin_inff() : __builtin_inff(), second = best;
         int bidx = 0x7fffffff;
         // filtered scan: this level's input rows as bf16 hi / lo planes, K-step s = features 2 (8 s + j) + h
-        rq_bf16x8 xh[2], xl[2];
+        rq_bf16x8 xh[S], xl[S];
+        GroupMax gm;
         if constexpr (FILT) {
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    __bf16 hi, lo;
-                    bf16_split(r[8 * sx + j], hi, lo);
-                    xh[sx][j] = hi;
-                    xl[sx][j] = lo;
-                }
+            split_row<KSTEPS>(r, xh, xl);
+            gm.as16 = p.gm16;
+            gm.slot = p.gm16 ? reinterpret_cast<float *>(reinterpret_cast<unsigned short *>(gm_s) + (size_t)wave * 8 * 64 + lane)
+                             : gm_s + (size_t)wave * 8 * 64 + lane;
+            gm.grun = -__builtin_inff();
+            gm.gcnt = 0; gm.g = 0; gm.tpg = p.tpg;
         }
 
-        const float *buf = smem + (p.resident ? l * buf_floats : 0);
+        const float *buf = smem + (resident ? l * buf_floats : 0);
         for (int ch = 0; ch < p.nchunks; ++ch) {
             const int kbase = ch * Kc;
-            if (!p.resident) {
+            if (!resident) {
                 __syncthreads();  // previous chunk fully consumed
                 if constexpr (FILT)
-                    stage_codes_bf16<NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
-                                         kbase, Kc, K);
+                    stage_codes_bf16<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
+                                                 kbase, Kc, K);
                 else
                     stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
                                             kbase, Kc, K, D);
@@ -645,24 +796,37 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             }
             if (active) {
                 if constexpr (FILT)
-                    scan_codes_bf16(reinterpret_cast<const rq_bf16x8 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h, xh, xl,
-                                    xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
+                    scan_codes_split<S, !COOP>(reinterpret_cast<const rq_bf16x8 *>(buf),
+                                               reinterpret_cast<const rq_bf16x4 *>(buf + KSTEPS * 2 * Kc), Kc, kbase, il, h, xh,
+                                               xl, best, bidx, second, gm, COOP ? wave : 0, COOP ? kCoopWaves : 1);
                 else
                     scan_codes<KSTEPS, MARGIN>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h,
                                                r, xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
             }
         }
 
+        if constexpr (FILT) {
+            if (!COOP && gm.gcnt) gm.flush();   // a partly filled last group
+            if (l == L - 1 && next_tile >= 0) load_tile_rows<KSTEPS, FULLD>(p, next_tile, il, h, D, rn);
+        }
         RQ_STAMP(3 + 8 * l);
         // lanes (il,0) and (il,1) scanned disjoint code subsets: keep the smaller, ties -> lower index
-        // (lexicographic (distance, index) minimum == first-index argmin over the union)
+        // (lexicographic (distance, index) minimum == first-index argmin over the union; FILT: larger score)
         if (active) {
             const float ob = shfl_xor32(best);
             const int oi = shfl_xor32(bidx);
-            if (TRACK2) second = rq_min3(second, shfl_xor32(second), rq_max(best, ob));
-            if (ob < best || (ob == best && oi < bidx)) {
-                best = ob;
-                bidx = oi;
+            if constexpr (FILT) {
+                second = rq_max3(second, shfl_xor32(second), rq_min(best, ob));
+                if (ob > best || (ob == best && oi < bidx)) {
+                    best = ob;
+                    bidx = oi;
+                }
+            } else {
+                if (TRACK2) second = rq_min3(second, shfl_xor32(second), rq_max(best, ob));
+                if (ob < best || (ob == best && oi < bidx)) {
+                    best = ob;
+                    bidx = oi;
+                }
             }
         }
         if (COOP) {
@@ -686,17 +850,25 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             while (__hip_atomic_load(&cnt[step & (kCoopSteps - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
                 __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            best = __builtin_inff();
-            second = __builtin_inff();
+            best = FILT ? -__builtin_inff() : __builtin_inff();
+            second = best;
             bidx = 0x7fffffff;
 #pragma unroll
             for (int w = 0; w < kCoopWaves; ++w) {
                 const float ov = cv[w * 32 + il];
                 const int oi = ci[w * 32 + il];
-                if (TRACK2) second = rq_min3(second, c2[w * 32 + il], rq_max(best, ov));
-                if (ov < best || (ov == best && oi < bidx)) {
-                    best = ov;
-                    bidx = oi;
+                if constexpr (FILT) {
+                    second = rq_max3(second, c2[w * 32 + il], rq_min(best, ov));
+                    if (ov > best || (ov == best && oi < bidx)) {
+                        best = ov;
+                        bidx = oi;
+                    }
+                } else {
+                    if (TRACK2) second = rq_min3(second, c2[w * 32 + il], rq_max(best, ov));
+                    if (ov < best || (ov == best && oi < bidx)) {
+                        best = ov;
+                        bidx = oi;
+                    }
                 }
             }
         }
@@ -707,24 +879,26 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             // fast path only when no distance term can overflow (then fma(-2,acc,tt) == tt - 2*acc exactly)
             const float guard = xsq + csqmax_l;
             bool bad = !(guard < 1.0e38f);
+            unsigned cmask = 0;          // filtered scan: this lane's candidate groups (rows that are too close to call)
+            bool full_scan = bad;        // rows that need torch.min's rule over every code
             if constexpr (FILT) {
-                // Too close to call?  |d~ - d| for any code, d the oracle's fp32 distance and d~ the scanned one, is at
-                // most 2 |x.c - (xh.ch + xh.cl + xl.ch)| + rounding: the dropped terms are <= 3 * 2^-18 sum|x_d c_d|, the
-                // fp32 accumulation of 96 exact products <= ~2^-16.4 sum|x_d c_d|, the oracle's own chain 2^-19; with
-                // sum|x_d c_d| <= |x| |c| that is < 2^-14.5 |x| |c| (measured maximum on config-2-like data: 2^-16.3,
-                // tools/bf16_filter_study.py).  The argmin of d~ is the argmin of d whenever the two smallest d~ differ
-                // by more than twice that (plus one ulp of d); the test uses 2^-12 |x| max|c| (2.8 times the bound, 20 times the measured
-                // maximum) + 2^-20 (|x|^2 + max|c|^2) and also sends rows of
-                // vanishing magnitude (bf16 denormals may be flushed) and any NaN to the exact scan.
+                // Too close to call?  best / second are scores; Th is half the distance-gap bound (filt_threshold).  Rows of
+                // vanishing magnitude (the bound's sqrt underflows; bf16 pieces may be flushed) and any NaN go exact too.
                 const float scale2 = xsq * csqmax_l;
-                // (second term: the final rounding of d and d~ themselves, half an ulp of |d| <= 2 (|x|^2 + max|c|^2) each
-                // -- it dominates when the row is much larger than every code or the reverse, where neighbouring codes'
-                // distances differ by a few ulps only)
-                const float T = 2.4414062e-4f * __builtin_sqrtf(scale2) + 9.5367432e-7f * guard;   // 2^-12, 2^-20
+                const float Th = filt_threshold(xsq, csqmax_l);
+                full_scan = bad || !(scale2 > 1.0e-30f) || COOP;
 #ifndef RQ_FILT_NOSLOW   // (developer timing build, tools/ab_build.sh: how fast is the scan without its exact re-checks?)
-                bad = bad || !((second - best) > T) || !(scale2 > 1.0e-30f);
+                const bool close = !((best - second) > Th);
+                bad = bad || !(scale2 > 1.0e-30f) || close;
+                if (!COOP) {
+                    // groups of codes that may hold the exact argmin: every code whose score is within Th of the best
+                    if (__ballot(close && !full_scan)) {
+                        const float thr = best - Th;
+                        for (int gi = 0; gi < p.ngroups; ++gi) cmask |= (gm.read(gi) >= thr) ? (1u << gi) : 0u;
+                    }
+                }
 #else
-                (void)T;
+                (void)Th;
 #endif
             }
             unsigned long long badmask = __ballot(bad) & 0xffffffffull;
@@ -736,14 +910,22 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                     badmask &= badmask - 1;
                     const float xj = __shfl(xsq, j, 64);
                     int res;
-                    if constexpr (FILT) res = slow_argmin_row32(r, j, xj, cb_l, csq_l, K);
-                    else res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
+                    if constexpr (FILT) {
+                        const unsigned all = p.ngroups >= 32 ? 0xffffffffu : ((1u << p.ngroups) - 1u);
+                        const bool fs = __builtin_amdgcn_readlane((int)full_scan, j) != 0;
+                        const unsigned gmask = fs ? all
+                                                  : ((unsigned)__builtin_amdgcn_readlane((int)cmask, j) |
+                                                     (unsigned)__builtin_amdgcn_readlane((int)cmask, j + 32));
+                        res = exact_argmin_groups<KSTEPS>(r, j, xj, gmask, 32 * p.tpg, cb_l, csq_l, K);
+                    } else {
+                        res = slow_argmin_row<KSTEPS>(r, j, xj, cb_l, csq_l, K, p.D);
+                    }
                     if (il == j) bidx = res;
                 }
             }
             if (MARGIN) {
                 // relative top-2 margin of this level's argmin (see include/rqhip.h); 0 for exact-scan rows
-                const float cwin = p.resident ? buf[KSTEPS * 2 * Kc + bidx] : p.csq[(size_t)l * p.Kp + bidx];
+                const float cwin = resident ? buf[KSTEPS * 2 * Kc + bidx] : p.csq[(size_t)l * p.Kp + bidx];
                 float m = (second - best) / (xsq + cwin);
                 if (bad || m != m) m = 0.0f;
                 if (writer && h == 0) p.tie_margin[(size_t)l * p.B + row] = m;
@@ -753,17 +935,19 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             // codeword gather (quantize.py:101-102) for this lane's feature parity: from the staged LDS image
             // when the whole level is resident, else from global memory (L2)
             float e[KSTEPS];
-            if (p.resident && !FILT) {
+            if (resident && !FILT) {
                 const f32x4 *img = reinterpret_cast<const f32x4 *>(buf) + h * Kc + bidx;
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     const f32x4 v = img[q * 2 * Kc];
                     e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
                 }
+            } else if (FULLD) {
+                load_pair_row_vec<KSTEPS>(p.cb + ((size_t)l * K + bidx) * D, h, e);
             } else {
                 const float *src = p.cb + ((size_t)l * K + bidx) * D + h;
 #pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) e[kk] = (FULLD || 2 * kk + h < D) ? src[2 * kk] : 0.0f;
+                for (int kk = 0; kk < KSTEPS; ++kk) e[kk] = (2 * kk + h < D) ? src[2 * kk] : 0.0f;
             }
             // QuantizeLoss (loss.py:38-41): both terms equal sum((x-emb)^2)
             float sa = 0.0f;
@@ -782,12 +966,19 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
 
             RQ_STAMP(6 + 8 * l);
             if (writer) {
-                if (h == 0) *ids_ptr = (int64_t)bidx;
-                if (norm_ptr) {  // uniform branch: the sqrt sequence is skipped when norms are not requested
+                // (the row number is laundered through an empty asm: otherwise the compiler forms all these addresses
+                // once per tile, keeps them across the scans of every level and spills them -- 22 MB of scratch
+                // traffic per 100 000-row launch in round 2)
+                long long rowv = row;
+                asm volatile("" : "+v"(rowv));
+                if (h == 0) p.ids[(size_t)l * p.B + rowv] = (int64_t)bidx;
+                if (p.embs_norm) {  // uniform branch: the sqrt sequence is skipped when norms are not requested
                     const float onorm = __builtin_sqrtf(pair_sumsq<KSTEPS>(o));
-                    if (h == 0) norm_ptr[l] = onorm;
+                    if (h == 0) p.embs_norm[(size_t)rowv * L + l] = onorm;
                 }
-                if (resid_ptr) {
+                // (full-width kernels store float4 row chunks: pointer to the row; otherwise to this lane's first feature)
+                if (p.residuals) {
+                    float *resid_ptr = p.residuals + l * level_stride + (size_t)rowv * D + (FULLD ? 0 : h);
                     if (FULLD) {
                         store_pair_row<KSTEPS>(resid_ptr, h, r);
                     } else {
@@ -796,7 +987,8 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                             if (2 * kk + h < D) resid_ptr[2 * kk] = r[kk];
                     }
                 }
-                if (embs_ptr) {
+                if (p.embs) {
+                    float *embs_ptr = p.embs + l * level_stride + (size_t)rowv * D + (FULLD ? 0 : h);
                     if (FULLD) {
                         store_pair_row<KSTEPS>(embs_ptr, h, o);
                     } else {
@@ -806,9 +998,6 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                     }
                 }
             }
-            ids_ptr += p.B;
-            if (resid_ptr) resid_ptr += level_stride;
-            if (embs_ptr) embs_ptr += level_stride;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 es[kk] = (l == 0) ? o[kk] : es[kk] + o[kk];
@@ -819,12 +1008,14 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
 
     RQ_STAMP(100);
     if (writer) {
-        if (h == 0 && p.loss) p.loss[row] = lsum;
+        long long rowv = row;
+        asm volatile("" : "+v"(rowv));
+        if (h == 0 && p.loss) p.loss[rowv] = lsum;
         if (p.emb_sum) {
             if (FULLD) {
-                store_pair_row<KSTEPS>(p.emb_sum + (size_t)row * D, h, es);
+                store_pair_row<KSTEPS>(p.emb_sum + (size_t)rowv * D, h, es);
             } else {
-                float *dst = p.emb_sum + (size_t)row * D + h;
+                float *dst = p.emb_sum + (size_t)rowv * D + h;
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk)
                     if (2 * kk + h < D) dst[2 * kk] = es[kk];
@@ -834,8 +1025,9 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
     RQ_STAMP(101);
 }
 
-template <int KSTEPS, int MODE, bool FULLD, int NT, bool MARGIN, bool FILT = false>
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool MARGIN, bool FILT = false, int RES = -1>
 __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
+    const bool resident = RES < 0 ? (p.resident != 0) : (RES == 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *smem = reinterpret_cast<float *>(smem_raw);
 
@@ -846,31 +1038,14 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     const int h = lane >> 5;
     const int D = FULLD ? 2 * KSTEPS : p.D;
     const int K = p.K, Kc = p.Kc, L = p.L;
-    const int buf_floats = Kc * (KSTEPS * 2 + 1);
+    const int buf_floats = Kc * (KSTEPS * 2 + (FILT ? 2 : 1));   // image + (q pieces : csq) per code
     constexpr int kWavesPerWg = NT / RQ_WAVE;
     const long long total_waves = (long long)gridDim.x * kWavesPerWg;
     // round `it`: waves are enumerated wave-major (wave w of every workgroup before wave w+1), so a partly
     // filled last round spreads over all CUs instead of filling the first workgroups only
     const long long wave_slot = (long long)wave * gridDim.x + blockIdx.x;
 
-    // rows of a tile as this lane fetches them: full-width kernels take their half of the row as float4s ("raw",
-    // see rows_to_pairs), the others their features d = 2 kk + h one by one
-    auto load_rows = [&](long long tile, float(&v)[KSTEPS]) {
-        const long long row = tile * 32 + il;
-        const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
-        if (FULLD) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.res0 + (size_t)rowc * D + h * KSTEPS);
-#pragma unroll
-            for (int j = 0; j < KSTEPS / 4; ++j) {
-                const f32x4 q = src[j];
-                v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
-            }
-        } else {
-            const float *src = p.res0 + (size_t)rowc * D + h;
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) v[kk] = (2 * kk + h < D) ? src[2 * kk] : 0.0f;
-        }
-    };
+    auto load_rows = [&](long long tile, float(&v)[KSTEPS]) { load_tile_rows<KSTEPS, FULLD>(p, tile, il, h, D, v); };
     auto unpack_rows = [&](const float(&raw)[KSTEPS], float(&v)[KSTEPS]) {
         if (FULLD) {
             rows_to_pairs<KSTEPS>(raw, v);
@@ -886,13 +1061,14 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     load_rows(wave_slot, rn);
     // per-level max codebook norm (Inf/NaN guard) lives in LDS: no global load inside the level loop, so the
     // in-order vmcnt counter never makes a level wait for the previous level's stores
-    float *csqmax_s = smem + (p.resident ? L : 1) * buf_floats;
+    float *csqmax_s = smem + (resident ? L : 1) * buf_floats;
     float *cand_s = csqmax_s + 16;  // cooperative-tile candidates and counters (kCoopLdsFloats)
+    float *gm_s = cand_s + kCoopLdsFloats;   // filtered scan: per-wave group maxima (GroupMax), 8 x 64 words per wave
     if (tid < L) csqmax_s[tid] = p.csqmax[tid];
     if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 2 * kCoopCandFloats)[tid] = 0;
     RQ_STAMP(200);
-    if (p.resident) {
-        if constexpr (FILT) stage_codes_bf16<NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K);
+    if (resident) {
+        if constexpr (FILT) stage_codes_bf16<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K);
         else stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
     }
     RQ_STAMP(201);
@@ -906,24 +1082,27 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     for (int it = 0; it < p.n_iter; ++it) {
         const long long tile = (long long)it * total_waves + wave_slot;
         const bool active = tile < p.coop_first;
-        if (p.resident && !active) break;
+        if (resident && !active) break;
         float r[KSTEPS];
         unpack_rows(rn, r);
-        if (it + 1 < p.n_iter) load_rows(tile + total_waves, rn);
-        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN, FILT>(p, smem, csqmax_s, cand_s, active ? tile : p.n_tiles, r, D, buf_floats, 0);
+        const long long next = (it + 1 < p.n_iter) ? tile + total_waves : -1;
+        if (!FILT && next >= 0) load_rows(next, rn);   // (filtered kernels fetch it after the last level's scan)
+        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN, FILT, RES>(p, smem, csqmax_s, cand_s, gm_s, active ? tile : p.n_tiles, r, D,
+                                                              buf_floats, 0, FILT ? next : -1, rn);
         RQ_TRACE(trace_slot);
         ++trace_slot;
     }
     // cooperative tiles (resident mode only), one per workgroup at a time, by the first four waves -- the oldest
     // wave of each SIMD, which finishes its own tile of a full round first
-    if (wave < kCoopWaves) {
+    if (resident && wave < kCoopWaves) {
         int phase = 0;
         // (fetching the next cooperative tile's rows under the current one was measured: no gain)
         for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
             float raw[KSTEPS], r[KSTEPS];
             load_rows(tile, raw);
             unpack_rows(raw, r);
-            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN, FILT>(p, smem, csqmax_s, cand_s, tile, r, D, buf_floats, phase);
+            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN, FILT, RES>(p, smem, csqmax_s, cand_s, gm_s, tile, r, D, buf_floats, phase, -1,
+                                                                 raw);
             phase += L;
             RQ_TRACE(trace_slot);
             ++trace_slot;
@@ -947,12 +1126,59 @@ extern "C" int rqhip_debug_trace(unsigned long long *out, int clear) {
 }
 #endif
 
+// ---- the scores the filtered scan ranks by, written out (tests only) -------------------------------------------------
+// One wave per 32 rows; 64 codes staged at a time with the product kernels' own staging, split and instruction chain.
+template <int KSTEPS>
+__global__ __launch_bounds__(64) void filter_scores_kernel(const float *__restrict__ x, long long B, const float *__restrict__ cb,
+                                                           const float *__restrict__ csq, int K, float *__restrict__ scores) {
+    constexpr int S = KSTEPS / 8, D = 2 * KSTEPS, Kc = 64;
+    __shared__ __attribute__((aligned(16))) float buf[Kc * (2 * KSTEPS + 2)];
+    const int lane = threadIdx.x & 63, il = lane & 31, h = lane >> 5;
+    const long long row = (long long)blockIdx.x * 32 + il;
+    float r[KSTEPS];
+    load_pair_row_vec<KSTEPS>(x + (size_t)(row < B ? row : B - 1) * D, h, r);
+    rq_bf16x8 xh[S], xl[S];
+    split_row<KSTEPS>(r, xh, xl);
+    const rq_bf16x8 ones = split_ones(h);
+    for (int kbase = 0; kbase < K; kbase += Kc) {
+        __syncthreads();
+        stage_codes_bf16<KSTEPS, 64>(buf, Kc * (2 * KSTEPS + 2), 1, cb, csq, 0, kbase, Kc, K);
+        __syncthreads();
+        const rq_bf16x8 *img = reinterpret_cast<const rq_bf16x8 *>(buf);
+        const rq_bf16x4 *qimg = reinterpret_cast<const rq_bf16x4 *>(buf + 2 * KSTEPS * Kc);
+        for (int t = 0; t < Kc / 32; ++t) {
+            rq_bf16x8 a[2 * S];
+#pragma unroll
+            for (int b = 0; b < 2 * S; ++b) a[b] = img[(size_t)(b * 2 + h) * Kc + t * 32 + il];
+            const rq_bf16x4 q = qimg[t * 32 + il];
+            const rq_bf16x8 aq = {q[0], q[1], q[2], q[3], (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+            const f32x16 acc = split_scores<S>(a, aq, xh, xl, ones);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int k = kbase + t * 32 + 8 * (j >> 2) + 4 * h + (j & 3);
+                if (row < B && k < K) scores[(size_t)row * K + k] = acc[j];
+            }
+        }
+    }
+}
+
 // threads per workgroup by register appetite: <= 168 VGPRs at KSTEPS <= 16 (3 waves/SIMD), 256 at 32, 512 at 64
 template <int KSTEPS>
 struct WgThreads { static constexpr int value = KSTEPS <= 16 ? 768 : KSTEPS == 32 ? 512 : 256; };
 
+int launch_rq_forward_valu(const float *res0, int64_t B, int D, const float *codebooks, int L, int K, int mode, float beta,
+                           int64_t *ids, float *embs, float *residuals, float *emb_sum, float *loss, float *embs_norm,
+                           const float *csq, int csq_stride, const float *csqmax, hipStream_t s);   // rq_forward_valu.hip
+
+// does this launch take the filtered scan?  D = 32 / 64, full-width aligned rows, no margins, not forced to fp32
+static bool filtered_launch(const RqFwdParams &p, unsigned flags) {
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    return (p.D == 32 || p.D == 64) && !p.tie_margin && !(flags & RQHIP_FWD_SCAN_FP32) && al16(p.res0) && al16(p.cb) &&
+           al16(p.embs) && al16(p.residuals) && al16(p.emb_sum);
+}
+
 template <int KSTEPS>
-static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hipStream_t s) {
+static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, unsigned flags, hipStream_t s) {
     constexpr int NT = WgThreads<KSTEPS>::value;
     auto go = [&](auto kern) -> int {
         // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of the per-call
@@ -967,18 +1193,21 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, hip
     };
     // full-width kernels move rows as float4s: every row pointer must be 16-byte aligned (rows are 8*KSTEPS bytes)
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool full = p.D == 2 * KSTEPS && al16(p.res0) && al16(p.embs) && al16(p.residuals) && al16(p.emb_sum);
+    const bool full = p.D == 2 * KSTEPS && al16(p.res0) && al16(p.cb) && al16(p.embs) && al16(p.residuals) && al16(p.emb_sum);
     const bool margin = p.tie_margin != nullptr;
-    // D = 32, aligned rows, no margins wanted: the filtered scan (bf16-split matrix products + exact scan of the rows that
-    // are too close to call).  RQ_NO_FILTER=1 keeps the all-fp32 scan (developer A/B switch, read once).
-    static const bool use_filter = getenv("RQ_NO_FILTER") == nullptr;
-    if constexpr (KSTEPS == 16) {
-        if (full && !margin && use_filter) {
+    // D = 32 / 64, aligned rows, no margins wanted: the filtered scan (bf16-split matrix products + exact re-decision of
+    // the rows that are too close to call).  RQHIP_FWD_SCAN_FP32 keeps the all-fp32 scan (bench / test A/B).
+    if constexpr (KSTEPS == 16 || KSTEPS == 32) {
+        if (filtered_launch(p, flags)) {
+#define RQ_GOF(MODE_)                                                                       \
+    return p.resident ? go(rq_forward_kernel<KSTEPS, MODE_, true, NT, false, true, 1>)     \
+                      : go(rq_forward_kernel<KSTEPS, MODE_, true, NT, false, true, 0>)
             switch (mode) {
-                case RQHIP_MODE_EVAL: return go(rq_forward_kernel<16, RQHIP_MODE_EVAL, true, NT, false, true>);
-                case RQHIP_MODE_STE: return go(rq_forward_kernel<16, RQHIP_MODE_STE, true, NT, false, true>);
-                case RQHIP_MODE_ROTATION: return go(rq_forward_kernel<16, RQHIP_MODE_ROTATION, true, NT, false, true>);
+                case RQHIP_MODE_EVAL: RQ_GOF(RQHIP_MODE_EVAL);
+                case RQHIP_MODE_STE: RQ_GOF(RQHIP_MODE_STE);
+                case RQHIP_MODE_ROTATION: RQ_GOF(RQHIP_MODE_ROTATION);
             }
+#undef RQ_GOF
         }
     }
 #define RQ_GO(MODE_)                                                                                              \
@@ -1011,10 +1240,51 @@ extern "C" size_t rqhip_rq_forward_workspace_bytes(int L, int K) {
     return ((size_t)L * pad32(K) + (size_t)L) * sizeof(float);
 }
 
+extern "C" int rqhip_filter_scores(const float *x, int64_t B, int D, const float *codebook, int K, float *scores,
+                                   void *workspace, size_t workspace_bytes, rqhip_stream_t stream) {
+    if (B < 0 || K < 1 || K > 65536 || (B > 0 && (!x || !codebook || !scores))) {
+        set_error("filter_scores: bad arguments");
+        return RQHIP_EARG;
+    }
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if ((D != 32 && D != 64) || !al16(x) || !al16(codebook)) {
+        set_error("filter_scores: the filtered scan exists for D = 32 / 64 and 16-byte aligned rows only (D = %d)", D);
+        return RQHIP_EUNSUPPORTED;
+    }
+    if (!workspace || workspace_bytes < rqhip_rq_forward_workspace_bytes(1, K)) {
+        set_error("filter_scores: workspace too small");
+        return RQHIP_EWORKSPACE;
+    }
+    if (B == 0) return RQHIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int Kp = pad32(K);
+    float *csq = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(rq_csq_kernel, dim3(1), dim3(256), 0, s, codebook, 1, K, Kp, D, csq, csq + Kp);
+    RQ_CHECK_LAUNCH("rq_csq_kernel");
+    const int grid = (int)((B + 31) / 32);
+    if (D == 32) hipLaunchKernelGGL(filter_scores_kernel<16>, dim3(grid), dim3(64), 0, s, x, (long long)B, codebook, csq, K, scores);
+    else hipLaunchKernelGGL(filter_scores_kernel<32>, dim3(grid), dim3(64), 0, s, x, (long long)B, codebook, csq, K, scores);
+    RQ_CHECK_LAUNCH("filter_scores_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" void rqhip_filter_bound(float *c1, float *c2) {
+    if (c1) *c1 = kFiltC1;
+    if (c2) *c2 = kFiltC2;
+}
+
 extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                                 int mode, float beta, int64_t *ids, float *embs, float *residuals,
                                 float *emb_sum, float *loss, float *embs_norm, float *tie_margin, void *workspace,
                                 size_t workspace_bytes, rqhip_stream_t stream) {
+    return rqhip_rq_forward_ex(res0, B, D, codebooks, L, K, mode, beta, ids, embs, residuals, emb_sum, loss, embs_norm,
+                               tie_margin, workspace, workspace_bytes, 0u, stream);
+}
+
+extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                                   int mode, float beta, int64_t *ids, float *embs, float *residuals,
+                                   float *emb_sum, float *loss, float *embs_norm, float *tie_margin, void *workspace,
+                                   size_t workspace_bytes, unsigned flags, rqhip_stream_t stream) {
     if (B < 0 || !codebooks || (B > 0 && (!res0 || !ids))) {
         set_error("rq_forward: null pointer or negative B");
         return RQHIP_EARG;
@@ -1025,6 +1295,10 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     }
     if (mode != RQHIP_MODE_EVAL && mode != RQHIP_MODE_STE && mode != RQHIP_MODE_ROTATION) {
         set_error("rq_forward: mode %d is not EVAL/STE/ROTATION (Gumbel has its own entry point)", mode);
+        return RQHIP_EARG;
+    }
+    if (flags & ~(RQHIP_FWD_SCAN_FP32 | RQHIP_FWD_SCAN_VALU | RQHIP_FWD_NO_COOP_TAIL)) {
+        set_error("rq_forward: unknown flags 0x%x", flags);
         return RQHIP_EARG;
     }
     if (!workspace || workspace_bytes < rqhip_rq_forward_workspace_bytes(L, K)) {
@@ -1040,6 +1314,14 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     hipLaunchKernelGGL(rq_csq_kernel, dim3(L), dim3(256), 0, s, codebooks, L, K, Kp, D, csq, csqmax);
     RQ_CHECK_LAUNCH("rq_csq_kernel");
 
+    if (flags & RQHIP_FWD_SCAN_VALU) {
+        if (tie_margin) {
+            set_error("rq_forward (VALU scan): tie_margin is not available");
+            return RQHIP_EUNSUPPORTED;
+        }
+        return launch_rq_forward_valu(res0, B, D, codebooks, L, K, mode, beta, ids, embs, residuals, emb_sum, loss, embs_norm,
+                                      csq, Kp, csqmax, s);
+    }
     const int ksteps = ksteps_for(D);
     const int Dp = ksteps * 2;
     RqFwdParams p;
@@ -1047,23 +1329,39 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     p.ids = ids; p.embs = embs; p.residuals = residuals; p.emb_sum = emb_sum; p.loss = loss;
     p.embs_norm = embs_norm; p.tie_margin = tie_margin;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
-    const size_t level_bytes = (size_t)Kp * (Dp + 1) * sizeof(float);
-    if (level_bytes * L + 64 + kCoopLdsFloats * sizeof(float) <= (size_t)kLdsBudget) {
+    p.tpg = 1; p.ngroups = 0; p.gm16 = 0;
+    const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
+    const bool filt = filtered_launch(p, flags);
+    // per code: the operand image (Dp words) + its squared norm (fp32 scan) or the three bf16 pieces of -|c|^2/2 (filtered)
+    const size_t code_bytes = (size_t)(Dp + (filt ? 2 : 1)) * sizeof(float);
+    const size_t fixed_bytes = 64 + kCoopLdsFloats * sizeof(float);
+    // filtered scan: 8 group maxima per lane and wave, fp32 -- or bf16 (rounded up) when LDS is short
+    const size_t gm32 = filt ? (size_t)waves_per_wg * 8 * 64 * sizeof(float) : 0;
+    size_t gm_bytes = gm32;
+    const size_t level_bytes = (size_t)Kp * code_bytes;
+    if (level_bytes * L + fixed_bytes + gm_bytes <= (size_t)kLdsBudget) {
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
         p.resident = 0;
         // one workgroup per CU (its waves fill the register file), so a chunk may use the whole LDS
-        int kc = (int)(((size_t)kLdsBudget - 64 - kCoopLdsFloats * sizeof(float)) / ((size_t)(Dp + 1) * sizeof(float)));
+        if (filt && level_bytes + fixed_bytes + gm32 > (size_t)kLdsBudget && level_bytes + fixed_bytes + gm32 / 2 <= (size_t)kLdsBudget) {
+            p.gm16 = 1;   // K = 1024 at D = 32: the whole level fits beside half-width group maxima
+            gm_bytes = gm32 / 2;
+        }
+        int kc = (int)(((size_t)kLdsBudget - fixed_bytes - gm_bytes) / code_bytes);
         kc &= ~63;
         if (kc > Kp) kc = Kp;
         if (kc < 64) kc = 64;
         p.Kc = kc; p.nchunks = (Kp + kc - 1) / kc;
     }
-    const size_t lds = (size_t)p.Kc * (Dp + 1) * sizeof(float) * (p.resident ? L : 1) + 16 * sizeof(float) +
-                       (size_t)kCoopLdsFloats * sizeof(float);
+    if (filt) {
+        const int tiles = p.nchunks * (p.Kc / 32);   // code tiles a wave scans per level (padding included)
+        p.tpg = (tiles + 7) / 8;
+        p.ngroups = (tiles + p.tpg - 1) / p.tpg;
+    }
+    const size_t lds = (size_t)p.Kc * code_bytes * (p.resident ? L : 1) + fixed_bytes + gm_bytes;
     const int cus = cu_count();
     const int wg_per_cu = 1;  // 768 / 512 / 256 threads at <= 168 / 256 / 512 VGPRs: one workgroup fills a CU
-    const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
     long long cap = (long long)cus * wg_per_cu;
     // small batches (at most four row tiles per CU): every tile is cooperative, one workgroup per tile at a time
@@ -1077,18 +1375,17 @@ extern "C" int rqhip_rq_forward(const float *res0, int64_t B, int D, const float
     // four SIMDs), not per wave slot: at D = 64 (8 waves per workgroup) 3125 tiles are 3 x 1024 + 53, and the 53 used to
     // run as ordinary tiles of a fourth SIMD round on 53 CUs.
     p.coop_first = all_coop ? 0 : p.n_tiles;
-    static const bool coop_tail = getenv("RQ_NO_COOP_TAIL") == nullptr;  // developer A/B switch, read once
-    if (!all_coop && p.resident && coop_tail) {
+    if (!all_coop && p.resident && !(flags & RQHIP_FWD_NO_COOP_TAIL)) {
         const long long rem = p.n_tiles % ((long long)grid * 4);
         if (rem > 0 && rem <= grid) p.coop_first = p.n_tiles - rem;
     }
     p.n_iter = (int)((p.coop_first + total_waves - 1) / total_waves);
 
     switch (ksteps) {
-        case 4: return launch_mode<4>(p, mode, grid, lds, s);
-        case 8: return launch_mode<8>(p, mode, grid, lds, s);
-        case 16: return launch_mode<16>(p, mode, grid, lds, s);
-        case 32: return launch_mode<32>(p, mode, grid, lds, s);
-        default: return launch_mode<64>(p, mode, grid, lds, s);
+        case 4: return launch_mode<4>(p, mode, grid, lds, flags, s);
+        case 8: return launch_mode<8>(p, mode, grid, lds, flags, s);
+        case 16: return launch_mode<16>(p, mode, grid, lds, flags, s);
+        case 32: return launch_mode<32>(p, mode, grid, lds, flags, s);
+        default: return launch_mode<64>(p, mode, grid, lds, flags, s);
     }
 }

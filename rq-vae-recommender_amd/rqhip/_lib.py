@@ -14,9 +14,11 @@ import subprocess
 import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-SO_PATH = os.environ.get("RQHIP_SO", os.path.join(_CSRC, "librqhip.so"))  # RQHIP_SO: developer override (A/B builds)
+SO_PATH = os.path.join(_CSRC, "librqhip.so")
 
 MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
+# rqhip_rq_forward_ex flags (include/rqhip.h)
+FWD_SCAN_FP32, FWD_SCAN_VALU, FWD_NO_COOP_TAIL = 0x1, 0x2, 0x10
 
 # every symbol include/rqhip.h declares: (restype, argtypes)
 _i64, _int, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
@@ -27,6 +29,10 @@ SIGNATURES = {
     "rqhip_rq_forward_workspace_bytes": (_sz, [_int, _int]),
     "rqhip_rq_forward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _sz, _vp]),
+    "rqhip_rq_forward_ex": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _sz, C.c_uint, _vp]),
+    "rqhip_filter_bound": (None, [C.POINTER(_f32), C.POINTER(_f32)]),
+    "rqhip_filter_scores": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _sz, _vp]),
     "rqhip_rq_backward_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "rqhip_rq_backward_plan": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "rqhip_rq_backward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -77,20 +83,26 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def load(path: str) -> C.CDLL:
+    """Bind every symbol of include/rqhip.h in the library at `path` and make it the one `lib()` returns.  Called
+    implicitly with the in-tree build; developer tools (tools/ab_*.py) call it with another build of the same ABI
+    BEFORE the first op to compare two builds -- an explicit call, not an environment switch."""
+    global _lib
+    if not os.path.exists(path):
+        raise RqHipError(
+            f"{path} not found: build it with `python __graft_entry__.py` or `make -C {_CSRC}`. "
+            "The HIP extension is the product path; there is no CPU fallback.")
+    handle = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here == header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = handle
+    return handle
+
+
 def lib() -> C.CDLL:
     """The loaded library; raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise RqHipError(
-                f"{SO_PATH} not found: build it with `python __graft_entry__.py` or `make -C {_CSRC}`. "
-                "The HIP extension is the product path; there is no CPU fallback.")
-        handle = C.CDLL(SO_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)  # AttributeError here == header/library mismatch
-            fn.restype, fn.argtypes = res, args
-        _lib = handle
-    return _lib
+    return _lib if _lib is not None else load(SO_PATH)
 
 
 def check(rc: int, what: str) -> None:

@@ -60,10 +60,41 @@ class RqForwardOut(NamedTuple):
 TIE_TAU = 1e-6  # rows with tie_margin below this are near-ties: another correct fp32 evaluation may pick the other code
 
 
+_SCAN_FLAGS = {"auto": 0, "fp32": _lib.FWD_SCAN_FP32, "valu": _lib.FWD_SCAN_VALU}
+
+
+def filter_bound():
+    """(c1, c2) of the filtered scan's too-close-to-call threshold (rqhip_filter_bound; host-side, no GPU needed)."""
+    import ctypes as C
+    c1, c2 = C.c_float(0), C.c_float(0)
+    _lib.lib().rqhip_filter_bound(C.byref(c1), C.byref(c2))
+    return c1.value, c2.value
+
+
+def filter_scores(x: Tensor, codebook: Tensor) -> Tensor:
+    """The approximate scores x.c_k - |c_k|^2/2 the filtered scan ranks by (rqhip_filter_scores; test hook of the error
+    bound).  x [B,D], codebook [K,D], D = 32 or 64 -> [B,K] fp32."""
+    _need_gpu(x, codebook)
+    x, codebook = _f32c(x, "x"), _f32c(codebook, "codebook")
+    B, D = x.shape
+    K = codebook.shape[0]
+    with torch.cuda.device(x.device):
+        l = _lib.lib()
+        out = torch.empty((B, K), dtype=torch.float32, device=x.device)
+        wsb = l.rqhip_rq_forward_workspace_bytes(1, K)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+        check(l.rqhip_filter_scores(_ptr(x), B, D, _ptr(codebook), K, _ptr(out), _ptr(ws), wsb, _stream()),
+              "rqhip_filter_scores")
+    return out
+
+
 def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_embs: bool = True,
                want_residuals: bool = True, want_emb_sum: bool = True, want_loss: bool = True,
-               want_norm: bool = True, want_margin: bool = False) -> RqForwardOut:
-    """L fused quantisation levels (rqhip_rq_forward).  res0 [B,D], codebooks [L,K,D]."""
+               want_norm: bool = True, want_margin: bool = False, scan: str = "auto",
+               coop_tail: bool = True) -> RqForwardOut:
+    """L fused quantisation levels (rqhip_rq_forward_ex).  res0 [B,D], codebooks [L,K,D].
+    scan: "auto" (the filtered bf16-split scan where it applies, else fp32 MFMA), "fp32" (always the fp32 MFMA scan),
+    "valu" (LDS/VALU scan, D = 32 only) -- same bits from all three, for A/B timing and tests."""
     _need_gpu(res0, codebooks)
     res0, codebooks = _f32c(res0, "res0"), _f32c(codebooks, "codebooks")
     if res0.dim() != 2 or codebooks.dim() != 3 or codebooks.shape[2] != res0.shape[1]:
@@ -83,10 +114,11 @@ def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_
         margin = f(L, B) if want_margin else None
         wsb = l.rqhip_rq_forward_workspace_bytes(L, K)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-        rc = l.rqhip_rq_forward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(embs),
-                                _ptr(residuals), _ptr(emb_sum), _ptr(loss), _ptr(norm), _ptr(margin), _ptr(ws), wsb,
-                                _stream())
-        check(rc, "rqhip_rq_forward")
+        flags = _SCAN_FLAGS[scan] | (0 if coop_tail else _lib.FWD_NO_COOP_TAIL)
+        rc = l.rqhip_rq_forward_ex(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(embs),
+                                   _ptr(residuals), _ptr(emb_sum), _ptr(loss), _ptr(norm), _ptr(margin), _ptr(ws), wsb,
+                                   flags, _stream())
+        check(rc, "rqhip_rq_forward_ex")
     return RqForwardOut(ids, embs, residuals, emb_sum, loss, norm, margin)
 
 

@@ -161,21 +161,16 @@ def test_forward_full_size_properties(B, D, K, L, mode):
     assert torch.equal(plain.ids.cpu(), ids) and torch.equal(plain.loss.cpu(), out.loss.cpu())
 
 
-@pytest.mark.parametrize("flavour", ["random", "clustered", "near_duplicate_codes", "tiny_scale", "mixed_scale",
-                                     "rows_dwarf_codes", "codes_dwarf_rows"])
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_filtered_scan_returns_the_fp32_scan(flavour, mode):
-    """D = 32 launches without margins scan with bf16-split matrix products and re-check, exactly, every row whose two
-    smallest approximate distances are closer than the error bound (csrc/rq_forward.hip, FILT).  The all-fp32 kernel
-    (selected by asking for margins, itself bit-exact vs the oracle in the tests above) must be reproduced bit for bit
-    -- ids, losses, sums -- on many rows, including data built to sit on the decision boundaries."""
-    from rqhip import ops
-    g = torch.Generator().manual_seed(100 + mode)
-    B, D, K, L = 300_000, 32, 256, 3
+def _filter_flavour(flavour, mode, D=32):
+    """(x [B,D], cb [L,K,D]) torch CPU tensors built to sit on the filtered scan's decision boundaries."""
+    g = torch.Generator().manual_seed(100 + mode + D)
+    B, K, L = 100_000, 256, 3
     if flavour == "random":
+        B = 300_000
         x = torch.randn(B, D, generator=g) * 0.5
         cb = torch.randn(L, K, D, generator=g) * 0.3
     elif flavour == "clustered":          # codebook = perturbed data points: many rows close to two codes
+        B = 300_000
         x = torch.randn(B, D, generator=g) * 0.5
         cb = torch.stack([x[torch.randperm(B, generator=g)[:K]] / (l + 1) + 0.02 * torch.randn(K, D, generator=g)
                           for l in range(L)])
@@ -184,36 +179,111 @@ def test_filtered_scan_returns_the_fp32_scan(flavour, mode):
         half = torch.randn(L, K // 2, D, generator=g) * 0.3
         twin = half * (1.0 + 3e-7 * torch.randn(L, K // 2, D, generator=g))
         cb = torch.cat([half, twin], dim=1)
-        B = 40_000                          # (all rows take the exact path)
-        x = x[:B]
     elif flavour == "tiny_scale":           # |x|^2 max|c|^2 underflows: the bound is meaningless, every row goes exact
-        B = 40_000
         x = torch.randn(B, D, generator=g) * 1e-18
         cb = torch.randn(L, K, D, generator=g) * 1e-18
     elif flavour in ("rows_dwarf_codes", "codes_dwarf_rows"):
         # |x| >> every |c| (or the reverse): all distances of a row agree in their leading digits, neighbouring codes
         # differ by a few ulps of the distance itself -- the fp32 rounding of d decides, not the dot-product error
-        B = 100_000
         big, small = (1.0e5, 1.0) if flavour == "rows_dwarf_codes" else (1.0, 1.0e5)
         x = torch.randn(B, D, generator=g) * big
         cb = torch.randn(L, K, D, generator=g) * small
-    else:                                   # rows and codes spread over twelve orders of magnitude
-        B = 40_000
+    elif flavour == "split_worst_case":
+        # the operands of tests/test_filter_bound.py: every mantissa on the bf16 split's worst case, |x_d| proportional to
+        # |c_d|, error signs aligned for one code and opposed for its mirror -- tiled to full size, every level
+        import test_filter_bound as fb
+        xw, cw = fb._worst_case_operands(D, n_rows=64, seed=mode)
+        rep = torch.from_numpy(xw).repeat(B // 64 + 1, 1)[:B]
+        x = rep * (1.0 + 2.0 ** -20 * torch.randint(-8, 9, (B, 1), generator=g).float())      # rows a few ulps apart
+        cb = torch.from_numpy(cw[:K]).unsqueeze(0).repeat(L, 1, 1) * torch.tensor([1.0, 0.5, 0.25]).view(L, 1, 1)
+    else:                                   # mixed_scale: rows and codes spread over twelve orders of magnitude
         x = torch.randn(B, D, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (B, 1), generator=g).float())
         cb = torch.randn(L, K, D, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (L, K, 1), generator=g).float())
-    x, cb = x.cuda().contiguous(), cb.cuda().contiguous()
-    ref = ops.rq_forward(x, cb, mode, 0.25, want_margin=True, want_embs=False, want_residuals=False)
-    got = ops.rq_forward(x, cb, mode, 0.25, want_embs=False, want_residuals=False)
-    assert torch.equal(got.ids, ref.ids), int((got.ids != ref.ids).sum())
-    assert torch.equal(got.loss.view(torch.int32), ref.loss.view(torch.int32))
-    assert torch.equal(got.emb_sum.view(torch.int32), ref.emb_sum.view(torch.int32))
-    # the K = 1024, four-level shape of configuration 4 (staged in chunks, workgroup-wide barriers around the re-checks)
-    if flavour in ("random", "clustered") and mode == 1:
-        cb4 = (torch.randn(4, 1024, D, generator=g) * 0.3).cuda()
-        x4 = x[:125_000]
-        ref = ops.rq_forward(x4, cb4, mode, 0.25, want_margin=True, want_embs=False, want_residuals=False)
-        got = ops.rq_forward(x4, cb4, mode, 0.25, want_embs=False, want_residuals=False)
-        assert torch.equal(got.ids, ref.ids) and torch.equal(got.loss.view(torch.int32), ref.loss.view(torch.int32))
+    return x.contiguous(), cb.contiguous()
+
+
+def _recheck_rate(x, cb, mode):
+    """Fraction of (row, level) decisions whose EXACT top-2 distance gap is below the filter's threshold T: an estimate
+    of how many rows the filtered kernel re-decides exactly (it tests the approximate gap, which differs by < T)."""
+    from rqhip import ops
+    c1, c2 = ops.filter_bound()
+    out = ops.rq_forward(x, cb, mode, 0.25, want_margin=True, want_embs=False)
+    res = out.residuals                                     # [L,B,D]
+    xsq = (res.double() ** 2).sum(-1)                       # [L,B]
+    csq = (cb.double() ** 2).sum(-1)                        # [L,K]
+    cwin = torch.gather(csq, 1, out.ids)                    # [L,B]
+    gap = out.tie_margin.double() * (xsq + cwin)
+    T = c1 * torch.sqrt(xsq * csq.max(dim=1, keepdim=True).values) + c2 * (xsq + csq.max(dim=1, keepdim=True).values)
+    return float((gap <= T).double().mean())
+
+
+@pytest.mark.parametrize("flavour", ["random", "clustered", "near_duplicate_codes", "tiny_scale", "mixed_scale",
+                                     "rows_dwarf_codes", "codes_dwarf_rows", "split_worst_case"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_filtered_scan_equals_the_oracle(flavour, mode):
+    """D = 32 launches without margins rank the codes by bf16-split scores on the matrix cores and re-decide, with the
+    oracle's arithmetic, every row whose two best scores are closer than the proven error bound (csrc/rq_forward.hip
+    FILT; tests/test_filter_bound.py).  The product launch must reproduce THE ORACLE bit for bit -- ids, losses, sums --
+    on >= 100 000 rows of every flavour of data built to sit on the decision boundaries."""
+    from rqhip import ops
+    x, cb = _filter_flavour(flavour, mode)
+    xg, cg = x.cuda(), cb.cuda()
+    got = ops.rq_forward(xg, cg, mode, 0.25, want_embs=False, want_residuals=False)
+    ref = o.rq_forward(x.numpy(), cb.numpy(), mode, 0.25)
+    _assert_bitexact(got.ids.cpu().numpy(), ref["ids"], f"ids ({flavour}, mode {mode})")
+    _assert_bitexact(got.loss.cpu().numpy(), ref["loss"], f"loss ({flavour}, mode {mode})")
+    _assert_bitexact(got.emb_sum.cpu().numpy(), ref["emb_sum"], f"emb_sum ({flavour}, mode {mode})")
+    _assert_bitexact(got.embs_norm.cpu().numpy(), ref["embs_norm"], f"embs_norm ({flavour}, mode {mode})")
+    # the all-fp32 scan and the product scan are interchangeable
+    f32 = ops.rq_forward(xg, cg, mode, 0.25, want_embs=False, want_residuals=False, scan="fp32")
+    assert torch.equal(f32.ids, got.ids) and torch.equal(f32.loss.view(torch.int32), got.loss.view(torch.int32))
+    print(f"{flavour} mode {mode}: {x.shape[0]} rows, estimated exact re-decisions {100 * _recheck_rate(xg, cg, mode):.3f} % "
+          "of the (row, level) decisions")
+
+
+@pytest.mark.parametrize("flavour", ["random", "clustered", "split_worst_case"])
+def test_filtered_scan_equals_the_oracle_other_shapes(flavour):
+    """The K = 1024, four-level shape of configuration 4 (one level at a time in LDS, half-width group maxima), a K that
+    is not a multiple of the tile and D = 64 (configuration 3's width) -- against the oracle, bit for bit."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(7)
+    x, cb = _filter_flavour(flavour, 1)
+    x4 = x[:125_000]
+    cb4 = torch.cat([cb[:, :, :], cb[:, :, :] * 0.7 + 0.01 * torch.randn(cb.shape, generator=g),
+                     torch.randn(3, 512, 32, generator=g) * cb.abs().mean()], dim=1)            # [3,1024,32]
+    cb4 = torch.cat([cb4, cb4[:1] * 0.3], dim=0).contiguous()                                   # [4,1024,32]
+    cases = [(x4, cb4, 1), (x[:60_000], cb[:, :200].contiguous(), 0)]
+    x64, cb64 = _filter_flavour(flavour, 2, D=64)
+    cases.append((x64[:100_000], cb64, 2))
+    cases.append((x64[:40_000], cb64, 1))
+    for xx, cc, mode in cases:
+        got = ops.rq_forward(xx.cuda(), cc.cuda(), mode, 0.25, want_embs=False, want_residuals=False)
+        ref = o.rq_forward(xx.numpy(), cc.numpy(), mode, 0.25)
+        what = f"({flavour}, {tuple(xx.shape)} x {tuple(cc.shape)}, mode {mode})"
+        _assert_bitexact(got.ids.cpu().numpy(), ref["ids"], "ids " + what)
+        _assert_bitexact(got.loss.cpu().numpy(), ref["loss"], "loss " + what)
+        _assert_bitexact(got.emb_sum.cpu().numpy(), ref["emb_sum"], "emb_sum " + what)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("B,K,L", [(1, 256, 3), (1000, 256, 3), (100_000, 256, 3), (5000, 1024, 4), (777, 37, 2)])
+def test_valu_scan_equals_the_oracle(mode, B, K, L):
+    """The LDS / vector-ALU form of the forward (csrc/rq_forward_valu.hip, RQHIP_FWD_SCAN_VALU) -- the kernel the MFMA
+    form is measured against -- returns the oracle's bits too."""
+    from rqhip import ops
+    rng = np.random.default_rng(B + K + L + mode)
+    x = (rng.standard_normal((B, 32)) * 0.7).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, 32)) * np.array([0.6 / (l + 1) for l in range(L)])[:, None, None]).astype(np.float32)
+    if B >= 1000:
+        x[5] = np.nan
+        x[6, 3] = np.inf
+        x[7] = 3e19
+    ref = o.rq_forward(x, cbs, mode, 0.25)
+    out = ops.rq_forward(_gpu(x), _gpu(cbs), mode, 0.25, scan="valu")
+    for k in ("ids", "embs", "residuals", "emb_sum", "loss", "embs_norm"):
+        _assert_bitexact(getattr(out, k).cpu().numpy(), ref[k], f"{k} (VALU scan, mode {mode}, B={B}, K={K})")
+    with pytest.raises(ops.RqHipError):
+        ops.rq_forward(_gpu(x), _gpu(cbs), 2, 0.25, scan="valu")          # rotation trick: MFMA kernels only
 
 
 # ---------------------------------------------------------------- backward ---------------------------
