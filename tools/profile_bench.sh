@@ -1,21 +1,23 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 900 -- 'TAG=r02 bash tools/profile_bench.sh'
+#   gpurun --timeout 900 -- 'TAG=r03 [CFG=c4] bash tools/profile_bench.sh'
 # Pass 1: --kernel-trace --stats of the default bench (no CPU baseline leg).  Passes 2, 3: one PMC counter each
 # (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only -- never combined with sys/hip traces.  Outputs under
 # gpurun_out/prof_$TAG/; tools/summarize_profile.py turns them into the files committed under profiles/.
 set -u
 REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
-TAG="${TAG:-r02}"
-OUT="$REPO/gpurun_out/prof_$TAG"
+TAG="${TAG:-r03}"
+CFG="${CFG:-c2}"   # c2 | c4
+OUT="$REPO/gpurun_out/prof_${TAG}$([ $CFG = c2 ] || echo _$CFG)"
 mkdir -p "$OUT"
+sha256sum "$REPO/rq-vae-recommender_amd/csrc/librqhip.so" > "$OUT/librqhip.sha256"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 300 python "$REPO/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"   # the default line: 200 steps, parity gate, CPU baseline
+timeout -k 5 300 python "$REPO/bench.py" --config $CFG > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"   # the default line: 200 steps, parity gate, CPU baseline
 timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
-    python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-parity > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+    python "$REPO/bench.py" --config $CFG --steps $([ $CFG = c2 ] && echo 20 || echo 3) --warmup 3 --no-cpu-baseline --no-parity --min-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
-        python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-parity > /dev/null 2> "$OUT/pmc_$c.err"
+        python "$REPO/bench.py" --config $CFG --steps $([ $CFG = c2 ] && echo 5 || echo 1) --warmup 2 --no-cpu-baseline --no-parity --min-seconds 0 > /dev/null 2> "$OUT/pmc_$c.err"
 done
 # keep what summarize_profile.py reads (gpurun copies back at most 64 MiB): the stats table, and the counter rows
 # of the hand-written kernels; drop the per-dispatch traces

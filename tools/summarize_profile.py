@@ -2,7 +2,7 @@
 """Turn gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh on the GPU box) into the committed evidence:
    profiles/<tag>_bench_kernel_stats.csv, <tag>_bench_kernel_stats_summary.txt, <tag>_bench_n1.json,
    <tag>_pmc_traffic_c2.json (the file bench.py reads `roofline.traffic` from)
-usage: python tools/summarize_profile.py [tag, default r02]"""
+usage: python tools/summarize_profile.py [tag, default r03] [c2 | c4]"""
 import csv
 import glob
 import json
@@ -11,8 +11,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+CFG = sys.argv[2] if len(sys.argv) > 2 else "c2"
+SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}" + ("" if CFG == "c2" else f"_{CFG}"))
+PRE = TAG if CFG == "c2" else f"{TAG}_{CFG}"     # file-name prefix under profiles/
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -23,18 +25,20 @@ def one(pattern):
     return hits[-1]
 
 
+sha_file = os.path.join(SRC, "librqhip.sha256")
+lib_sha = open(sha_file).read().split()[0] if os.path.exists(sha_file) else None
 bench = json.loads(open(os.path.join(SRC, "bench_n1.json")).read().strip().splitlines()[-1])
-with open(os.path.join(DST, f"{TAG}_bench_n1.json"), "w") as f:
+with open(os.path.join(DST, f"{PRE}_bench_n1.json"), "w") as f:
     f.write(json.dumps(bench) + "\n")
 
 stats = one("stats/**/*kernel_stats.csv")
-shutil.copyfile(stats, os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
+shutil.copyfile(stats, os.path.join(DST, f"{PRE}_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(DST, f"{TAG}_bench_kernel_stats_summary.txt"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity` (MI355X, {TAG})\n")
-    f.write(f"# bench line of the same build: profiles/{TAG}_bench_n1.json ({bench['value'] / 1e6:.2f} M items/s, "
+with open(os.path.join(DST, f"{PRE}_bench_kernel_stats_summary.txt"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --config {CFG} --steps {20 if CFG == 'c2' else 3} --warmup 3 --no-cpu-baseline --no-parity` (MI355X, {TAG}; librqhip.so sha256 {str(lib_sha)[:16]})\n")
+    f.write(f"# bench line of the same build: profiles/{PRE}_bench_n1.json ({bench['value'] / 1e6:.2f} M items/s, "
             f"{bench['ms_per_step']:.2f} ms/step; roofline launch mean {bench['roofline']['launch_ms_mean'] * 1e3:.1f} us by HIP events)\n")
-    f.write(f"# top kernels by total time; names shortened; full CSV: {TAG}_bench_kernel_stats.csv\n\n")
+    f.write(f"# top kernels by total time; names shortened; full CSV: {PRE}_bench_kernel_stats.csv\n\n")
     f.write(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}\n")
     for r in rows[:40]:
         f.write(f"{r['Name'][:70]:70s} {int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.1f} "
@@ -45,7 +49,9 @@ with open(os.path.join(DST, f"{TAG}_bench_kernel_stats_summary.txt"), "w") as f:
         f.write(f"{r['Name'][:70]:70s} {int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.1f} "
                 f"{float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f}\n")
 
-pmc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 5 "
+cfg_name = bench["config"].get("name", "c2")
+pmc = {"librqhip_sha256": lib_sha,   # of the library the counters were collected on (bench.py checks it before using them)
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 5 "
                   "--warmup 2 --no-cpu-baseline --no-parity   (tools/profile_bench.sh)",
        "note": "KB per launch; max = the B=100000 launches (mean includes the 20000-row k-means warm-up launch). gfx950 "
                "correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE under-reports coalesced streaming reads by "
@@ -69,16 +75,16 @@ fwk = [k for k in pmc["kernels"] if "rq_forward_kernel" in k and "FETCH_SIZE_KB_
        and "WRITE_SIZE_KB_max" in pmc["kernels"][k]]
 if fwk:
     v = pmc["kernels"][fwk[0]]
-    rows = bench["config"]["rows_per_gpu_per_step"]
+    rows = bench["config"]["micro_batch_rows"]
     corrected = (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024.0
     algorithmic = bench["roofline"]["hbm_view"]["algorithmic_bytes_per_row"] * rows
     pmc["rq_forward_kernel"] = {"rows_per_launch": rows, "hbm_bytes_per_launch_corrected": corrected,
                                 "algorithmic_bytes_per_launch": algorithmic, "ratio": corrected / algorithmic}
-with open(os.path.join(DST, f"{TAG}_pmc_traffic_c2.json"), "w") as f:
+with open(os.path.join(DST, f"{TAG}_pmc_traffic_{cfg_name}.json"), "w") as f:
     json.dump(pmc, f, indent=1)
     f.write("\n")
 fw = [k for k in pmc["kernels"] if "rq_forward_kernel" in k]
 for k in fw:
     v = pmc["kernels"][k]
     print(k, "-> traffic per launch (2*FETCH+WRITE) =", (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024 / 1e6, "MB")
-print(f"wrote profiles/{TAG}_*")
+print(f"wrote profiles/{PRE}_*")
