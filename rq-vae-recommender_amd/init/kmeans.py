@@ -22,18 +22,18 @@ import torch.distributed as dist
 
 from rqhip import ops
 
-# When True, kmeans_init_ treats `x` as THIS RANK'S BLOCK of the rows and runs the row-sharded Lloyd loop (one
-# all-reduce of [K, D+1] sums || counts per iteration).  train_rqvae sets it around the
-# warm-up forward when it feeds every rank its own slice of the first 20 000 items.
-SHARDED_INIT = False
 
+def kmeans_init_(tensor: torch.Tensor, x: torch.Tensor, rows_sharded: bool = False) -> None:
+    """Overwrite `tensor` [K,D] with k-means centroids of `x` [B,D] (in place, no grad).
 
-def kmeans_init_(tensor: torch.Tensor, x: torch.Tensor) -> None:
-    """Overwrite `tensor` [K,D] with k-means centroids of `x` [B,D] (in place, no grad)."""
+    rows_sharded (not in the reference's signature; default = its behaviour): `x` is THIS RANK'S BLOCK of the rows and
+    the Lloyd loop is the row-sharded one -- one all-reduce of [K, D+1] sums || counts per iteration (SURVEY.md section
+    8e).  Quantize passes its `kmeans_rows_sharded` attribute, which train_rqvae sets for the warm-up forward when it
+    feeds every rank its own slice of the first 20 000 items."""
     assert tensor.dim() == 2
     assert x.dim() == 2
     with torch.no_grad():
-        sharded = SHARDED_INIT and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        sharded = rows_sharded and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         out = Kmeans(k=tensor.shape[0]).run(x, sharded=sharded)
         tensor.data.copy_(out.centroids)
 

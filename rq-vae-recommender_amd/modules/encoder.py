@@ -17,10 +17,11 @@ from rqhip import ops, torch_ops
 
 
 def _grad_sink(w: Tensor):
-    """The parameter's slice of a flat gradient buffer (rqhip.dist.FlatGradReducer.attach), usable for the FIRST
-    gradient of a step only: later ones must be accumulated by autograd, not overwritten."""
-    view = getattr(w, "_rq_grad_view", None)
-    return view if (view is not None and w.grad is None) else None
+    """The parameter's slice of a flat gradient buffer (rqhip.dist.FlatGradReducer.attach), for the FIRST producer of
+    this parameter's gradient in a step only: later ones (the same MLP applied twice under one loss) get None and
+    return ordinary tensors, which autograd accumulates."""
+    from rqhip.dist import claim_grad_sink
+    return claim_grad_sink(w)
 
 
 def _adopt(gw: Tensor, sink) -> Tensor:

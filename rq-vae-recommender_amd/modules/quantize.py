@@ -78,6 +78,7 @@ class Quantize(nn.Module):
         self.distance_mode = distance_mode
         self.do_kmeans_init = do_kmeans_init
         self.kmeans_initted = False
+        self.kmeans_rows_sharded = False   # multi-GPU warm-up: the lazy init sees this rank's block of the rows only
         self.embedding = nn.Embedding(n_embed, embed_dim)
         # identity unless sim_vq / codebook_normalize: then ordinary torch ops in front of the kernel
         self.out_proj = nn.Sequential(
@@ -119,7 +120,7 @@ class Quantize(nn.Module):
 
     @torch.no_grad()
     def _kmeans_init(self, x: Tensor) -> None:
-        kmeans_init_(self.embedding.weight, x=x)
+        kmeans_init_(self.embedding.weight, x=x, rows_sharded=self.kmeans_rows_sharded)
         self.kmeans_initted = True
 
     def get_item_embeddings(self, item_ids: Tensor) -> Tensor:

@@ -179,7 +179,8 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         # (the kernels are fp32: a float64 / fp16 batch is compared in the model's dtype, as it was encoded)
         reconstruction = self.reconstruction_loss(x_hat, x if x.dtype == x_hat.dtype else x.to(x_hat.dtype))
         rqvae_loss = st.loss
-        if reconstruction.dim() == 1 and reconstruction.is_cuda and reconstruction.dtype == torch.float32:
+        if (reconstruction.dim() == 1 and reconstruction.is_cuda and reconstruction.dtype == torch.float32
+                and reconstruction.numel() > 0):   # (an empty batch keeps the reference's expression: three NaN means)
             # the three batch means of rqvae.py:154,171-172 in one launch
             if torch_ops.enabled():
                 loss, recon_mean, rq_mean = torch.ops.rqhip.loss_means(reconstruction, rqvae_loss).unbind(0)

@@ -56,9 +56,12 @@ class RqStackFunction(torch.autograd.Function):
         sink = ctx.grad_sink
         out_cb = None
         if need_cb and sink is not None and tuple(sink.view.shape) == tuple(codebooks.shape) and all(
-                p.grad is None for p in sink.params):
+                p.grad is None and getattr(p, "_rq_sink_epoch", -1) != sink.owner.epoch for p in sink.params):
             out_cb = sink.view      # first gradient of the step: straight into the flat buffer (autograd's stack backward
-                                    # hands each level's slice to its parameter as a view)
+                                    # hands each level's slice to its parameter as a view); claimed for this epoch, so a
+                                    # second pass of the same model under one loss accumulates through autograd instead
+            for p in sink.params:
+                p._rq_sink_epoch = sink.owner.epoch
         g_res0, g_cb = ops.rq_backward(res0, codebooks, ctx.mode, ctx.beta, ids, g_embs=_dense(g_embs),
                                        g_embsum=_dense(g_embsum), g_resid=_dense(g_resid), g_loss=_dense(g_loss),
                                        need_res0=need_res0, need_codebooks=need_cb, out_g_codebooks=out_cb)
@@ -132,10 +135,13 @@ class ReconLossFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
-        if ctx.spec:
+        if ctx.spec and not getattr(ctx, "spec_consumed", False):
+            # the speculative buffer is handed to autograd (and fixed up in place) ONCE; a second backward through a
+            # retained graph recomputes from x_hat and x below instead of returning the first call's tensor again
+            ctx.spec_consumed = True
             x_hat, x, g_spec = ctx.saved_tensors
             return ops.recon_loss_backward_spec(x_hat, x, _dense(g_out), ctx.row_scale, g_spec), None
-        x_hat, x = ctx.saved_tensors
+        x_hat, x = ctx.saved_tensors[:2]
         need_hat, need_x = ctx.needs_input_grad
         if not (need_hat or need_x):
             return None, None

@@ -6,8 +6,10 @@ accelerate's DDP wrap performs implicitly in the reference (train_rqvae.py:153,1
 and MI355X-shaped: after backward all gradients are packed into ONE flat fp32 buffer (4.6 MB for the Amazon
 config) with a single kernel, so a step issues exactly one in-place all-reduce -- the payload is far below
 the xGMI bandwidth regime, what matters is one collective instead of a bucket per layer -- followed by a 1/W
-scale (DDP's mean); the optimizer then reads views of that buffer.  k-means init runs on the first <= 20 000 rows, which every rank holds: rank 0 computes it and
-broadcasts the parameters (this also removes the reference's latent per-rank-divergent init).
+scale (DDP's mean); the optimizer then reads views of that buffer.  The k-means init is row-sharded too: every rank
+takes its block of the first <= 20 000 rows through the model, rank 0 draws the seed / reseed row numbers and
+broadcasts them, and each Lloyd iteration is one all-reduce of the [K, D+1] sums || counts (init/kmeans.py) -- which
+also removes the reference's latent per-rank-divergent init.
 
 On CPU (tests) the same code runs over the gloo backend.
 """
@@ -27,21 +29,27 @@ def env_world() -> tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_from_env(device_type: str = "cuda") -> tuple[int, int, int]:
-    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, local, world)."""
+def init_from_env(device_type: str = "cuda", backend: Optional[str] = None, force: bool = False,
+                  device_index: Optional[int] = None) -> tuple[int, int, int]:
+    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, local, world).
+
+    backend: default "nccl" (= RCCL) for cuda, "gloo" for cpu.  "gloo" with device tensors is what the tests use to run
+    TWO ranks of the product step on ONE GPU (RCCL refuses two ranks on one device; gloo stages through the host).
+    force: create the group even for a single rank (exercises the process-group code path).
+    device_index: the GPU this rank uses (default LOCAL_RANK)."""
     rank, local_rank, world = env_world()
-    force = os.environ.get("RQ_FORCE_DIST") == "1"  # exercise the process-group path with a single rank (tests)
+    dev = local_rank if device_index is None else device_index
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        backend = backend or ("nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(dev)
+        if device_type == "cuda" and backend == "nccl":
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return rank, local_rank, world
+    return rank, dev, world
 
 
 def world_size() -> int:
@@ -98,6 +106,7 @@ class FlatGradReducer:
         self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dtype)
         self._views = []
         self._offsets = []
+        self.epoch = 0      # bumped by zero_(): a slice may be written in place by ONE backward node per epoch
         offset = 0
         for p in self.params:
             n = p.numel()
@@ -111,6 +120,8 @@ class FlatGradReducer:
         from types import SimpleNamespace
         for p, v in zip(self.params, self._views):
             p._rq_grad_view = v
+            p._rq_grad_owner = self
+            p._rq_sink_epoch = -1
         layers = getattr(model, "layers", None)
         if layers is not None and len(layers) > 0 and all(hasattr(l, "embedding") for l in layers):
             cbs = [l.embedding.weight for l in layers]
@@ -120,11 +131,15 @@ class FlatGradReducer:
                 K, D = cbs[0].shape
                 off = self._offsets[idx[0]]
                 model._rq_cb_grad_sink = SimpleNamespace(view=self.flat[off:off + len(cbs) * K * D].view(len(cbs), K, D),
-                                                         params=cbs)
+                                                         params=cbs, owner=self)
         return self
 
     def zero_(self) -> None:
-        """Use instead of optimizer.zero_grad()."""
+        """Use instead of optimizer.zero_grad().  Starts a new epoch: until the next call, the FIRST backward node that
+        produces a parameter's gradient may write it straight into the parameter's slice (`claim_grad_sink`); any further
+        producer of the same parameter in the same backward pass -- one module applied twice under one loss -- sees the
+        slice taken and returns an ordinary tensor, which autograd accumulates."""
+        self.epoch += 1
         for p in self.params:
             p.grad = None
 
@@ -142,6 +157,19 @@ class FlatGradReducer:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / w)
         return self.flat
+
+
+def claim_grad_sink(w: Tensor):
+    """The slice of the flat buffer `w`'s gradient may be written into, or None.  Granted once per parameter and epoch
+    (`FlatGradReducer.zero_`) and only while `.grad` is unset: AccumulateGrad runs after ALL producers of a parameter
+    have run, so `w.grad is None` alone cannot tell the first producer from the second (two of them writing the same
+    slice and autograd then summing the alias with itself was a silent wrong gradient -- ADVICE r2)."""
+    view = getattr(w, "_rq_grad_view", None)
+    owner = getattr(w, "_rq_grad_owner", None)
+    if view is None or owner is None or w.grad is not None or getattr(w, "_rq_sink_epoch", -1) == owner.epoch:
+        return None
+    w._rq_sink_epoch = owner.epoch
+    return view
 
 
 @torch.no_grad()

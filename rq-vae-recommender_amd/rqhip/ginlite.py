@@ -4,6 +4,7 @@ The reference drives `train_rqvae.train` with gin (train_rqvae.py:24, modules/ut
 config files use a small subset of gin's grammar, which is all this module understands:
 
     import a.b.c                      -> importlib.import_module (registers enum constants as a side effect)
+    include 'other.gin'               -> gin's include: parse that file first (path relative to the including file)
     # comment
     scope.name = <python literal>     -> int / float / str / bool / None / list literals
     scope.name = %mod.path.Enum.MEMBER -> constants registered by @constants_from_enum
@@ -76,13 +77,19 @@ def _parse_value(text: str) -> Any:
         raise ValueError(f"ginlite cannot parse value {text!r} (supported: python literals and %constants)") from exc
 
 
-def parse_config(text: str) -> None:
+def parse_config(text: str, base_dir: str | None = None) -> None:
     for lineno, raw in enumerate(text.splitlines(), 1):
         line = raw.split("#", 1)[0].strip() if not ('"' in raw or "'" in raw) else _strip_comment(raw).strip()
         if not line:
             continue
         if line.startswith("import "):
             importlib.import_module(line[len("import "):].strip())
+            continue
+        if line.startswith("include "):
+            import os
+            inc = ast.literal_eval(line[len("include "):].strip())
+            parse_config_file(inc if os.path.isabs(inc) or base_dir is None or os.path.exists(inc)
+                              else os.path.join(base_dir, inc))
             continue
         if "=" not in line:
             raise ValueError(f"ginlite: line {lineno}: expected 'scope.name = value', got {raw!r}")
@@ -110,8 +117,9 @@ def _strip_comment(raw: str) -> str:
 
 
 def parse_config_file(path: str) -> None:
+    import os
     with open(path, "r", encoding="utf-8") as fh:
-        parse_config(fh.read())
+        parse_config(fh.read(), base_dir=os.path.dirname(os.path.abspath(path)))
 
 
 def query_parameter(key: str) -> Any:

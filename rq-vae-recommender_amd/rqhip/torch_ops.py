@@ -186,7 +186,8 @@ def _rl_setup(ctx, inputs, output):
 
 def _rl_backward(ctx, g_out):
     x_hat, x = ctx.saved_tensors
-    return torch.ops.rqhip.recon_loss_backward(x_hat, x, g_out), None
+    g_hat = torch.ops.rqhip.recon_loss_backward(x_hat, x, g_out)
+    return g_hat, (-g_hat if ctx.needs_input_grad[1] else None)   # d/dx of sum (x_hat - x)^2 is the negative
 
 
 recon_loss.register_autograd(_rl_backward, setup_context=_rl_setup)

@@ -10,18 +10,19 @@ What is MI355X-native about it:
   * one process per GPU (`torchrun --nproc-per-node N train_rqvae.py cfg.gin`): no accelerate/DDP wrapper --
     gradients live in one flat buffer and a step issues exactly one RCCL all-reduce (rqhip/dist.py); every
     rank draws its own batches from the full dataset, as the un-`prepare`d dataloader of the reference does
-    (train_rqvae.py:119-120); rank 0 alone runs the k-means warm-up and broadcasts the result;
+    (train_rqvae.py:119-120); the k-means warm-up is row-sharded: every rank takes its block of the first 20 000 items
+    through the model, rank 0 draws the seed / reseed rows, each Lloyd iteration all-reduces the [K, D+1] sums || counts;
   * the item-feature matrix is resident in HBM and batches are gathered on the device (data/processed.py),
     there is no host->device copy in the loop;
   * the progress-bar losses are read back every `log_every` steps instead of three `.cpu().item()` syncs
     per step (train_rqvae.py:197-199);
   * at the reference's batch sizes (640 / 64 rows) a step is ~45 kernel launches of a few microseconds each, i.e.
-    launch-bound: with `use_hip_graph=True` (off in the signature, ON in the shipped gin configs; single GPU) the whole step (forward,
-    HIP quantisation kernels, backward, fused AdamW) is captured into a hipGraph and replayed on full-size batches
-    (0.99 -> 0.38 ms per step at batch 640 on MI355X in tools/bench_small_batch.py); epoch-tail batches are
-    skipped, and the graph is re-captured after every eval / tokenisation / checkpoint excursion (a precaution kept
-    from round 1; the faults seen then came from memset nodes in the captured graph, since replaced by kernels --
-    DESIGN.md section 8).
+    launch-bound: with `use_hip_graph=True` (off in the signature and in the reference-equivalent gin configs, on in
+    configs/*_graph.gin; single GPU) the whole step (forward, HIP quantisation kernels, backward, fused AdamW) is
+    captured into a hipGraph and replayed on full-size batches (0.99 -> 0.38 ms per step at batch 640 on MI355X in
+    tools/bench_small_batch.py).  The training schedule is the reference's either way: the short batch that ends an
+    epoch (drop_last=False, train_rqvae.py:82-88) is trained on eagerly, and the graph is re-captured after every eager
+    excursion (epoch tail, eval, tokenisation, checkpoint).
 wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
 """
 import os
@@ -110,14 +111,9 @@ class _GraphedStep:
 
     def _step(self):
         from data.schemas import SeqBatch
-        part = os.environ.get("RQ_GRAPH_PART", "all")  # debugging aid: capture only a prefix of the step
         self._reducer.zero_()
         out = self._model(SeqBatch(None, None, None, self.x, None, None), gumbel_t=self._t)
-        if part == "fwd":
-            return out
         out.loss.backward()
-        if part == "fwdbwd":
-            return out
         self._opt.step()
         return out
 
@@ -127,20 +123,18 @@ class _GraphedStep:
         capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
         import copy
         self.x.copy_(x)
-        rollback = os.environ.get("RQ_GRAPH_NO_ROLLBACK") != "1"   # developer switch
-        params = [p.detach().clone() for p in self._model.parameters()] if rollback else []
-        opt_state = copy.deepcopy(self._opt.state_dict()) if rollback else None
+        params = [p.detach().clone() for p in self._model.parameters()]
+        opt_state = copy.deepcopy(self._opt.state_dict())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
             for _ in range(2):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
-        if rollback:
-            with torch.no_grad():
-                for p, saved in zip(self._model.parameters(), params):
-                    p.copy_(saved)
-            self._opt.load_state_dict(opt_state)
+        with torch.no_grad():
+            for p, saved in zip(self._model.parameters(), params):
+                p.copy_(saved)
+        self._opt.load_state_dict(opt_state)
         self._reducer.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -151,8 +145,7 @@ class _GraphedStep:
         del out
 
     def run(self, x: torch.Tensor):
-        if os.environ.get("RQ_GRAPH_FIXED_BATCH") != "1":   # developer switch: replay on the captured batch
-            self.x.copy_(x)
+        self.x.copy_(x)
         self.graph.replay()
         return self.out
 
@@ -273,14 +266,15 @@ def train(
             # (train_rqvae.py:178-183).  With several ranks each takes its block of those rows through the model and the
             # Lloyd iterations all-reduce the [K, D+1] sums || counts (init/kmeans.py): every rank
             # ends with the same codebooks -- unlike the reference, whose ranks would each seed their own
-            import init.kmeans as _km
-            n_warm = min(int(os.environ.get("RQ_WARM_ROWS", "20000")), len(train_dataset))
+            n_warm = min(20000, len(train_dataset))
             lo, hi = rqdist.shard_bounds(n_warm)
-            _km.SHARDED_INIT = world > 1
+            for layer in model.layers:
+                layer.kmeans_rows_sharded = world > 1
             try:
                 model(train_dataset[torch.arange(lo, hi)], t)  # output (and its autograd graph) dropped at once
             finally:
-                _km.SHARDED_INIT = False
+                for layer in model.layers:
+                    layer.kmeans_rows_sharded = False
 
         data = next(train_batches) if gradient_accumulate_every == 1 else None
         if graphed is not None and it >= graph_after:
@@ -289,9 +283,6 @@ def train(
                 print(f"use_hip_graph: the training split has {len(train_dataset)} rows < batch_size {batch_size}; "
                       "falling back to the eager step")
                 graphed = None
-            else:
-                while data.x.shape[0] != batch_size:   # graph mode trains on full batches only: epoch tails are skipped
-                    data = next(train_batches)
         if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
             if graphed.graph is None:
                 graphed.capture(data.x)
@@ -314,6 +305,8 @@ def train(
                 data = None
             reducer.allreduce_mean()
             optimizer.step()
+            if graphed is not None and graphed.graph is not None:
+                graphed.invalidate()   # an eager step (the short batch that ends an epoch) ran between two replays
 
         window.append(torch.stack([total_loss, model_output.reconstruction_loss.detach(),
                                    model_output.rqvae_loss.detach()]))  # stack copies: safe with graph-static outputs

@@ -378,6 +378,56 @@ def test_config3_real_shape_training_step_matches_reference():
         assert np.abs(got_d).max() <= float(g["lr"]) * 1.05 + 1e-7
 
 
+def test_flat_reducer_attach_one_model_applied_twice_under_one_loss():
+    """a parameter that feeds TWO backward nodes of one backward() -- the same RqVae / MLP applied
+    to two batches under one loss -- must get the SUM of both gradients.  AccumulateGrad runs only after both producers,
+    so `.grad is None` cannot tell them apart; the slice of the flat buffer is claimed once per epoch (`zero_()`), the
+    second producer returns an ordinary tensor and autograd accumulates."""
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    from rqhip.dist import FlatGradReducer
+
+    def make():
+        torch.manual_seed(0)
+        m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
+                  n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.STE).cuda()
+        with torch.no_grad():
+            for l, layer in enumerate(m.layers):
+                layer.embedding.weight.copy_(torch.randn(256, 32, device="cuda") * (0.05 / (l + 1)))
+        return m.train()
+
+    x = torch.nn.functional.normalize(torch.randn(4096, 768, device="cuda"), dim=-1)
+    b1, b2 = SeqBatch(None, None, None, x[:2048], None, None), SeqBatch(None, None, None, x[2048:], None, None)
+    plain, attached = make(), make()
+    red = FlatGradReducer(attached.parameters()).attach(attached)
+    for _ in range(2):      # two steps: the claim must be released by zero_()
+        for p in plain.parameters():
+            p.grad = None
+        red.zero_()
+        (plain(b1, 0.2).loss + 0.5 * plain(b2, 0.2).loss).backward()
+        (attached(b1, 0.2).loss + 0.5 * attached(b2, 0.2).loss).backward()
+        for (name, p), q in zip(attached.named_parameters(), plain.parameters()):
+            scale = max(q.grad.abs().max().item(), 1e-6)
+            assert (p.grad - q.grad).abs().max().item() <= 1e-6 * scale, name   # (sum order of the two terms may differ)
+            assert p.grad.untyped_storage().data_ptr() == red.flat.untyped_storage().data_ptr(), name
+
+
+def test_recon_loss_second_backward_through_a_retained_graph():
+    """the speculative reconstruction-loss gradient is handed out once; a second backward through a
+    retained graph recomputes instead of returning the first call's (in-place fixed-up) tensor."""
+    from rqhip.autograd import ReconLossFunction
+    x = torch.randn(512, 768, device="cuda")
+    x_hat = torch.randn(512, 768, device="cuda", requires_grad=True)
+    out = ReconLossFunction.apply(x_hat, x)
+    w1 = torch.rand(512, device="cuda")
+    g1, = torch.autograd.grad(out, x_hat, grad_outputs=w1, retain_graph=True)
+    g1 = g1.clone()
+    g2, = torch.autograd.grad(out, x_hat, grad_outputs=torch.full((512,), 1.0 / 512, device="cuda"))
+    assert torch.allclose(g1, 2 * (x_hat.detach() - x) * w1[:, None], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(g2, 2 * (x_hat.detach() - x) / 512, rtol=1e-6, atol=1e-9)
+
+
 def test_flat_reducer_attach_puts_gradients_in_the_flat_buffer_without_copies():
     """rqhip.dist.FlatGradReducer.attach: the backward functions write each weight / codebook gradient straight into its
     slice of the flat all-reduce buffer (first gradient of a step) and autograd accumulates later ones there; values

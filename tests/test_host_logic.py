@@ -273,3 +273,23 @@ def test_loss_scale_hint_nests_and_restores():
     except RuntimeError:
         pass
     assert ag._LOSS_SCALE == 1.0
+
+
+def test_grad_sink_is_claimed_once_per_parameter_and_epoch():
+    """rqhip.dist.claim_grad_sink: the in-place slice goes to the first producer of an epoch only."""
+    import torch
+    from rqhip.dist import FlatGradReducer, claim_grad_sink
+    w = torch.nn.Parameter(torch.zeros(3, 2))
+    other = torch.nn.Parameter(torch.zeros(2))
+    assert claim_grad_sink(w) is None                      # never attached
+    red = FlatGradReducer([w, other]).attach(None)
+    red.zero_()
+    v = claim_grad_sink(w)
+    assert v is not None and v.data_ptr() == red.flat.data_ptr()
+    assert claim_grad_sink(w) is None                      # second producer of the same backward pass
+    assert claim_grad_sink(other) is not None              # claims are per parameter
+    red.zero_()
+    assert claim_grad_sink(w) is not None                  # released by the next epoch
+    red.zero_()
+    w.grad = torch.ones(3, 2)
+    assert claim_grad_sink(w) is None                      # a gradient is already there: autograd accumulates

@@ -37,7 +37,10 @@ def main():
     g = torch.Generator().manual_seed(0)
     shapes = [("c2", 100_000, 32, 256, 3), ("c2_1M", 1_000_000, 32, 256, 3), ("c4_micro", 125_000, 32, 1024, 4),
               ("batch640", 640, 32, 256, 3), ("d64", 100_000, 64, 256, 3)]
+    only = set(sys.argv[1:])
     for name, B, D, K, L in shapes:
+        if only and name not in only:
+            continue
         x = (torch.randn(B, D, generator=g) * 0.5).cuda()
         cb = torch.stack([x[torch.randperm(B, generator=g)[:K].cuda()] / (l + 1) + 0.02 * torch.randn(K, D, generator=g).cuda()
                           for l in range(L)]).contiguous()
