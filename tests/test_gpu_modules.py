@@ -410,7 +410,7 @@ def test_flat_reducer_attach_one_model_applied_twice_under_one_loss():
         for (name, p), q in zip(attached.named_parameters(), plain.parameters()):
             scale = max(q.grad.abs().max().item(), 1e-6)
             assert (p.grad - q.grad).abs().max().item() <= 1e-6 * scale, name   # (sum order of the two terms may differ)
-            assert p.grad.untyped_storage().data_ptr() == red.flat.untyped_storage().data_ptr(), name
+        # (where autograd summed two producers the result is its own tensor, not the slice: allreduce_mean() packs those)
 
 
 def test_recon_loss_second_backward_through_a_retained_graph():
