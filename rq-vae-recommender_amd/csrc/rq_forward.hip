@@ -92,6 +92,9 @@ struct RqFwdParams {
     float beta;
     // filtered scan: per-group score maxima in LDS (GroupMax): tiles per group, groups per level, bf16 storage
     int tpg, ngroups, gm16;
+    // filtered scan, one chunk per level: the codebook norms are formed by the kernel itself while it stages the codes
+    // (no rq_csq_kernel launch in front: 7-12 us of every call); fp32 copy in LDS for the exact re-decision
+    int incsq;
 };
 
 // rows of a tile as lane (il, h) fetches them: full-width kernels take their half of the row as float4s ("raw", see
@@ -276,7 +279,8 @@ __device__ __forceinline__ float filt_threshold(float xsq, float csqmax) {
 
 template <int KSTEPS, int NT>
 __device__ __forceinline__ void stage_codes_bf16(float *buf0, int buf_floats, int nbuf, const float *__restrict__ cb0,
-                                                 const float *__restrict__ csq0, int csq_stride, int kbase, int Kc, int K) {
+                                                 const float *__restrict__ csq0, int csq_stride, int kbase, int Kc, int K,
+                                                 float *csq_lds = nullptr, unsigned *csqmax_bits = nullptr, int level0 = 0) {
     constexpr int D = 2 * KSTEPS, S = KSTEPS / 8, d4n = D / 4, cstep = NT / d4n;
     const int tid = threadIdx.x;
     const int d4 = tid & (d4n - 1);
@@ -311,10 +315,37 @@ __device__ __forceinline__ void stage_codes_bf16(float *buf0, int buf_floats, in
         }
     }
     {
+        // -|c|^2 / 2 as three bf16 pieces.  csq_lds != nullptr: the norms are formed HERE, one thread per code, with
+        // rq_csq_kernel's arithmetic (parity accumulators, multiply and add separately rounded: oracle sumsq2) from the
+        // fp32 code rows in L2; they also go to csq_lds (fp32, for the exact re-decision) and into the level's maximum
+        // csqmax_bits[level] (unsigned order == float order for values >= 0; a NaN norm sorts above +Inf and poisons the
+        // level's guard, as rq_csq_kernel's NaN-propagating maximum does).
         int c2 = tid, b2 = 0;
         while (c2 >= Kc) { c2 -= Kc; ++b2; }
         while (b2 < nbuf) {
-            const float q = (kbase + c2 < K) ? -0.5f * csq0[b2 * csq_stride + kbase + c2] : -3.0e38f;
+            float cs;
+            if (kbase + c2 >= K) {
+                cs = __builtin_inff();
+            } else if (csq_lds) {
+                const f32x4 *row = reinterpret_cast<const f32x4 *>(cb0 + (size_t)(b2 * K + kbase + c2) * D);
+                f32x4 v[d4n];
+#pragma unroll
+                for (int j = 0; j < d4n; ++j) v[j] = row[j];
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < d4n; ++j) {
+                    a0 = a0 + v[j].x * v[j].x;
+                    a1 = a1 + v[j].y * v[j].y;
+                    a0 = a0 + v[j].z * v[j].z;
+                    a1 = a1 + v[j].w * v[j].w;
+                }
+                cs = a0 + a1;
+                atomicMax(csqmax_bits + level0 + b2, (cs != cs) ? 0x7fc00000u : __float_as_uint(cs));
+            } else {
+                cs = csq0[b2 * csq_stride + kbase + c2];
+            }
+            if (csq_lds) csq_lds[b2 * Kc + c2] = cs;
+            const float q = (kbase + c2 < K) ? -0.5f * cs : -3.0e38f;
             const __bf16 qh = (__bf16)q;
             const float r1 = q - (float)qh;          // exact
             const __bf16 qm = (__bf16)r1;
@@ -733,8 +764,8 @@ __device__ __forceinline__ void scan_codes_split(const rq_bf16x8 *__restrict__ i
 //       across every scan: the filtered kernel spilled 20 of them).
 template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN, bool FILT, int RES>
 __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
-                                        float *gm_s, long long tile, float (&r)[KSTEPS], int D, int buf_floats, int phase,
-                                        long long next_tile, float (&rn)[KSTEPS]) {
+                                        float *gm_s, float *csqf_s, long long tile, float (&r)[KSTEPS], int D, int buf_floats,
+                                        int phase, long long next_tile, float (&rn)[KSTEPS]) {
     constexpr int KQ = KSTEPS / 4;
     constexpr int S = FILT ? KSTEPS / 8 : 1;   // 16-wide K steps of the bf16 matrix instruction
     constexpr bool TRACK2 = MARGIN || FILT;   // the runner-up is tracked
@@ -762,8 +793,6 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
 
     for (int l = 0; l < L; ++l) {
         RQ_STAMP(2 + 8 * l);
-        const float csqmax_l = csqmax_s[l];
-
         // |x|^2 (quantize.py:114): parity accumulators, multiply and add separately rounded
         const float xsq = pair_sumsq<KSTEPS>(r);
 
@@ -788,7 +817,8 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 __syncthreads();  // previous chunk fully consumed
                 if constexpr (FILT)
                     stage_codes_bf16<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
-                                                 kbase, Kc, K);
+                                                 kbase, Kc, K, p.incsq ? csqf_s : nullptr,
+                                                 const_cast<unsigned *>(reinterpret_cast<const unsigned *>(csqmax_s)), l);
                 else
                     stage_codes<KSTEPS, NT>(smem, buf_floats, 1, p.cb + (size_t)l * K * D, p.csq + (size_t)l * p.Kp, p.Kp,
                                             kbase, Kc, K, D);
@@ -805,6 +835,8 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             }
         }
 
+        // (read after the scans: with in-kernel norms a non-resident level's maximum is complete only after its staging barrier)
+        const float csqmax_l = csqmax_s[l];
         if constexpr (FILT) {
             if (!COOP && gm.gcnt) gm.flush();   // a partly filled last group
             if (l == L - 1 && next_tile >= 0) load_tile_rows<KSTEPS, FULLD>(p, next_tile, il, h, D, rn);
@@ -904,7 +936,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             unsigned long long badmask = __ballot(bad) & 0xffffffffull;
             if (badmask) {
                 const float *cb_l = p.cb + (size_t)l * K * D;
-                const float *csq_l = p.csq + (size_t)l * p.Kp;
+                const float *csq_l = (FILT && p.incsq) ? csqf_s + (resident ? l * Kc : 0) : p.csq + (size_t)l * p.Kp;
                 while (badmask) {
                     const int j = __builtin_ctzll(badmask);
                     badmask &= badmask - 1;
@@ -1064,12 +1096,20 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
     float *csqmax_s = smem + (resident ? L : 1) * buf_floats;
     float *cand_s = csqmax_s + 16;  // cooperative-tile candidates and counters (kCoopLdsFloats)
     float *gm_s = cand_s + kCoopLdsFloats;   // filtered scan: per-wave group maxima (GroupMax), 8 x 64 words per wave
-    if (tid < L) csqmax_s[tid] = p.csqmax[tid];
+    // fp32 codebook norms formed in the kernel (p.incsq), behind the group maxima: [levels resident][Kc]
+    float *csqf_s = gm_s + (size_t)kWavesPerWg * 8 * 64 / (FILT && p.gm16 ? 2 : 1);
+    const bool incsq = FILT && p.incsq;
+    if (tid < 16) csqmax_s[tid] = incsq ? 0.0f : (tid < L ? p.csqmax[tid] : 0.0f);   // (bit pattern 0: atomicMax identity)
     if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 2 * kCoopCandFloats)[tid] = 0;
     RQ_STAMP(200);
     if (resident) {
-        if constexpr (FILT) stage_codes_bf16<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K);
-        else stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
+        if constexpr (FILT) {
+            if (incsq) __syncthreads();   // the level maxima are zeroed before anybody raises them
+            stage_codes_bf16<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, incsq ? csqf_s : nullptr,
+                                         reinterpret_cast<unsigned *>(csqmax_s), 0);
+        } else {
+            stage_codes<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, D);
+        }
     }
     RQ_STAMP(201);
     __syncthreads();
@@ -1087,8 +1127,9 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
         unpack_rows(rn, r);
         const long long next = (it + 1 < p.n_iter) ? tile + total_waves : -1;
         if (!FILT && next >= 0) load_rows(next, rn);   // (filtered kernels fetch it after the last level's scan)
-        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN, FILT, RES>(p, smem, csqmax_s, cand_s, gm_s, active ? tile : p.n_tiles, r, D,
-                                                              buf_floats, 0, FILT ? next : -1, rn);
+        rq_tile<KSTEPS, MODE, FULLD, NT, false, MARGIN, FILT, RES>(p, smem, csqmax_s, cand_s, gm_s, csqf_s,
+                                                                   active ? tile : p.n_tiles, r, D, buf_floats, 0,
+                                                                   FILT ? next : -1, rn);
         RQ_TRACE(trace_slot);
         ++trace_slot;
     }
@@ -1101,8 +1142,8 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
             float raw[KSTEPS], r[KSTEPS];
             load_rows(tile, raw);
             unpack_rows(raw, r);
-            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN, FILT, RES>(p, smem, csqmax_s, cand_s, gm_s, tile, r, D, buf_floats, phase, -1,
-                                                                 raw);
+            rq_tile<KSTEPS, MODE, FULLD, NT, true, MARGIN, FILT, RES>(p, smem, csqmax_s, cand_s, gm_s, csqf_s, tile, r, D, buf_floats,
+                                                                      phase, -1, raw);
             phase += L;
             RQ_TRACE(trace_slot);
             ++trace_slot;
@@ -1311,10 +1352,14 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
     const int Kp = pad32(K);
     float *csq = reinterpret_cast<float *>(workspace);
     float *csqmax = csq + (size_t)L * Kp;
-    hipLaunchKernelGGL(rq_csq_kernel, dim3(L), dim3(256), 0, s, codebooks, L, K, Kp, D, csq, csqmax);
-    RQ_CHECK_LAUNCH("rq_csq_kernel");
+    auto launch_csq = [&]() -> int {
+        hipLaunchKernelGGL(rq_csq_kernel, dim3(L), dim3(256), 0, s, codebooks, L, K, Kp, D, csq, csqmax);
+        RQ_CHECK_LAUNCH("rq_csq_kernel");
+        return 0;
+    };
 
     if (flags & RQHIP_FWD_SCAN_VALU) {
+        if (int rc = launch_csq()) return rc;
         if (tie_margin) {
             set_error("rq_forward (VALU scan): tie_margin is not available");
             return RQHIP_EUNSUPPORTED;
@@ -1329,7 +1374,7 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
     p.ids = ids; p.embs = embs; p.residuals = residuals; p.emb_sum = emb_sum; p.loss = loss;
     p.embs_norm = embs_norm; p.tie_margin = tie_margin;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
-    p.tpg = 1; p.ngroups = 0; p.gm16 = 0;
+    p.tpg = 1; p.ngroups = 0; p.gm16 = 0; p.incsq = 0;
     const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
     const bool filt = filtered_launch(p, flags);
     // per code: the operand image (Dp words) + its squared norm (fp32 scan) or the three bf16 pieces of -|c|^2/2 (filtered)
@@ -1338,7 +1383,8 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
     // filtered scan: 8 group maxima per lane and wave, fp32 -- or bf16 (rounded up) when LDS is short
     const size_t gm32 = filt ? (size_t)waves_per_wg * 8 * 64 * sizeof(float) : 0;
     size_t gm_bytes = gm32;
-    const size_t level_bytes = (size_t)Kp * code_bytes;
+    // filtered scan: + an fp32 copy of the norms the kernel forms itself (4 bytes per code) while a level is one chunk
+    const size_t level_bytes = (size_t)Kp * (code_bytes + (filt ? sizeof(float) : 0));
     if (level_bytes * L + fixed_bytes + gm_bytes <= (size_t)kLdsBudget) {
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
@@ -1348,7 +1394,7 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
             p.gm16 = 1;   // K = 1024 at D = 32: the whole level fits beside half-width group maxima
             gm_bytes = gm32 / 2;
         }
-        int kc = (int)(((size_t)kLdsBudget - fixed_bytes - gm_bytes) / code_bytes);
+        int kc = (int)(((size_t)kLdsBudget - fixed_bytes - gm_bytes) / (code_bytes + (filt ? sizeof(float) : 0)));
         kc &= ~63;
         if (kc > Kp) kc = Kp;
         if (kc < 64) kc = 64;
@@ -1359,7 +1405,10 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
         p.tpg = (tiles + 7) / 8;
         p.ngroups = (tiles + p.tpg - 1) / p.tpg;
     }
-    const size_t lds = (size_t)p.Kc * code_bytes * (p.resident ? L : 1) + fixed_bytes + gm_bytes;
+    p.incsq = filt && p.nchunks == 1;
+    if (!p.incsq)
+        if (int rc = launch_csq()) return rc;
+    const size_t lds = (size_t)p.Kc * (code_bytes + (filt ? sizeof(float) : 0)) * (p.resident ? L : 1) + fixed_bytes + gm_bytes;
     const int cus = cu_count();
     const int wg_per_cu = 1;  // 768 / 512 / 256 threads at <= 168 / 256 / 512 VGPRs: one workgroup fills a CU
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
