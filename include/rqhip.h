@@ -151,6 +151,11 @@ int rqhip_gumbel_forward(const float *x, int64_t B, int D, const float *codebook
 /*   g_emb [B,D] / g_loss [B] upstream (may be NULL); outputs g_x [B,D], g_codebook [K,D] (overwritten).
  *   workspace: rqhip_gumbel_backward_workspace_bytes(B,D,K) */
 size_t rqhip_gumbel_backward_workspace_bytes(int64_t B, int D, int K);
+/* Both Gumbel entry points pick between two implementations with the same results: from `min_rows` rows (default 4096;
+ * D = 32, K in {32, 64, 128, 256}, 16-byte aligned rows) the matrix-instruction kernels (32 rows per wave), below it the
+ * one-row-per-wave kernels.  set_to > 0 changes the process-wide threshold (tests force the matrix path on small ragged
+ * batches with 1); returns the previous value; set_to <= 0 only queries. */
+int64_t rqhip_gumbel_matrix_path_min_rows(int64_t set_to);
 int rqhip_gumbel_backward(const float *x, int64_t B, int D, const float *codebook, int K,
                           const float *U, float temperature, float beta, const float *g_emb,
                           const float *g_loss, float *g_x, float *g_codebook, void *workspace,

@@ -373,6 +373,12 @@ static int check_shape(const char *who, int64_t B, int D, int K, bool backward) 
 
 using namespace rqhip;
 
+extern "C" int64_t rqhip_gumbel_matrix_path_min_rows(int64_t set_to) {
+    const int64_t before = (int64_t)gumbel_mfma_min_rows();
+    if (set_to > 0) gumbel_mfma_set_min_rows((long long)set_to);
+    return before;
+}
+
 extern "C" int rqhip_gumbel_forward(const float *x, int64_t B, int D, const float *codebook, int K, const float *U,
                                     float temperature, float beta, int64_t *ids, float *emb, float *loss,
                                     rqhip_stream_t stream) {

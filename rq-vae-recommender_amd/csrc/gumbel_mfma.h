@@ -23,6 +23,7 @@ int gumbel_mfma_backward(const GumbelMfmaParams &p, hipStream_t s);
 // rows from which the 32-rows-per-wave kernels beat the one-row-per-wave ones of gumbel.hip (fewer rows cannot fill
 // the chip with 32-row tiles); RQ_GUMBEL_MFMA_MIN_ROWS overrides (developer / test switch)
 long long gumbel_mfma_min_rows();
+void gumbel_mfma_set_min_rows(long long n);
 
 #ifdef __HIPCC__
 // Softmax arithmetic of both Gumbel kernels (~150 -> ~50 VALU instructions per (row, code)):

@@ -411,14 +411,9 @@ static int gm_grid(long long n_tiles, int wg_per_cu) {
     return (int)(want < cap ? want : cap);
 }
 
-long long gumbel_mfma_min_rows() {
-    static long long v = -1;
-    if (v < 0) {
-        const char *e = getenv("RQ_GUMBEL_MFMA_MIN_ROWS");
-        v = e ? atoll(e) : 4096;
-    }
-    return v;
-}
+static long long g_gumbel_mfma_min_rows = 4096;
+long long gumbel_mfma_min_rows() { return g_gumbel_mfma_min_rows; }
+void gumbel_mfma_set_min_rows(long long n) { g_gumbel_mfma_min_rows = n < 1 ? 1 : n; }
 
 bool gumbel_mfma_supported(int D, int K, const void *x, const void *U, const void *a, const void *b) {
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };

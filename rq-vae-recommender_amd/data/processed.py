@@ -10,10 +10,10 @@ that gin configs name as `%data.processed.RecDataset.AMAZON`.
 Source of the matrix, in order:
   1. `<root>/item_features.pt` -- a dict {"x": float32 [N, >=768], "is_train": bool [N] (optional)} that a
      user exports once from the reference's processed HeteroData (`data["item"].x`, `["is_train"]`);
-  2. ONLY when $RQ_SYNTH_ITEMS=<N> is set (explicit opt-in, loud warning, `ds.synthetic` is True): a
-     deterministic synthetic corpus of N unit-norm 768-d rows (seed 1234) with the reference's 95/5 split
-     (seed 42, data/amazon.py:154-156).  Otherwise a missing file raises FileNotFoundError -- the reference
-     would download the data or fail here, never train on noise.
+  2. ONLY when the folder is NAMED "synthetic:<N>" (e.g. `train.dataset_folder="synthetic:87585"`: an explicit opt-in
+     in the configuration itself, loud warning, `ds.synthetic` is True): a deterministic synthetic corpus of N unit-norm
+     768-d rows (seed 1234) with the reference's 95/5 split (seed 42, data/amazon.py:154-156).  Otherwise a missing file
+     raises FileNotFoundError -- the reference would download the data or fail here, never train on noise.
 MI355X-first: the matrix is moved to the GPU once (`to_device`) and batches are gathered there -- 10 M x 768
 fp32 = 30.7 GB fits one 288 GB HBM stack many times over -- so no PCIe copy sits in the training loop.
 """
@@ -61,21 +61,22 @@ class ItemData(Dataset):
         self.synthetic = False
         if item_matrix is None:
             path = os.path.join(root, "item_features.pt")
-            if os.path.exists(path):
-                blob = torch.load(path, map_location="cpu", weights_only=True)
-                item_matrix, is_train = blob["x"].to(torch.float32), blob.get("is_train", is_train)
-            elif os.environ.get("RQ_SYNTH_ITEMS"):
-                # explicit opt-in only: a run on noise must never look like a run on the dataset
-                n = int(os.environ["RQ_SYNTH_ITEMS"])
-                print(f"[ItemData] WARNING: {path} not found -- using {n} SYNTHETIC unit-norm items "
-                      f"(RQ_SYNTH_ITEMS={n}); results say nothing about the real corpus", flush=True)
+            if str(root).startswith("synthetic:"):
+                # explicit opt-in only, spelled out in the configuration: a run on noise must never look like a run on
+                # the dataset
+                n = int(str(root).split(":", 1)[1])
+                print(f"[ItemData] WARNING: dataset folder {root!r} -- using {n} SYNTHETIC unit-norm items; "
+                      "results say nothing about a real corpus", flush=True)
                 item_matrix = synthetic_item_matrix(n)
                 self.synthetic = True
+            elif os.path.exists(path):
+                blob = torch.load(path, map_location="cpu", weights_only=True)
+                item_matrix, is_train = blob["x"].to(torch.float32), blob.get("is_train", is_train)
             else:
                 raise FileNotFoundError(
                     f"{path} not found.  Export the item features first (INTEGRATION.md, 'Item features': "
                     "torch.save({'x': item_matrix_fp32[N, >=768], 'is_train': mask}, '<dataset_folder>/item_features.pt')) "
-                    "or opt in to synthetic items explicitly with RQ_SYNTH_ITEMS=<n>.")
+                    "or opt in to synthetic items explicitly by naming the folder 'synthetic:<n>'.")
         if is_train is None:
             is_train = synthetic_train_mask(item_matrix.shape[0])
         if train_test_split == "train":

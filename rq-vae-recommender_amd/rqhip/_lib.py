@@ -39,6 +39,7 @@ SIGNATURES = {
                                  _vp, _sz, _vp]),
     "rqhip_gumbel_forward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rqhip_gumbel_backward_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "rqhip_gumbel_matrix_path_min_rows": (_i64, [_i64]),
     "rqhip_gumbel_backward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _vp]),
     "rqhip_kmeans_assign": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp]),

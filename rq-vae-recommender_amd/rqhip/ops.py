@@ -319,6 +319,12 @@ def topk_first_match(actual: Tensor, top_k: Tensor) -> Tensor:
     return rank
 
 
+def gumbel_matrix_path_min_rows(set_to: int = 0) -> int:
+    """Query (set_to <= 0) or set the batch size from which the Gumbel level runs on the matrix instructions
+    (rqhip_gumbel_matrix_path_min_rows); returns the previous value."""
+    return int(_lib.lib().rqhip_gumbel_matrix_path_min_rows(int(set_to)))
+
+
 def gumbel_forward(x: Tensor, codebook: Tensor, U: Tensor, temperature: float, beta: float):
     """One GUMBEL_SOFTMAX level, training (rqhip_gumbel_forward) -> (ids [B], emb [B,D], loss [B])."""
     _need_gpu(x, codebook, U)

@@ -10,8 +10,7 @@ an op, so that
   * `torch.library.opcheck` can validate schema, fake tensors and autograd registration (tests/test_gpu_torch_ops.py).
 
 The direct Function path stays the default in eager mode: a custom_op call costs a few more microseconds of Python
-dispatch than the bare ctypes call, which matters at the reference's launch-bound batch sizes.  `enable()` (or
-RQHIP_TORCH_OPS=1) switches modules/rqvae.py and modules/encoder.py to the registered ops.
+dispatch than the bare ctypes call, which matters at the reference's launch-bound batch sizes.  `enable()` (`rqhip.torch_ops.enable()`) switches modules/rqvae.py and modules/encoder.py to the registered ops.
 
 Each op names the C entry point it wraps (include/rqhip.h); there is no arithmetic here.
 """
@@ -25,7 +24,7 @@ from torch import Tensor
 
 from . import ops
 
-_ENABLED = os.environ.get("RQHIP_TORCH_OPS") == "1"
+_ENABLED = False   # rqhip.torch_ops.enable() switches the module mirrors to the registered operators
 
 
 def enable(on: bool = True) -> None:

@@ -9,7 +9,7 @@ training step but not part of the hand-written hot path. 
 * kernel choice: the default heuristic picks poor fp32 kernels for these tall-skinny shapes (32 TFLOP/s at
   100 000 x 768 x 512); TunableOp's per-shape selection reaches ~110 TFLOP/s.  The selections for the shipped
   shapes are committed in tuning/tunableop_gfx950.csv and loaded here with tuning DISABLED, so a run never pays
-  tuning time; set RQ_TUNE_GEMMS=1 to tune shapes that are not in the file (new batch sizes) and write them back.
+  tuning time; `enable_tuned_gemms(tune=True)` (tools/tune_gemms.py) tunes shapes that are not in the file (new batch sizes) and writes them back.
 """
 from __future__ import annotations
 
@@ -21,20 +21,22 @@ TUNING_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
                            "tunableop_gfx950.csv")
 
 
-def enable_tuned_gemms(verbose: bool = False) -> bool:
-    """Turn on TunableOp with the committed selections; returns True when active."""
-    if not torch.cuda.is_available() or os.environ.get("RQ_DISABLE_TUNABLEOP") == "1":
+def enable_tuned_gemms(verbose: bool = False, tune: bool = False, out_file: str | None = None, tune_ms: int = 30) -> bool:
+    """Turn on TunableOp with the committed selections; returns True when active.
+    tune=True (tools/tune_gemms.py only): also tune shapes that are not in the file and write the table to `out_file`
+    (default: the committed file) when the process exits."""
+    if not torch.cuda.is_available():
         return False
     import torch.cuda.tunable as tunable
-    tune_now = os.environ.get("RQ_TUNE_GEMMS") == "1"
+    tune_now = bool(tune)
     if not tune_now and not os.path.exists(TUNING_FILE):
         return False
     tunable.enable(True)
     tunable.tuning_enable(tune_now)
     if tune_now:
         # results are (re)written to this file when the process exits
-        tunable.set_filename(os.environ.get("RQ_TUNE_GEMMS_OUT", TUNING_FILE))
-        tunable.set_max_tuning_duration(int(os.environ.get("RQ_TUNE_MS", "30")))
+        tunable.set_filename(out_file or TUNING_FILE)
+        tunable.set_max_tuning_duration(int(tune_ms))
         tunable.set_max_tuning_iterations(100)
     else:
         # read-only use: keep TunableOp's output name away from the committed file (N ranks of one job would

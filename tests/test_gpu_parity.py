@@ -477,15 +477,17 @@ def test_gumbel_matrix_path_vs_oracle(B, K, T):
     test_gumbel_forward_backward_vs_oracle(B, 32, K, T)
 
 
-def test_gumbel_matrix_path_small_batches(monkeypatch):
+def test_gumbel_matrix_path_small_batches():
     """The same kernels forced on for a ragged small batch (rows past the end of the last tile must not contribute)."""
-    import subprocess, sys
-    code = ("import sys; sys.path[:0] = ['tests', '.', 'rq-vae-recommender_amd']; import test_gpu_parity as t; "
-            "t.test_gumbel_forward_backward_vs_oracle(77, 32, 256, 0.2); t.test_gumbel_forward_backward_vs_oracle(1, 32, 64, 0.3)")
-    env = dict(os.environ, RQ_GUMBEL_MFMA_MIN_ROWS="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    from rqhip import ops
+    before = ops.gumbel_matrix_path_min_rows(1)
+    try:
+        assert ops.gumbel_matrix_path_min_rows() == 1
+        test_gumbel_forward_backward_vs_oracle(77, 32, 256, 0.2)
+        test_gumbel_forward_backward_vs_oracle(1, 32, 64, 0.3)
+    finally:
+        ops.gumbel_matrix_path_min_rows(before)
+    assert ops.gumbel_matrix_path_min_rows() == before == 4096
 
 
 def test_gumbel_unsupported_shape_fails_loudly():

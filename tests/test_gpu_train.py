@@ -13,7 +13,6 @@ pytestmark = pytest.mark.gpu
 def _run(cfg_name, tmp_path, monkeypatch, **overrides):
     import train_rqvae
     from rqhip import ginlite
-    monkeypatch.setenv("RQ_SYNTH_ITEMS", "3000")
     try:
         import gin  # noqa: F401
         pytest.skip("real gin-config present: bindings below are written for the in-tree subset")
@@ -23,7 +22,7 @@ def _run(cfg_name, tmp_path, monkeypatch, **overrides):
     ginlite.parse_config_file(os.path.join(PKG, "configs", cfg_name))
     out_dir = str(tmp_path) + "/"
     kw = dict(iterations=12, eval_every=6, save_model_every=12, save_dir_root=out_dir, wandb_logging=False,
-              dataset_folder=str(tmp_path / "no_such_dataset"), log_every=4)
+              dataset_folder="synthetic:3000", log_every=4)
     kw.update(overrides)
     res = train_rqvae.train(**kw)
     ginlite.clear_config()
@@ -39,7 +38,7 @@ def test_train_amazon_config_short_run_checkpoint_and_resume(tmp_path, monkeypat
     ckpt = os.path.join(out_dir, "checkpoint_11.pt")
     assert os.path.exists(ckpt)
     state = torch.load(ckpt, map_location="cpu", weights_only=False)
-    # the reference's four keys; a run on the opt-in synthetic corpus (RQ_SYNTH_ITEMS, as here) adds the marker "data"
+    # the reference's four keys; a run on the opt-in synthetic corpus (dataset_folder="synthetic:<n>", as here) adds the marker "data"
     assert set(state) == {"iter", "model", "model_config", "optimizer", "data"} and state["iter"] == 11
     assert state["data"] == "synthetic"
     assert {"layers.0.embedding.weight", "encoder.mlp.0.weight", "decoder.mlp.6.weight"} <= set(state["model"])

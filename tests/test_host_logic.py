@@ -216,14 +216,12 @@ def test_entry_point_fails_loudly_without_gpu():
 
 
 def test_item_data_refuses_to_invent_a_corpus(tmp_path, monkeypatch, capsys):
-    """a missing item_features.pt raises; synthetic items need the explicit RQ_SYNTH_ITEMS opt-in."""
+    """a missing item_features.pt raises; synthetic items need the explicit "synthetic:<n>" folder name."""
     import pytest
     from data.processed import ItemData
-    monkeypatch.delenv("RQ_SYNTH_ITEMS", raising=False)
     with pytest.raises(FileNotFoundError, match="item_features.pt"):
         ItemData(root=str(tmp_path / "dataset" / "amazon"))
-    monkeypatch.setenv("RQ_SYNTH_ITEMS", "40")
-    ds = ItemData(root=str(tmp_path / "dataset" / "amazon"))
+    ds = ItemData(root="synthetic:40")
     assert ds.synthetic and len(ds) == 40
     assert "SYNTHETIC" in capsys.readouterr().out
 

@@ -5,7 +5,6 @@ faulthandler.enable(); faulthandler.dump_traceback_later(30, exit=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")):
     sys.path.insert(0, p)
-os.environ["RQ_SYNTH_ITEMS"] = "3000"
 import numpy as np, torch
 from data.schemas import SeqBatch
 from data.processed import ItemData
@@ -19,7 +18,7 @@ tuning.enable_tuned_gemms()
 torch.manual_seed(0); np.random.seed(0)
 B = 640
 dev = torch.device("cuda", 0)
-ds = ItemData(root="/tmp/none", train_test_split="train").to_device(dev)
+ds = ItemData(root="synthetic:3000", train_test_split="train").to_device(dev)
 batches = train_rqvae._DeviceBatcher(ds, B)
 m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3, n_cat_features=0,
           codebook_kmeans_init=True, codebook_mode=QuantizeForwardMode.STE).to(dev)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe (GPU box): Linear+ReLU as two kernels vs torch._addmm_activation (hipBLASLt ReLU epilogue) for
 the RQ-VAE MLP shapes at 100 000 rows, with TunableOp tuning enabled for both.
-usage: RQ_TUNE_GEMMS=1 RQ_TUNE_GEMMS_OUT=gpurun_out/tune_probe.csv python tools/relu_epilogue_probe.py"""
+usage: python tools/relu_epilogue_probe.py   (tunes the probed shapes into gpurun_out/tune_probe.csv)"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate TunableOp selections for the RQ-VAE MLP GEMMs at the shipped batch sizes (run on the GPU box):
-    RQ_TUNE_GEMMS=1 RQ_TUNE_GEMMS_OUT=gpurun_out/tunableop_gfx950.csv python tools/tune_gemms.py 100000 20000 640
+    python tools/tune_gemms.py --out gpurun_out/tunableop_gfx950.csv 100000 20000 640
 then copy the CSV to rq-vae-recommender_amd/tuning/tunableop_gfx950.csv."""
 import os
 import sys
@@ -9,7 +9,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")):
     sys.path.insert(0, p)
-os.environ.setdefault("RQ_TUNE_GEMMS", "1")
 
 import torch  # noqa: E402
 from data.schemas import SeqBatch  # noqa: E402
@@ -17,8 +16,12 @@ from modules.quantize import QuantizeForwardMode  # noqa: E402
 from modules.rqvae import RqVae  # noqa: E402
 from rqhip import tuning  # noqa: E402
 
-assert tuning.enable_tuned_gemms(verbose=True)
-sizes = [int(v) for v in sys.argv[1:]] or [100000]
+argv = sys.argv[1:]
+out_file = None
+if argv[:1] == ["--out"]:
+    out_file, argv = argv[1], argv[2:]
+assert tuning.enable_tuned_gemms(verbose=True, tune=True, out_file=out_file)
+sizes = [int(v) for v in argv] or [100000]
 for embed, mode in ((32, QuantizeForwardMode.STE), (64, QuantizeForwardMode.ROTATION_TRICK)):
     torch.manual_seed(0)
     m = RqVae(input_dim=768, embed_dim=embed, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
