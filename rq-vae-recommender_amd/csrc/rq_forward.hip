@@ -92,7 +92,7 @@ struct RqFwdParams {
     float beta;
     // filtered scan: per-group score maxima in LDS (GroupMax): tiles per group, groups per level, bf16 storage
     int tpg, ngroups, gm16;
-    // filtered scan, one chunk per level: the codebook norms are formed by the kernel itself while it stages the codes
+    // filtered scan with all levels resident: the codebook norms are formed by the kernel itself while it stages the codes
     // (no rq_csq_kernel launch in front: 7-12 us of every call); fp32 copy in LDS for the exact re-decision
     int incsq;
 };
@@ -1383,9 +1383,12 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
     // filtered scan: 8 group maxima per lane and wave, fp32 -- or bf16 (rounded up) when LDS is short
     const size_t gm32 = filt ? (size_t)waves_per_wg * 8 * 64 * sizeof(float) : 0;
     size_t gm_bytes = gm32;
-    // filtered scan: + an fp32 copy of the norms the kernel forms itself (4 bytes per code) while a level is one chunk
-    const size_t level_bytes = (size_t)Kp * (code_bytes + (filt ? sizeof(float) : 0));
-    if (level_bytes * L + fixed_bytes + gm_bytes <= (size_t)kLdsBudget) {
+    // filtered scan with every level resident: + an fp32 copy of the norms, which the kernel then forms itself while it
+    // stages (4 bytes per code).  Launches that stage level by level keep rq_csq_kernel in front: they would redo the
+    // norms at every level of every round of row tiles (measured: 211 -> 228 us on the 125 000 x 4 x 1024 micro-batch).
+    const size_t csq_copy = filt ? sizeof(float) : 0;
+    const size_t level_bytes = (size_t)Kp * code_bytes;
+    if ((level_bytes + (size_t)Kp * csq_copy) * L + fixed_bytes + gm_bytes <= (size_t)kLdsBudget) {
         p.resident = 1; p.Kc = Kp; p.nchunks = 1;
     } else {
         p.resident = 0;
@@ -1394,7 +1397,7 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
             p.gm16 = 1;   // K = 1024 at D = 32: the whole level fits beside half-width group maxima
             gm_bytes = gm32 / 2;
         }
-        int kc = (int)(((size_t)kLdsBudget - fixed_bytes - gm_bytes) / (code_bytes + (filt ? sizeof(float) : 0)));
+        int kc = (int)(((size_t)kLdsBudget - fixed_bytes - gm_bytes) / code_bytes);
         kc &= ~63;
         if (kc > Kp) kc = Kp;
         if (kc < 64) kc = 64;
@@ -1405,10 +1408,10 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
         p.tpg = (tiles + 7) / 8;
         p.ngroups = (tiles + p.tpg - 1) / p.tpg;
     }
-    p.incsq = filt && p.nchunks == 1;
+    p.incsq = filt && p.resident;
     if (!p.incsq)
         if (int rc = launch_csq()) return rc;
-    const size_t lds = (size_t)p.Kc * (code_bytes + (filt ? sizeof(float) : 0)) * (p.resident ? L : 1) + fixed_bytes + gm_bytes;
+    const size_t lds = (size_t)p.Kc * (code_bytes + (p.incsq ? csq_copy : 0)) * (p.resident ? L : 1) + fixed_bytes + gm_bytes;
     const int cus = cu_count();
     const int wg_per_cu = 1;  // 768 / 512 / 256 threads at <= 168 / 256 / 512 VGPRs: one workgroup fills a CU
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
