@@ -295,6 +295,17 @@ size_t rqhip_linear_wgrad_workspace_bytes(int64_t M, int N, int K);
 int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                        float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
                        rqhip_stream_t stream);
+/* The same call with a kernel-selection flag (rqhip_linear_wgrad passes 0).  Layers whose dimensions are multiples of
+ * 128 x 256 / 256 x 128 run by default on the bf16 matrix cores with every fp32 operand split into three bf16 pieces and
+ * the six piece products that matter (dropped terms <= 2^-23 of a product: below fp32's own rounding of it; fp32
+ * accumulation; csrc/wgrad_split.hip): same fixed row ranges and reduction tree, bit-reproducible run to run, but the
+ * order inside the matrix instruction is not one the oracle can restate, so that result is held to "no less exact than the
+ * library's fp32 GEMM against fp64", not bit-exactness.  RQHIP_WGRAD_FP32 selects the fp32-MFMA kernel whose summation
+ * order oracle/rq_oracle.c:rqo_linear_wgrad restates bit for bit (and which small layers always use). */
+#define RQHIP_WGRAD_FP32 0x1u
+int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_t M, int N, int K,
+                          float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
+                          unsigned flags, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every

@@ -275,6 +275,10 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
     return pl;
 }
 
+int wgrad_split_cfg(int N, int K);   // wgrad_split.hip
+int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
+                       int nslab_n, int nslab_k, int msplit, hipStream_t s);
+
 }  // namespace rqhip
 
 using namespace rqhip;
@@ -309,6 +313,16 @@ static int wgrad_launch(const WgradParams &p, const WgradPlan &pl, bool mask, hi
 extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                                   float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
                                   rqhip_stream_t stream) {
+    return rqhip_linear_wgrad_ex(g, y, x, M, N, K, g_masked, dW, workspace, workspace_bytes, 0u, stream);
+}
+
+extern "C" int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_t M, int N, int K,
+                                     float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
+                                     unsigned flags, rqhip_stream_t stream) {
+    if (flags & ~RQHIP_WGRAD_FP32) {
+        set_error("linear_wgrad: unknown flags 0x%x", flags);
+        return RQHIP_EARG;
+    }
     if (M < 0 || N <= 0 || K <= 0 || !dW || (M > 0 && (!g || !x))) {
         set_error("linear_wgrad: null pointer or bad size");
         return RQHIP_EARG;
@@ -341,6 +355,11 @@ extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x
     p.pow2 = pl.pow2;
     const bool mask = y != nullptr;
     int rc = 0;
+    // large layers: the six-term bf16-split kernel (wgrad_split.hip) unless the oracle-exact fp32 kernel is asked for
+    const int scfg = (flags & RQHIP_WGRAD_FP32) ? -1 : wgrad_split_cfg(N, K);
+    if (scfg >= 0 && scfg == pl.cfg) {
+        rc = launch_wgrad_split(scfg, g, y, x, M, N, K, g_masked, p.out, pl.nslab_n, pl.nslab_k, pl.msplit, s);
+    } else
     switch (pl.cfg) {
         case 0: rc = wgrad_launch<4, 2, 2, 4, 32>(p, pl, mask, s); break;
         case 1: rc = wgrad_launch<4, 1, 1, 8, 32>(p, pl, mask, s); break;

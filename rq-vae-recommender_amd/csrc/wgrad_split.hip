@@ -1,0 +1,252 @@
+// wgrad_split.hip -- the weight gradient of a bias-free Linear(+ReLU) layer on the bf16 matrix cores, without narrowing
+// the arithmetic (gfx950).  SURVEY.md section 8 row f2; reference modules/encoder.py:25-38 (autograd of relu(x W^T)).
+//
+// dW[n,k] = sum_m g_pre[m,n] x[m,k] reduces over the M = 100 000 batch rows into a small output.  wgrad.hip does it with
+// v_mfma_f32_32x32x2_f32 and is bound by that pipe (505 us of matrix time for the 512 x 768 layer at the fp32 peak).
+// Here every fp32 operand is split into THREE bf16 pieces, v = h + m + l EXACTLY (8 + 8 + 8 significant bits), and the
+// product is formed from the six piece products that matter,
+//     g x  ~  gh xh + gh xm + gm xh + gh xl + gl xh + gm xm          (dropped: gm xl + gl xm + gl xl <= 2^-23 |g x|),
+// each a v_mfma_f32_32x32x16_bf16 (products of two bf16 are exact in fp32; accumulation in fp32): six instructions of 32
+// cycles do the work of eight of 64 cycles -- 2.7x less matrix time -- and the dropped terms are below one fp32 rounding
+// of the product itself.  What it gives up: the summation order is the matrix pipe's, not a chain the oracle can restate,
+// so dW is reproducible run to run (fixed instruction order, fixed reduction tree) but checked against fp64 with a
+// tolerance (tests/test_gpu_wgrad.py: no less exact than the library's fp32 GEMM), not bit for bit.
+// RQHIP_WGRAD_FP32 (rqhip_linear_wgrad_ex) keeps wgrad.hip's oracle-exact kernel.
+//
+// Mapping
+//   * A = g_pre^T (32 n x 16 m), B = x (16 m x 32 k): a lane's operand is EIGHT CONSECUTIVE ROWS of one column, so the
+//     rows are transposed on the way into LDS: a staging thread takes 4 rows x 4 columns (four 16-byte loads per tensor,
+//     coalesced along the row), applies the ReLU mask, splits, and writes per column and piece one 8-byte half of the
+//     16-byte element [piece][row octet][column] -- which a lane then fetches with one conflict-free ds_read_b128.
+//   * a workgroup owns an Nt x Kt block of dW and a contiguous range of rows, streams 16-row stages through a
+//     double-buffered LDS image (98 KB at 256 x 256), a wave owns (32 TA) x (32 TB); per stage and wave: 3 (TA + TB)
+//     operand reads, 6 TA TB matrix instructions.  Row ranges are reduced by wgrad.hip's balanced tree (second kernel).
+//   * g_pre is written back once (the k-slab-0 workgroups) for the data-gradient GEMM that follows, as in wgrad.hip.
+#include "rqhip_common.h"
+
+namespace rqhip {
+
+typedef float ws_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ws_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ws_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ws_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ws_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWsRows = 16;   // rows per LDS stage = one K step of the matrix instruction
+
+struct WgradSplitParams {
+    const float *g, *y, *x;
+    float *gm, *out;
+    long long M;
+    int N, K;
+    int nslab_n, nslab_k, msplit;
+    long long n_chunks;   // ceil(M / 32): the row ranges are cut on wgrad.hip's 32-row granules
+};
+
+// (a, b) -> three dwords, each the packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
+__device__ __forceinline__ void ws_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    const ws_bf16x2 hh = __builtin_convertvector(ws_f32x2{a, b}, ws_bf16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const ws_bf16x2 mm = __builtin_convertvector(ws_f32x2{ra, rb}, ws_bf16x2);
+    m = __builtin_bit_cast(unsigned, mm);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    const ws_bf16x2 ll = __builtin_convertvector(ws_f32x2{sa, sb}, ws_bf16x2);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given
+template <int TA, int TB, int WA, int WB, bool MASK>
+__global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSplitParams p) {
+    constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB, NT = 64 * WA * WB;
+    constexpr int UNITS = Nt + Kt;                 // staging units of 4 rows x 4 columns per stage: Nt for g, Kt for x
+    constexpr int UQ = (UNITS + NT - 1) / NT;      // per thread
+    constexpr int PART_G = 3 * 2 * Nt * 4, PART_X = 3 * 2 * Kt * 4;   // dwords: [piece][octet][column] x 16 bytes
+    extern __shared__ __attribute__((aligned(16))) char ws_smem[];
+    unsigned *sbuf = reinterpret_cast<unsigned *>(ws_smem);      // [2][PART_G + PART_X]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    const int wa = wave / WB, wb = wave % WB;
+    const int nslabs = p.nslab_n * p.nslab_k;
+    int slab, split;
+    if ((p.msplit & 7) == 0) {   // slabs of one row range back to back on one XCD (they share its strips in that L2)
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slab = j % nslabs;
+        split = (j / nslabs) * 8 + xcd;
+    } else {
+        slab = blockIdx.x % nslabs;
+        split = blockIdx.x / nslabs;
+    }
+    const int slab_n = slab / p.nslab_k, slab_k = slab % p.nslab_k;
+    const int n0 = slab_n * Nt, k0 = slab_k * Kt;
+    const long long r_begin = (p.n_chunks * split / p.msplit) * 32;
+    long long r_end = (p.n_chunks * (split + 1) / p.msplit) * 32;
+    if (r_end > p.M) r_end = p.M;
+    const long long n_stage = (r_end - r_begin + kWsRows - 1) / kWsRows;
+    const bool write_back = MASK && p.gm != nullptr && slab_k == 0;
+
+    ws_f32x16 acc[TA][TB];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    ws_f32x4 rv[UQ][4], ry[MASK ? UQ : 1][4];
+    auto fetch = [&](long long stage) {
+        const long long row0 = r_begin + stage * kWsRows;
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int u = tid + q * NT;
+            const bool live = (UNITS % NT == 0) || u < UNITS;
+            const bool isg = u < Nt;                          // (wave-uniform: Nt is a multiple of 64)
+            const int idx = isg ? u : u - Nt, W = isg ? Nt : Kt;
+            const int cq = idx % (W / 4), rq = idx / (W / 4);
+            const float *base = isg ? p.g : p.x;
+            const int ld = isg ? p.N : p.K, c0 = isg ? n0 : k0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long row = row0 + 4 * rq + j;
+                const bool ok = live && row < r_end;
+                const size_t off = (size_t)(ok ? row : 0) * ld + c0 + 4 * cq;
+                rv[q][j] = ok ? *reinterpret_cast<const ws_f32x4 *>(base + off) : ws_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (MASK) ry[q][j] = (ok && isg) ? *reinterpret_cast<const ws_f32x4 *>(p.y + off) : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+        }
+    };
+    auto stash = [&](long long stage, int buf) {
+        const long long row0 = r_begin + stage * kWsRows;
+        unsigned *dst = sbuf + buf * (PART_G + PART_X);
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int u = tid + q * NT;
+            if (UNITS % NT != 0 && u >= UNITS) continue;
+            const bool isg = u < Nt;
+            const int idx = isg ? u : u - Nt, W = isg ? Nt : Kt;
+            const int cq = idx % (W / 4), rq = idx / (W / 4);
+            if (MASK && isg) {   // threshold_backward(gy, y, 0): 0 where y <= 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    rv[q][j].x = ry[q][j].x <= 0.0f ? 0.0f : rv[q][j].x;
+                    rv[q][j].y = ry[q][j].y <= 0.0f ? 0.0f : rv[q][j].y;
+                    rv[q][j].z = ry[q][j].z <= 0.0f ? 0.0f : rv[q][j].z;
+                    rv[q][j].w = ry[q][j].w <= 0.0f ? 0.0f : rv[q][j].w;
+                }
+                if (write_back) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const long long row = row0 + 4 * rq + j;
+                        if (row < r_end) *reinterpret_cast<ws_f32x4 *>(p.gm + (size_t)row * p.N + n0 + 4 * cq) = rv[q][j];
+                    }
+                }
+            }
+            // element [piece][octet = rq >> 1][column] is 16 bytes = rows 8 octet .. 8 octet + 7; this unit fills the
+            // half (rq & 1) of it for its four columns and every piece
+            unsigned *part = dst + (isg ? 0 : PART_G);
+            const int oct = rq >> 1, half = rq & 1;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                unsigned h01, m01, l01, h23, m23, l23;
+                ws_split2(rv[q][0][cc], rv[q][1][cc], h01, m01, l01);
+                ws_split2(rv[q][2][cc], rv[q][3][cc], h23, m23, l23);
+                const int col = 4 * cq + cc;
+                *reinterpret_cast<ws_u32x2 *>(part + ((0 * 2 + oct) * W + col) * 4 + 2 * half) = ws_u32x2{h01, h23};
+                *reinterpret_cast<ws_u32x2 *>(part + ((1 * 2 + oct) * W + col) * 4 + 2 * half) = ws_u32x2{m01, m23};
+                *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * W + col) * 4 + 2 * half) = ws_u32x2{l01, l23};
+            }
+        }
+    };
+
+    if (n_stage > 0) {
+        fetch(0);
+        stash(0, 0);
+    }
+    __syncthreads();
+    for (long long c = 0; c < n_stage; ++c) {
+        const int buf = (int)(c & 1);
+        const bool more = c + 1 < n_stage;
+        if (more) fetch(c + 1);
+        const ws_bf16x8 *gA = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X));
+        const ws_bf16x8 *xB = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X) + PART_G);
+        ws_bf16x8 a[TA][3], b[TB][3];
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a[t][pc] = gA[(pc * 2 + h) * Nt + wa * 32 * TA + 32 * t + il];
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) b[u][pc] = xB[(pc * 2 + h) * Kt + wb * 32 * TB + 32 * u + il];
+        // smallest products first (their sum is formed before it meets the large ones)
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                ws_f32x16 c16 = acc[t][u];
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][1], c16, 0, 0, 0);   // m m
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[u][0], c16, 0, 0, 0);   // l h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][2], c16, 0, 0, 0);   // h l
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][0], c16, 0, 0, 0);   // m h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][1], c16, 0, 0, 0);   // h m
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][0], c16, 0, 0, 0);   // h h
+                acc[t][u] = c16;
+            }
+        if (more) stash(c + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r]:
+    // n = n0 + wave's base + 32 t + 8 (r >> 2) + 4 h + (r & 3),  k = k0 + wave's base + 32 u + il
+    float *dst = p.out + (size_t)split * p.N * p.K;
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+                dst[(size_t)n * p.K + k0 + wb * 32 * TB + 32 * u + il] = acc[t][u][r];
+            }
+}
+
+// shapes the split kernel tiles: both dimensions multiples of 128 (every large layer of the 768-512-256-128 MLPs)
+int wgrad_split_cfg(int N, int K) {
+    if (N % 256 == 0 && K % 256 == 0) return 0;
+    if (N % 128 == 0 && K % 256 == 0) return 1;
+    if (N % 256 == 0 && K % 128 == 0) return 2;
+    return -1;
+}
+
+template <int TA, int TB, int WA, int WB>
+static int wgrad_split_go(const WgradSplitParams &p, bool mask, hipStream_t s) {
+    constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB;
+    const size_t lds = (size_t)2 * (Nt + Kt) * 3 * 2 * 16;
+    auto go = [&](auto kern) -> int {
+        static LdsGrant grant;
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
+        hipLaunchKernelGGL(kern, dim3(p.nslab_n * p.nslab_k * p.msplit), dim3(64 * WA * WB), lds, s, p);
+        RQ_CHECK_LAUNCH("wgrad_split_kernel");
+        return 0;
+    };
+    return mask ? go(wgrad_split_kernel<TA, TB, WA, WB, true>) : go(wgrad_split_kernel<TA, TB, WA, WB, false>);
+}
+
+// called by rqhip_linear_wgrad_ex (wgrad.hip), which owns the plan (row ranges, workspace) and the reduce kernel
+int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
+                       int nslab_n, int nslab_k, int msplit, hipStream_t s) {
+    WgradSplitParams p;
+    p.g = g; p.y = y; p.x = x; p.gm = gm; p.out = out;
+    p.M = M; p.N = N; p.K = K; p.nslab_n = nslab_n; p.nslab_k = nslab_k; p.msplit = msplit;
+    p.n_chunks = (M + 31) / 32;
+    const bool mask = y != nullptr;
+    switch (cfg) {
+        case 0: return wgrad_split_go<4, 2, 2, 4>(p, mask, s);    // 256 x 256, 8 waves of 128 x 64
+        case 1: return wgrad_split_go<2, 2, 2, 4>(p, mask, s);    // 128 x 256, 8 waves of 64 x 64
+        default: return wgrad_split_go<2, 2, 4, 2>(p, mask, s);   // 256 x 128
+    }
+}
+
+}  // namespace rqhip

@@ -19,6 +19,7 @@ SO_PATH = os.path.join(_CSRC, "librqhip.so")
 MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
 # rqhip_rq_forward_ex flags (include/rqhip.h)
 FWD_SCAN_FP32, FWD_SCAN_VALU, FWD_NO_COOP_TAIL = 0x1, 0x2, 0x10
+WGRAD_FP32 = 0x1   # rqhip_linear_wgrad_ex
 
 # every symbol include/rqhip.h declares: (restype, argtypes)
 _i64, _int, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
@@ -63,6 +64,7 @@ SIGNATURES = {
     "rqhip_linear_wgrad_plan": (_int, [_i64, _int, _int, C.POINTER(_int)]),
     "rqhip_linear_wgrad_workspace_bytes": (_sz, [_i64, _int, _int]),
     "rqhip_linear_wgrad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_linear_wgrad_ex": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, C.c_uint, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),
 }

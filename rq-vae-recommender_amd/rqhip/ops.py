@@ -481,11 +481,14 @@ def linear_wgrad_supported(n_out: int, n_in: int) -> bool:
     return bool(_lib.lib().rqhip_linear_wgrad_supported(int(n_out), int(n_in)))
 
 
-def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool = True, out: Optional[Tensor] = None):
+def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool = True, out: Optional[Tensor] = None,
+                 exact_fp32: bool = False):
     """dW [N,K] = (g * (y > 0))^T x with the ReLU backward fused (rqhip_linear_wgrad); y None = layer without ReLU.
     Returns (dW, g_pre): g_pre = the masked gradient in a fresh tensor when `want_masked` and y is given (the input
     of the data-gradient GEMM that follows), g itself when there is no mask, None when not wanted.  `out`: a
-    contiguous fp32 [N,K] tensor to receive dW (e.g. the parameter's slice of a flat gradient buffer)."""
+    contiguous fp32 [N,K] tensor to receive dW (e.g. the parameter's slice of a flat gradient buffer).
+    exact_fp32: force the fp32-MFMA kernel with the oracle-restated summation order (RQHIP_WGRAD_FP32) where the default is
+    the bf16-split kernel (large layers)."""
     _need_gpu(g, y, x)
     g, x = _f32c(g, "g"), _f32c(x, "x")
     y = _f32c(y, "y")
@@ -502,6 +505,7 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
         wsb = l.rqhip_linear_wgrad_workspace_bytes(M, N, K)
         ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
         gm = torch.empty_like(g) if (want_masked and y is not None) else None
-        rc = l.rqhip_linear_wgrad(_ptr(g), _ptr(y), _ptr(x), M, N, K, _ptr(gm), _ptr(dw), _ptr(ws), wsb, _stream())
-        check(rc, "rqhip_linear_wgrad")
+        rc = l.rqhip_linear_wgrad_ex(_ptr(g), _ptr(y), _ptr(x), M, N, K, _ptr(gm), _ptr(dw), _ptr(ws), wsb,
+                                     _lib.WGRAD_FP32 if exact_fp32 else 0, _stream())
+        check(rc, "rqhip_linear_wgrad_ex")
     return dw, (g if y is None else gm)
