@@ -74,11 +74,10 @@ class _LinearPlain(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad
         gw = None
         if need_w:
-            # without a mask to fuse the hand-written kernel only wins on the small layers; the 768 x 512 one stays
-            # with the library (measured 626 vs 600 us at 100 000 rows)
-            small = w.shape[0] * w.shape[1] <= 256 * 256
+            # (round 2 kept the 768 x 512 layer with the library: 626 vs 600 us for the fp32-MFMA kernel without a mask to
+            # fuse; the bf16-split kernel of round 3 takes it: csrc/wgrad_split.hip)
             sink = _grad_sink(w)
-            if small and _hip_wgrad_ok(gy, w):
+            if _hip_wgrad_ok(gy, w):
                 gw = ops.linear_wgrad(gy, None, x, out=sink)[0]
             else:
                 gw = torch.mm(gy.t(), x, out=sink) if sink is not None else gy.t().mm(x)
