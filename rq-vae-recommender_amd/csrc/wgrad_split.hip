@@ -160,20 +160,21 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         }
     };
 
-    // Software pipeline with a load-to-use distance of a WHOLE stage: the rows of stage c + 2 are requested before the
-    // matrix instructions of stage c and consumed (masked, split, written to LDS) at the top of the next iteration.  (A
-    // first version requested stage c + 1 before the matrix instructions of stage c and split it right after them: 1.3 us
-    // of matrix work do not cover an HBM round trip -- 3.1 us per stage measured, 0.4 of the matrix time.)
+    // Pipeline.  (1) Loads run two stages ahead: the rows of stage c + 2 are requested in iteration c and consumed
+    // (masked, split, written to LDS) in iteration c + 1.  (2) The two waves of a SIMD work OUT OF PHASE inside the one
+    // barrier interval of a stage: the first half of the workgroup's waves (one per SIMD) stages first and multiplies
+    // second, the other half multiplies first and stages second -- so each SIMD always has one wave on the matrix
+    // cores and one on the VALU / LDS.  A wave issues in order, and with every wave in the same phase (all split, then
+    // all multiply) nothing overlapped: 3.2 us per 16-row stage measured, the SUM of 1.3 us of matrix time and the
+    // staging.  Both phases read buffer `buf` and write buffer `buf ^ 1`, which every wave left at the last barrier.
+    const bool stage_first = wave < (WA * WB) / 2;
     if (n_stage > 0) {
         fetch(0);
         stash(0, 0);
         if (n_stage > 1) fetch(1);
     }
     __syncthreads();
-    for (long long c = 0; c < n_stage; ++c) {
-        const int buf = (int)(c & 1);
-        if (c + 1 < n_stage) stash(c + 1, buf ^ 1);     // (every wave left buffer buf ^ 1 at the last barrier)
-        if (c + 2 < n_stage) fetch(c + 2);
+    auto multiply = [&](int buf) {
         const ws_bf16x8 *gA = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X));
         const ws_bf16x8 *xB = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X) + PART_G);
         ws_bf16x8 a[TA][3], b[TB][3];
@@ -199,6 +200,18 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][0], c16, 0, 0, 0);   // h h
                 acc[t][u] = c16;
             }
+    };
+    for (long long c = 0; c < n_stage; ++c) {
+        const int buf = (int)(c & 1);
+        if (stage_first) {
+            if (c + 1 < n_stage) stash(c + 1, buf ^ 1);
+            if (c + 2 < n_stage) fetch(c + 2);
+        }
+        multiply(buf);
+        if (!stage_first) {
+            if (c + 1 < n_stage) stash(c + 1, buf ^ 1);
+            if (c + 2 < n_stage) fetch(c + 2);
+        }
         __syncthreads();
     }
 
