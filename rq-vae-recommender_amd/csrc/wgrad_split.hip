@@ -17,7 +17,8 @@
 //   * A = g_pre^T (32 n x 16 m), B = x (16 m x 32 k): a lane's operand is EIGHT CONSECUTIVE ROWS of one column, so the
 //     rows are transposed on the way into LDS: a staging thread takes 4 rows x 4 columns (four 16-byte loads per tensor,
 //     coalesced along the row), applies the ReLU mask, splits, and writes per column and piece one 8-byte half of the
-//     16-byte element [piece][row octet][column] -- which a lane then fetches with one conflict-free ds_read_b128.
+//     16-byte element [piece][row octet][position of the column] -- which a lane then fetches with one ds_read_b128;
+//     the column order in LDS is permuted so that both the strided writes and the reads are free of bank conflicts.
 //   * a workgroup owns an Nt x Kt block of dW and a contiguous range of rows, streams 16-row stages through a
 //     double-buffered LDS image (98 KB at 256 x 256), a wave owns (32 TA) x (32 TB); per stage and wave: 3 (TA + TB)
 //     operand reads, 6 TA TB matrix instructions.  Row ranges are reduced by wgrad.hip's balanced tree (second kernel).
@@ -62,7 +63,13 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB, NT = 64 * WA * WB;
     constexpr int UNITS = Nt + Kt;                 // staging units of 4 rows x 4 columns per stage: Nt for g, Kt for x
     constexpr int UQ = (UNITS + NT - 1) / NT;      // per thread
-    constexpr int PART_G = 3 * 2 * Nt * 4, PART_X = 3 * 2 * Kt * 4;   // dwords: [piece][octet][column] x 16 bytes
+    // LDS image of one operand: [piece][row octet][position] x 16 bytes, column c = 4 q + g at position g * S + q with
+    // S = W / 4 + 4.  A staging lane owns columns 4 cq .. 4 cq + 3, so for a fixed g the 64 lanes of a wave write 64
+    // CONSECUTIVE positions (with [column] order they wrote 64 bytes apart: a 16-way bank conflict on every one of the 12
+    // ds_write_b64 -- 1.7 us of the 3.2 us a stage took); the 16 lanes an operand read serves per cycle (columns
+    // c0 .. c0 + 15) hit positions g * S + q0 .. q0 + 3, g < 4: distinct modulo 16 because S = 4 (mod 16).
+    constexpr int SG = Nt / 4 + 4, SX = Kt / 4 + 4;
+    constexpr int PART_G = 3 * 2 * 4 * SG * 4, PART_X = 3 * 2 * 4 * SX * 4;   // dwords
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(ws_smem);      // [2][PART_G + PART_X]
 
@@ -143,19 +150,19 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
                     }
                 }
             }
-            // element [piece][octet = rq >> 1][column] is 16 bytes = rows 8 octet .. 8 octet + 7; this unit fills the
-            // half (rq & 1) of it for its four columns and every piece
+            // element [piece][octet = rq >> 1][position of the column] is 16 bytes = rows 8 octet .. 8 octet + 7; this unit
+            // fills the half (rq & 1) of it for its four columns and every piece
             unsigned *part = dst + (isg ? 0 : PART_G);
-            const int oct = rq >> 1, half = rq & 1;
+            const int oct = rq >> 1, half = rq & 1, S4 = 4 * (isg ? SG : SX);
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 unsigned h01, m01, l01, h23, m23, l23;
                 ws_split2(rv[q][0][cc], rv[q][1][cc], h01, m01, l01);
                 ws_split2(rv[q][2][cc], rv[q][3][cc], h23, m23, l23);
-                const int col = 4 * cq + cc;
-                *reinterpret_cast<ws_u32x2 *>(part + ((0 * 2 + oct) * W + col) * 4 + 2 * half) = ws_u32x2{h01, h23};
-                *reinterpret_cast<ws_u32x2 *>(part + ((1 * 2 + oct) * W + col) * 4 + 2 * half) = ws_u32x2{m01, m23};
-                *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * W + col) * 4 + 2 * half) = ws_u32x2{l01, l23};
+                const int pos = cc * (S4 / 4) + cq;      // column 4 cq + cc
+                *reinterpret_cast<ws_u32x2 *>(part + ((0 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{h01, h23};
+                *reinterpret_cast<ws_u32x2 *>(part + ((1 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{m01, m23};
+                *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{l01, l23};
             }
         }
     };
@@ -181,11 +188,13 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
         for (int t = 0; t < TA; ++t)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[t][pc] = gA[(pc * 2 + h) * Nt + wa * 32 * TA + 32 * t + il];
+            for (int pc = 0; pc < 3; ++pc)
+                a[t][pc] = gA[(pc * 2 + h) * (4 * SG) + (il & 3) * SG + ((wa * 32 * TA + 32 * t + il) >> 2)];
 #pragma unroll
         for (int u = 0; u < TB; ++u)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b[u][pc] = xB[(pc * 2 + h) * Kt + wb * 32 * TB + 32 * u + il];
+            for (int pc = 0; pc < 3; ++pc)
+                b[u][pc] = xB[(pc * 2 + h) * (4 * SX) + (il & 3) * SX + ((wb * 32 * TB + 32 * u + il) >> 2)];
         // smallest products first (their sum is formed before it meets the large ones)
 #pragma unroll
         for (int t = 0; t < TA; ++t)
@@ -240,7 +249,7 @@ int wgrad_split_cfg(int N, int K) {
 template <int TA, int TB, int WA, int WB>
 static int wgrad_split_go(const WgradSplitParams &p, bool mask, hipStream_t s) {
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB;
-    const size_t lds = (size_t)2 * (Nt + Kt) * 3 * 2 * 16;
+    const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * 3 * 2 * 16;
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
