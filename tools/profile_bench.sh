@@ -24,8 +24,18 @@ done
 for f in $(find "$OUT" -name "*counter_collection.csv"); do
     { head -1 "$f"; grep "rqhip::" "$f"; } > "$f.tmp" && mv "$f.tmp" "$f"
 done
+# per-dispatch durations of the forward kernel (the bench line's HIP-event mean is checked against these), then drop the trace
+for f in $(find "$OUT/stats" -name "*kernel_trace.csv"); do
+    python - "$f" "$OUT/rq_forward_dispatches.json" <<'PY'
+import csv, json, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rq_forward_kernel" in r["Kernel_Name"]]
+d = [{"kernel": r["Kernel_Name"][:80], "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+      "grid": int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)} for r in rows]
+json.dump(d, open(sys.argv[2], "w"))
+PY
+done
 find "$OUT" -name "*kernel_trace.csv" -delete
-find "$OUT" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
+find "$OUT" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" ! -name "*.sha256" -delete
 find "$OUT" -name "*.csv" -size +8M -delete
 du -sh "$OUT"; tail -3 "$OUT/stats.err"
 find "$OUT" -name "*.csv" | sed "s#$REPO/##"
