@@ -308,6 +308,24 @@ int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_
                           unsigned flags, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The activation GEMMs of the MLPs (reference modules/encoder.py:25-38: `relu(x W^T)` forward; autograd's `g W` data
+ * gradient) on the bf16 matrix cores with three exact bf16 pieces per fp32 operand and the six piece products that matter
+ * (csrc/gemm_split.hip; same arithmetic as the bf16-split weight gradient above).
+ *   rqhip_weight_planes : split a weight matrix w [rows, cols] once per step into the kernel's image.  transpose = 0: the
+ *       image of w itself (Nc = rows output columns, reduction R = cols: the forward, C = A w^T); transpose = 1: of w^T
+ *       (Nc = cols, R = rows: the data gradient, C = A w).  `planes`: rqhip_weight_planes_bytes(Nc, R) bytes, caller-owned.
+ *   rqhip_gemm_split    : C [M, Nc] = A [M, R] . image^T, optional ReLU.  Needs Nc % 256 == 0, R % 16 == 0
+ *       (rqhip_gemm_split_supported), 16-byte aligned pointers; one launch at a time per image (it holds the kernel's
+ *       tile dispenser).  Results are bit-reproducible; accuracy against fp64 is that of an fp32 GEMM (tests).
+ */
+int rqhip_gemm_split_supported(int Nc, int R);
+size_t rqhip_weight_planes_bytes(int Nc, int R);
+int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void *planes, size_t planes_bytes,
+                        rqhip_stream_t stream);
+int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
+                     rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every
  * rqhip_rq_forward call brackets its MAIN kernel (not the codebook-norm prologue) with a hipEvent pair
  * recorded on the call's stream.  rqhip_profile_read synchronises the recorded events and returns the

@@ -1,0 +1,269 @@
+// gemm_split.hip -- the activation GEMMs of the encoder / decoder MLPs on the bf16 matrix cores without narrowing the
+// arithmetic (gfx950).  SURVEY.md section 8 row f2; reference modules/encoder.py:25-38 (`relu(x W^T)` forward) and its
+// autograd (`g W` data gradient).
+//
+//   C[M, Nc] = A[M, R] . B[Nc, R]^T      A: fp32 activations (x, or the masked gradient g_pre), streamed from HBM
+//                                         B: a weight matrix (W for the forward, W^T for the data gradient), small
+//   optional ReLU epilogue (the forward of every layer but the last).
+//
+// Same arithmetic as csrc/wgrad_split.hip: every fp32 value is the exact sum of three bf16 pieces h + m + l, the product
+// is formed from the six piece products that matter (dropped terms <= 2^-23 of a product, below fp32's own rounding of
+// it), each piece product is exact in fp32 and accumulates in fp32 inside v_mfma_f32_32x32x16_bf16.  The library's fp32
+// GEMMs run these tall-skinny shapes at the fp32 matrix peak (443-582 us for the 78.6 GFLOP layers); six bf16
+// instructions of 32 cycles do the work of eight fp32 instructions of 64.
+//
+// Mapping
+//   * both operands are consumed along the reduction index as they lie in memory (a lane's operand = 8 consecutive r of
+//     one row of A / one row of B): no transposition.  The weight is split ONCE per step by `weight_planes_kernel` into
+//     the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage is three contiguous 4 KB runs.
+//   * workgroup = 128 rows x 256 columns, 8 waves of 64 x 64 (<= 128 VGPRs: two workgroups per CU run out of phase and
+//     hide each other's barriers), 16-deep stages through a double-buffered LDS image (36 KB per stage), loads two
+//     stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
+//     tiles on 512 slots; a static round-robin would leave the last round a tenth full).
+//   * results do not depend on which workgroup computes a tile: bit-reproducible run to run.
+#include "rqhip_common.h"
+
+namespace rqhip {
+
+typedef float gs_f32x16 __attribute__((ext_vector_type(16)));
+typedef float gs_f32x4 __attribute__((ext_vector_type(4)));
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGsRows = 128, kGsCols = 256, kGsThreads = 512, kGsK = 16;
+
+__device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    const gs_bf16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_bf16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const gs_bf16x2 mm = __builtin_convertvector(gs_f32x2{ra, rb}, gs_bf16x2);
+    m = __builtin_bit_cast(unsigned, mm);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    const gs_bf16x2 ll = __builtin_convertvector(gs_f32x2{sa, sb}, gs_bf16x2);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
+// planes[s][piece][half][n] (16 bytes: r = 16 s + 8 half + j, j < 8) of src[n][r] (transpose == 0, src is [Nc, R]) or of
+// src[r][n] (transpose == 1, src is [R, Nc]: the data gradient multiplies by W, i.e. B = W^T).  One thread per element.
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float *__restrict__ src, int Nc, int R, int transpose,
+                                                            unsigned *__restrict__ planes) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;     // (n, r pair): r = 2 rp, 2 rp + 1
+    const long long total = (long long)Nc * (R / 2);
+    if (e < 4) planes[(size_t)(R / kGsK) * 6 * Nc * 4 + e] = 0u;        // the tile dispenser behind the image
+    if (e >= total) return;
+    const int n = (int)(e % Nc), rp = (int)(e / Nc), r = 2 * rp;
+    const float a = transpose ? src[(size_t)r * Nc + n] : src[(size_t)n * R + r];
+    const float b = transpose ? src[(size_t)(r + 1) * Nc + n] : src[(size_t)n * R + r + 1];
+    unsigned h, m, l;
+    gs_split2(a, b, h, m, l);
+    const int s = r >> 4, half = (r >> 3) & 1, j2 = (r & 7) >> 1;      // dword j2 of the 16-byte element
+    const size_t base = ((size_t)(s * 3) * 2 + half) * Nc + n;
+    planes[(base + 0 * 2 * (size_t)Nc) * 4 + j2] = h;
+    planes[(base + 1 * 2 * (size_t)Nc) * 4 + j2] = m;
+    planes[(base + 2 * 2 * (size_t)Nc) * 4 + j2] = l;
+}
+
+struct GemmSplitParams {
+    const float *A;          // [M, R]
+    const unsigned *planes;  // weight image, see weight_planes_kernel
+    float *C;                // [M, Nc]
+    long long M;
+    int R, Nc;
+    int n_row_tiles, n_col_tiles;
+    unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
+};
+
+template <bool RELU>
+__global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
+    constexpr int PA = 3 * 2 * kGsRows * 4, PB = 3 * 2 * kGsCols * 4;   // dwords per stage image
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);            // [2][PA + PB]
+    __shared__ unsigned s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;                            // 2 x 4 waves of 64 x 64
+    const int n_stage = p.R / kGsK;
+    const unsigned n_tiles = (unsigned)p.n_row_tiles * (unsigned)p.n_col_tiles;
+    // staging roles: A -- thread (row = tid >> 2, kq = tid & 3) owns 4 consecutive r of one row; B -- three 16-byte
+    // elements of the stage's weight image per thread
+    const int arow = tid >> 2, akq = tid & 3;
+
+    for (;;) {
+        __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
+        if (tid == 0) s_tile = atomicAdd(p.counter, 1u);
+        __syncthreads();
+        const unsigned tile = s_tile;
+        if (tile >= n_tiles) {
+            // the last workgroup to leave re-arms the dispenser for the next launch (nobody takes a ticket after it)
+            if (tid == 0 && atomicAdd(p.counter + 1, 1u) == gridDim.x - 1) {
+                p.counter[0] = 0u;
+                p.counter[1] = 0u;
+            }
+            break;
+        }
+        // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2)
+        const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+        const long long m0 = (long long)rt * kGsRows;
+        const int n0 = ct * kGsCols;
+        const long long arow_g = m0 + arow;
+        const bool arow_ok = arow_g < p.M;
+        const float *asrc = p.A + (size_t)(arow_ok ? arow_g : 0) * p.R + 4 * akq;
+
+        gs_f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+        gs_f32x4 ra;
+        gs_u32x4 rb[3];
+        auto fetch = [&](int stage) {
+            ra = arow_ok ? *reinterpret_cast<const gs_f32x4 *>(asrc + stage * kGsK) : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+            // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
+            // (piece, half) rows: element e = tid + 512 q  ->  (ph = e >> 8, col = e & 255)
+            const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = tid + kGsThreads * q;
+                rb[q] = img[(size_t)(e >> 8) * p.Nc + (e & 255)];
+            }
+        };
+        auto stash = [&](int buf) {
+            unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
+            unsigned h01, m01, l01, h23, m23, l23;
+            gs_split2(ra.x, ra.y, h01, m01, l01);
+            gs_split2(ra.z, ra.w, h23, m23, l23);
+            // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
+            unsigned *d = dA + (((akq >> 1) * kGsRows) + arow) * 4 + 2 * (akq & 1);
+            *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * kGsRows * 4) = gs_u32x2{h01, h23};
+            *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * kGsRows * 4) = gs_u32x2{m01, m23};
+            *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * kGsRows * 4) = gs_u32x2{l01, l23};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = tid + kGsThreads * q;
+                *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
+            }
+        };
+        auto multiply = [&](int buf) {
+            const gs_bf16x8 *aA = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB));
+            const gs_bf16x8 *bB = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB) + PA);
+            gs_bf16x8 b[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b[u][pc] = bB[(pc * 2 + h) * kGsCols + wn * 64 + 32 * u + il];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                gs_bf16x8 a[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * kGsRows + wm * 64 + 32 * t + il];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    gs_f32x16 c16 = acc[t][u];
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][1], c16, 0, 0, 0);   // m m (smallest first)
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[u][0], c16, 0, 0, 0);   // l h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][2], c16, 0, 0, 0);   // h l
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][0], c16, 0, 0, 0);   // m h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][1], c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][0], c16, 0, 0, 0);   // h h
+                    acc[t][u] = c16;
+                }
+            }
+        };
+
+        fetch(0);
+        stash(0);
+        if (n_stage > 1) fetch(1);
+        __syncthreads();
+        for (int c = 0; c < n_stage; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < n_stage) stash(buf ^ 1);      // rows of stage c + 1, requested a whole iteration ago
+            if (c + 2 < n_stage) fetch(c + 2);
+            multiply(buf);
+            __syncthreads();
+        }
+
+        // acc[t][u][r]: row = m0 + 64 wm + 32 t + 8 (r >> 2) + 4 h + (r & 3),  column = n0 + 64 wn + 32 u + il
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m0 + 64 * wm + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (row < p.M) {
+                    float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + il;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float v = acc[t][u][r];
+                        dst[32 * u] = RELU ? (v < 0.0f ? 0.0f : v) : v;   // (a NaN stays a NaN, as torch.relu)
+                    }
+                }
+            }
+    }
+}
+
+}  // namespace rqhip
+
+using namespace rqhip;
+
+extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R > 0 && Nc % kGsCols == 0 && R % kGsK == 0) ? 1 : 0; }
+
+extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) {
+    if (!rqhip_gemm_split_supported(Nc, R)) return 0;
+    return (size_t)(R / kGsK) * 6 * Nc * 16 + 64;    // + the tile counter behind the image
+}
+
+extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void *planes, size_t planes_bytes,
+                                   rqhip_stream_t stream) {
+    // w is [rows, cols] row-major.  transpose == 0: B = w (Nc = rows, R = cols); transpose == 1: B = w^T (Nc = cols, R = rows)
+    const int Nc = transpose ? cols : rows, R = transpose ? rows : cols;
+    if (!w || !planes || !rqhip_gemm_split_supported(Nc, R) || planes_bytes < rqhip_weight_planes_bytes(Nc, R)) {
+        set_error("weight_planes: bad arguments or unsupported shape (Nc = %d must be a multiple of 256, R = %d of 16)", Nc, R);
+        return RQHIP_EARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long total = (long long)Nc * (R / 2);
+    hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, Nc, R, transpose,
+                       reinterpret_cast<unsigned *>(planes));
+    RQ_CHECK_LAUNCH("weight_planes_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
+                                rqhip_stream_t stream) {
+    if (M < 0 || !planes || (M > 0 && (!A || !C)) || !rqhip_gemm_split_supported(Nc, R)) {
+        set_error("gemm_split: bad arguments or unsupported shape (Nc = %d, R = %d)", Nc, R);
+        return RQHIP_EARG;
+    }
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (!al16(A) || !al16(C) || !al16(planes) || (R % 4) != 0) {
+        set_error("gemm_split: pointers must be 16-byte aligned");
+        return RQHIP_EARG;
+    }
+    if (M == 0) return RQHIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GemmSplitParams p;
+    p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
+    p.n_row_tiles = (int)((M + kGsRows - 1) / kGsRows);
+    p.n_col_tiles = Nc / kGsCols;
+    // the tile dispenser lives behind the weight image (rqhip_weight_planes_bytes reserves it); a kernel zeroes it
+    // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_planes, re-armed by every launch): one
+    // GEMM at a time per image, i.e. launches on one stream
+    p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 6 * Nc * 4;
+    const size_t lds = (size_t)2 * (3 * 2 * (kGsRows + kGsCols) * 16);
+    long long tiles = (long long)p.n_row_tiles * p.n_col_tiles;
+    const long long slots = (long long)cu_count() * 2;     // two workgroups per CU (72 KB of LDS, 128 VGPRs each)
+    const int grid = (int)(tiles < slots ? tiles : slots);
+    auto go = [&](auto kern) -> int {
+        static LdsGrant grant;
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kGsThreads), lds, s, p);
+        RQ_CHECK_LAUNCH("gemm_split_kernel");
+        return 0;
+    };
+    return relu ? go(gemm_split_kernel<true>) : go(gemm_split_kernel<false>);
+}

@@ -65,6 +65,10 @@ SIGNATURES = {
     "rqhip_linear_wgrad_workspace_bytes": (_sz, [_i64, _int, _int]),
     "rqhip_linear_wgrad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_linear_wgrad_ex": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, C.c_uint, _vp]),
+    "rqhip_gemm_split_supported": (_int, [_int, _int]),
+    "rqhip_weight_planes_bytes": (_sz, [_int, _int]),
+    "rqhip_weight_planes": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp]),
+    "rqhip_gemm_split": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),
 }

@@ -509,3 +509,36 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
                                      _lib.WGRAD_FP32 if exact_fp32 else 0, _stream())
         check(rc, "rqhip_linear_wgrad_ex")
     return dw, (g if y is None else gm)
+
+
+def gemm_split_supported(n_cols: int, n_red: int) -> bool:
+    return bool(_lib.lib().rqhip_gemm_split_supported(int(n_cols), int(n_red)))
+
+
+def weight_planes(w: Tensor, transpose: bool = False) -> Tensor:
+    """The bf16-piece image of a weight matrix for `gemm_split` (rqhip_weight_planes): of w [rows, cols] itself
+    (forward: C = A w^T) or of w^T (`transpose`: data gradient, C = A w).  Returns an opaque uint8 tensor."""
+    _need_gpu(w)
+    w = _f32c(w, "w")
+    rows, cols = w.shape
+    Nc, R = (cols, rows) if transpose else (rows, cols)
+    with torch.cuda.device(w.device):
+        l = _lib.lib()
+        nbytes = l.rqhip_weight_planes_bytes(Nc, R)
+        if nbytes == 0:
+            raise RqHipError(f"weight_planes: unsupported shape {tuple(w.shape)} (transpose={transpose})")
+        planes = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+        check(l.rqhip_weight_planes(_ptr(w), rows, cols, int(transpose), _ptr(planes), nbytes, _stream()), "rqhip_weight_planes")
+    return planes
+
+
+def gemm_split(a: Tensor, planes: Tensor, n_cols: int, relu: bool = False) -> Tensor:
+    """C [M, n_cols] = a [M, R] . image^T with the optional ReLU epilogue (rqhip_gemm_split)."""
+    _need_gpu(a, planes)
+    a = _f32c(a, "a")
+    M, R = a.shape
+    with torch.cuda.device(a.device):
+        c = torch.empty((M, n_cols), dtype=torch.float32, device=a.device)
+        check(_lib.lib().rqhip_gemm_split(_ptr(a), M, R, _ptr(planes), int(n_cols), int(relu), _ptr(c), _stream()),
+              "rqhip_gemm_split")
+    return c
