@@ -16,9 +16,8 @@
 //   * both operands are consumed along the reduction index as they lie in memory (a lane's operand = 8 consecutive r of
 //     one row of A / one row of B): no transposition.  The weight is split ONCE per step by `weight_planes_kernel` into
 //     the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage is three contiguous 4 KB runs.
-//   * workgroup = 128 rows x 256 columns, 8 waves of 64 x 64 (<= 128 VGPRs: two workgroups per CU run out of phase and
-//     hide each other's barriers), 16-deep stages through a double-buffered LDS image (36 KB per stage), loads two
-//     stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
+//   * workgroup = 128 or 256 rows x 256 columns, 8 waves of 64 x 64 / 128 x 64, 16-deep stages through a double-buffered
+//     LDS image, loads two stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
 //     tiles on 512 slots; a static round-robin would leave the last round a tenth full).
 //   * results do not depend on which workgroup computes a tile: bit-reproducible run to run.
 #include "rqhip_common.h"
@@ -33,7 +32,7 @@ typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsRows = 128, kGsCols = 256, kGsThreads = 512, kGsK = 16;
+constexpr int kGsCols = 256, kGsThreads = 512, kGsK = 16;   // rows per workgroup: 64 TA (template)
 
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
     const gs_bf16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_bf16x2);
@@ -76,8 +75,9 @@ struct GemmSplitParams {
     unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
 };
 
-template <bool RELU>
+template <bool RELU, int TA>
 __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
+    constexpr int kGsRows = 64 * TA, AQ = TA / 2;                       // rows per workgroup; float4s of A per thread and stage
     constexpr int PA = 3 * 2 * kGsRows * 4, PB = 3 * 2 * kGsCols * 4;   // dwords per stage image
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);            // [2][PA + PB]
@@ -108,22 +108,29 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
         const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
         const long long m0 = (long long)rt * kGsRows;
         const int n0 = ct * kGsCols;
-        const long long arow_g = m0 + arow;
-        const bool arow_ok = arow_g < p.M;
-        const float *asrc = p.A + (size_t)(arow_ok ? arow_g : 0) * p.R + 4 * akq;
-
-        gs_f32x16 acc[2][2];
+        bool arow_ok[AQ];
+        const float *asrc[AQ];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int q = 0; q < AQ; ++q) {
+            const long long arow_g = m0 + arow + 128 * q;
+            arow_ok[q] = arow_g < p.M;
+            asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
+        }
+
+        gs_f32x16 acc[TA][2];
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
-        gs_f32x4 ra;
+        gs_f32x4 ra[AQ];
         gs_u32x4 rb[3];
         auto fetch = [&](int stage) {
-            ra = arow_ok ? *reinterpret_cast<const gs_f32x4 *>(asrc + stage * kGsK) : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < AQ; ++q)
+                ra[q] = arow_ok[q] ? *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK) : gs_f32x4{0.f, 0.f, 0.f, 0.f};
             // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
             // (piece, half) rows: element e = tid + 512 q  ->  (ph = e >> 8, col = e & 255)
             const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
@@ -135,14 +142,17 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
         };
         auto stash = [&](int buf) {
             unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
-            unsigned h01, m01, l01, h23, m23, l23;
-            gs_split2(ra.x, ra.y, h01, m01, l01);
-            gs_split2(ra.z, ra.w, h23, m23, l23);
-            // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
-            unsigned *d = dA + (((akq >> 1) * kGsRows) + arow) * 4 + 2 * (akq & 1);
-            *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * kGsRows * 4) = gs_u32x2{h01, h23};
-            *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * kGsRows * 4) = gs_u32x2{m01, m23};
-            *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * kGsRows * 4) = gs_u32x2{l01, l23};
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) {
+                unsigned h01, m01, l01, h23, m23, l23;
+                gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
+                gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
+                // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
+                unsigned *d = dA + (((akq >> 1) * kGsRows) + arow + 128 * q) * 4 + 2 * (akq & 1);
+                *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * kGsRows * 4) = gs_u32x2{h01, h23};
+                *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * kGsRows * 4) = gs_u32x2{m01, m23};
+                *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * kGsRows * 4) = gs_u32x2{l01, l23};
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int e = tid + kGsThreads * q;
@@ -158,10 +168,10 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) b[u][pc] = bB[(pc * 2 + h) * kGsCols + wn * 64 + 32 * u + il];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TA; ++t) {
                 gs_bf16x8 a[3];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * kGsRows + wm * 64 + 32 * t + il];
+                for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * kGsRows + wm * 32 * TA + 32 * t + il];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     gs_f32x16 c16 = acc[t][u];
@@ -188,12 +198,12 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
             __syncthreads();
         }
 
-        // acc[t][u][r]: row = m0 + 64 wm + 32 t + 8 (r >> 2) + 4 h + (r & 3),  column = n0 + 64 wn + 32 u + il
+        // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + 8 (r >> 2) + 4 h + (r & 3),  column = n0 + 64 wn + 32 u + il
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TA; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long row = m0 + 64 * wm + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+                const long long row = m0 + 32 * TA * wm + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
                 if (row < p.M) {
                     float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + il;
 #pragma unroll
@@ -233,8 +243,16 @@ extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int trans
     return RQHIP_OK;
 }
 
+static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C, int flags_tile,
+                             rqhip_stream_t stream);
+
 extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
                                 rqhip_stream_t stream) {
+    return gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, (relu >> 8) & 0xfff, stream);   // (bits 8.. of `relu`: tile rows, A/B)
+}
+
+static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C, int flags_tile,
+                             rqhip_stream_t stream) {
     if (M < 0 || !planes || (M > 0 && (!A || !C)) || !rqhip_gemm_split_supported(Nc, R)) {
         set_error("gemm_split: bad arguments or unsupported shape (Nc = %d, R = %d)", Nc, R);
         return RQHIP_EARG;
@@ -248,22 +266,29 @@ extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *pl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     GemmSplitParams p;
     p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
-    p.n_row_tiles = (int)((M + kGsRows - 1) / kGsRows);
+    // 256-row tiles (8 waves of 128 x 64: fewer LDS reads per matrix instruction) when they fill the chip evenly, else 128
+    const int cus = cu_count();
+    const long long t256 = ((M + 255) / 256) * (Nc / kGsCols), t128 = ((M + 127) / 128) * (Nc / kGsCols);
+    auto waste = [&](long long tiles, long long slots) { const long long rounds = (tiles + slots - 1) / slots; return (double)(rounds * slots) / (double)tiles; };
+    const bool big = (flags_tile == 256) || (flags_tile == 0 && waste(t256, cus) <= waste(t128, cus) * 1.05);
+    const int rows_per_wg = big ? 256 : 128;
+    p.n_row_tiles = (int)((M + rows_per_wg - 1) / rows_per_wg);
     p.n_col_tiles = Nc / kGsCols;
     // the tile dispenser lives behind the weight image (rqhip_weight_planes_bytes reserves it); a kernel zeroes it
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_planes, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 6 * Nc * 4;
-    const size_t lds = (size_t)2 * (3 * 2 * (kGsRows + kGsCols) * 16);
+    const size_t lds = (size_t)2 * (3 * 2 * (rows_per_wg + kGsCols) * 16);
     long long tiles = (long long)p.n_row_tiles * p.n_col_tiles;
-    const long long slots = (long long)cu_count() * 2;     // two workgroups per CU (72 KB of LDS, 128 VGPRs each)
+    const long long slots = (long long)cus;                // one workgroup per CU (163+ VGPRs x 512 threads)
     const int grid = (int)(tiles < slots ? tiles : slots);
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
-        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)lds));   // (+ 4 bytes of static LDS)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kGsThreads), lds, s, p);
         RQ_CHECK_LAUNCH("gemm_split_kernel");
         return 0;
     };
-    return relu ? go(gemm_split_kernel<true>) : go(gemm_split_kernel<false>);
+    if (big) return relu ? go(gemm_split_kernel<true, 4>) : go(gemm_split_kernel<false, 4>);
+    return relu ? go(gemm_split_kernel<true, 2>) : go(gemm_split_kernel<false, 2>);
 }

@@ -532,13 +532,14 @@ def weight_planes(w: Tensor, transpose: bool = False) -> Tensor:
     return planes
 
 
-def gemm_split(a: Tensor, planes: Tensor, n_cols: int, relu: bool = False) -> Tensor:
+def gemm_split(a: Tensor, planes: Tensor, n_cols: int, relu: bool = False, tile_rows: int = 0) -> Tensor:
     """C [M, n_cols] = a [M, R] . image^T with the optional ReLU epilogue (rqhip_gemm_split)."""
     _need_gpu(a, planes)
     a = _f32c(a, "a")
     M, R = a.shape
     with torch.cuda.device(a.device):
         c = torch.empty((M, n_cols), dtype=torch.float32, device=a.device)
-        check(_lib.lib().rqhip_gemm_split(_ptr(a), M, R, _ptr(planes), int(n_cols), int(relu), _ptr(c), _stream()),
+        check(_lib.lib().rqhip_gemm_split(_ptr(a), M, R, _ptr(planes), int(n_cols), int(relu) | (int(tile_rows) << 8), _ptr(c),
+                                          _stream()),
               "rqhip_gemm_split")
     return c
