@@ -36,11 +36,21 @@ def _adopt(gw: Tensor, sink) -> Tensor:
 # every supported data gradient and every supported forward but the first encoder layer's (768 -> 512 with the ReLU
 # epilogue: 470 vs 445-489 us, a tie) is faster; small batches are launch-bound and stay with the library.
 _SPLIT_MIN_ROWS = 4096
+_SPLIT_GEMMS = True
+
+
+def use_split_gemms(on: bool = True) -> bool:
+    """Route the large activation GEMMs through csrc/gemm_split.hip (default) or the library (A/B: tools/ab_step.py).
+    Returns the previous setting."""
+    global _SPLIT_GEMMS
+    before, _SPLIT_GEMMS = _SPLIT_GEMMS, bool(on)
+    return before
+
 _PLANES = {}   # (id(weight), transpose) -> (weight version, weakref, image): the image is rebuilt when the weight changes
 
 
 def _split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool) -> bool:
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= _SPLIT_MIN_ROWS
+    if not (_SPLIT_GEMMS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= _SPLIT_MIN_ROWS
             and x.is_contiguous() and ops.gemm_split_supported(n_cols, n_red)):
         return False
     return not (forward_relu and (n_cols, n_red) == (512, 768))
