@@ -15,7 +15,9 @@ import torch
 from torch import Tensor, nn
 
 from modules.normalize import L2NormalizationLayer
+from rqhip import linear as _lin
 from rqhip import ops, torch_ops
+from rqhip.linear import use_split_gemms  # noqa: F401  (A/B switch, tools/ab_step.py)
 
 
 def _grad_sink(w: Tensor):
@@ -31,61 +33,9 @@ def _adopt(gw: Tensor, sink) -> Tensor:
     return gw.view_as(gw) if sink is not None else gw
 
 
-# ---- the large activation GEMMs on the bf16 matrix cores (csrc/gemm_split.hip) ------------------------------------------
-# Measured at 100 000 rows against the tuned library fp32 GEMM of the same layer (tools/bench_gemm_split.py):
-# every supported data gradient and every supported forward but the first encoder layer's (768 -> 512 with the ReLU
-# epilogue: 470 vs 445-489 us, a tie) is faster; small batches are launch-bound and stay with the library.
-_SPLIT_MIN_ROWS = 4096
-_SPLIT_GEMMS = True
-
-
-def use_split_gemms(on: bool = True) -> bool:
-    """Route the large activation GEMMs through csrc/gemm_split.hip (default) or the library (A/B: tools/ab_step.py).
-    Returns the previous setting."""
-    global _SPLIT_GEMMS
-    before, _SPLIT_GEMMS = _SPLIT_GEMMS, bool(on)
-    return before
-
-_PLANES = {}   # (id(weight), transpose) -> (weight version, weakref, image): the image is rebuilt when the weight changes
-
-
-def _split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool) -> bool:
-    if not (_SPLIT_GEMMS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= _SPLIT_MIN_ROWS
-            and x.is_contiguous() and ops.gemm_split_supported(n_cols, n_red)):
-        return False
-    return not (forward_relu and (n_cols, n_red) == (512, 768))
-
-
-def _planes(w: Tensor, transpose: bool) -> Tensor:
-    """The bf16-piece image of `w` (or of its transpose), cached per weight VERSION: the optimizer's in-place update bumps
-    it, eval / tokenisation loops reuse the image.  While a hipGraph is being captured the image is always rebuilt -- the
-    replayed step updates the weights without running this Python code, so the rebuild has to be part of the graph."""
-    import weakref
-    wd = w.detach()
-    if torch.cuda.is_current_stream_capturing():
-        return ops.weight_planes(wd, transpose=transpose)
-    key = (id(w), transpose)
-    hit = _PLANES.get(key)
-    if hit is not None and hit[0] == w._version and hit[1]() is w and hit[2].device == w.device:
-        return hit[2]
-    img = ops.weight_planes(wd, transpose=transpose)
-    if len(_PLANES) > 64:
-        _PLANES.clear()
-    _PLANES[key] = (w._version, weakref.ref(w), img)
-    return img
-
-
 def _hip_wgrad_ok(g: Tensor, w: Tensor) -> bool:
     return (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[0] > 0
             and ops.linear_wgrad_supported(w.shape[0], w.shape[1]))
-
-
-def _input_grad(g: Tensor, w: Tensor) -> Tensor:
-    """g [M, N] . w [N, K]: the bf16-split kernel with the image of w^T where it applies, else the library GEMM."""
-    g = g if g.is_contiguous() else g.contiguous()
-    if _split_ok(g, w.shape[1], w.shape[0], False):
-        return ops.gemm_split(g, _planes(w, True), w.shape[1])
-    return g.mm(w)
 
 
 class _LinearReLU(torch.autograd.Function):
@@ -96,10 +46,7 @@ class _LinearReLU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, zero_bias: Tensor) -> Tensor:
-        if _split_ok(x, w.shape[0], w.shape[1], True):
-            y = ops.gemm_split(x, _planes(w, False), w.shape[0], relu=True)
-        else:
-            y = torch._addmm_activation(zero_bias, x, w.t())
+        y = _lin.forward(x, w, True, zero_bias)
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -113,7 +60,7 @@ class _LinearReLU(torch.autograd.Function):
         else:
             g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
             gw = (torch.mm(g.t(), x, out=sink) if sink is not None else g.t().mm(x)) if need_w else None
-        gx = _input_grad(g, w) if need_x else None
+        gx = _lin.input_grad(g, w) if need_x else None
         return gx, (_adopt(gw, sink) if need_w else None), None
 
 
@@ -123,9 +70,7 @@ class _LinearPlain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor) -> Tensor:
         ctx.save_for_backward(x, w)
-        if _split_ok(x, w.shape[0], w.shape[1], False):
-            return ops.gemm_split(x, _planes(w, False), w.shape[0])
-        return x.mm(w.t())
+        return _lin.forward(x, w, False)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
@@ -141,7 +86,7 @@ class _LinearPlain(torch.autograd.Function):
             else:
                 gw = torch.mm(gy.t(), x, out=sink) if sink is not None else gy.t().mm(x)
             gw = _adopt(gw, sink)
-        gx = _input_grad(gy, w) if need_x else None
+        gx = _lin.input_grad(gy, w) if need_x else None
         return gx, gw
 
 

@@ -22,6 +22,7 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
+from . import linear as _lin
 from . import ops
 
 _ENABLED = False   # rqhip.torch_ops.enable() switches the module mirrors to the registered operators
@@ -92,7 +93,7 @@ rq_stack.register_autograd(_rq_backward, setup_context=_rq_setup)
 # ---- Linear(+ReLU) of the MLPs: library GEMM forward, hand-written weight gradient backward --------------------------
 @torch.library.custom_op("rqhip::linear_relu", mutates_args=())
 def linear_relu(x: Tensor, w: Tensor) -> Tensor:
-    return torch._addmm_activation(x.new_zeros((w.shape[0],)), x, w.t())
+    return _lin.forward(x, w, True)
 
 
 @linear_relu.register_fake
@@ -104,13 +105,12 @@ def _(x, w):
 def linear_backward(gy: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, need_x: bool) -> List[Tensor]:
     """(gx, gw) of y = relu(x w^T) (y given) or y = x w^T (y None): rqhip_linear_wgrad + one library GEMM."""
     gy = gy.contiguous()
-    small_or_masked = y is not None or w.shape[0] * w.shape[1] <= 256 * 256
-    if small_or_masked and ops.linear_wgrad_supported(w.shape[0], w.shape[1]) and gy.shape[0] > 0:
+    if ops.linear_wgrad_supported(w.shape[0], w.shape[1]) and gy.shape[0] > 0:
         gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x)
     else:
         g = gy if y is None else torch.ops.aten.threshold_backward(gy, y, 0.0)
         gw = g.t().mm(x)
-    gx = g.mm(w) if need_x else gy.new_empty((0,))
+    gx = _lin.input_grad(g, w) if need_x else gy.new_empty((0,))
     return [gx, gw]
 
 
@@ -136,7 +136,7 @@ linear_relu.register_autograd(_lr_backward, setup_context=_lr_setup)
 
 @torch.library.custom_op("rqhip::linear_plain", mutates_args=())
 def linear_plain(x: Tensor, w: Tensor) -> Tensor:
-    return x.mm(w.t())
+    return _lin.forward(x, w, False)
 
 
 @linear_plain.register_fake

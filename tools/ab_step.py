@@ -14,6 +14,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")]
 import bench  # noqa: E402
 from data.schemas import SeqBatch  # noqa: E402
 from modules import encoder  # noqa: E402
+from rqhip import linear  # noqa: E402
 from rqhip import dist as rqdist, ops, tuning  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 250
@@ -50,7 +51,7 @@ rows = []
 for rep in range(3):
     for name, split_gemm, split_wgrad in (("split gemm + split wgrad", True, True), ("library gemm + split wgrad", False, True),
                                           ("library gemm + fp32 wgrad", False, False)):
-        encoder.use_split_gemms(split_gemm)
+        linear.use_split_gemms(split_gemm)
         ops.linear_wgrad = _wg if split_wgrad else (lambda *a, **k: _wg(*a, **dict(k, exact_fp32=True)))
         encoder.ops.linear_wgrad = ops.linear_wgrad
         ms = block(steps)
