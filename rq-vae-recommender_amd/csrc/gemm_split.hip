@@ -16,8 +16,8 @@
 //   * both operands are consumed along the reduction index as they lie in memory (a lane's operand = 8 consecutive r of
 //     one row of A / one row of B): no transposition.  The weight is split ONCE per step by `weight_planes_kernel` into
 //     the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage is three contiguous 4 KB runs.
-//   * workgroup = 128 or 256 rows x 256 columns, 8 waves of 64 x 64 / 128 x 64, 16-deep stages through a double-buffered
-//     LDS image, loads two stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
+//   * tile = 256 rows x 256 columns (8 waves of 128 x 64) for whole rounds of the chip, 64 x 256 (8 waves of 32 x 64) for
+//     what is left over; 16-deep stages through a double-buffered LDS image, loads two stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
 //     tiles on 512 slots; a static round-robin would leave the last round a tenth full).
 //   * results do not depend on which workgroup computes a tile: bit-reproducible run to run.
 #include "rqhip_common.h"
@@ -32,7 +32,7 @@ typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsCols = 256, kGsThreads = 512, kGsK = 16;   // rows per workgroup: 64 TA (template)
+constexpr int kGsCols = 256, kGsThreads = 512, kGsK = 16;   // rows per tile: 64 TA (256 or 64)
 
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
     const gs_bf16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_bf16x2);
@@ -71,32 +71,146 @@ struct GemmSplitParams {
     float *C;                // [M, Nc]
     long long M;
     int R, Nc;
-    int n_row_tiles, n_col_tiles;
+    int n_col_tiles;
+    // tiles 0 .. n_big - 1 are 256 rows high (rows [0, 256 rt_big)), the rest 64 rows high (from row 256 rt_big on)
+    unsigned n_big, n_tiles;
+    int rt_big;
     unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
 };
 
+// one output tile of 64 TA rows x 256 columns: 8 waves of (32 TA) x 64
 template <bool RELU, int TA>
-__global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
-    constexpr int kGsRows = 64 * TA, AQ = TA / 2;                       // rows per workgroup; float4s of A per thread and stage
-    constexpr int PA = 3 * 2 * kGsRows * 4, PB = 3 * 2 * kGsCols * 4;   // dwords per stage image
-    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
-    unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);            // [2][PA + PB]
-    __shared__ unsigned s_tile;
+__device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
+    constexpr int ROWS = 64 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
+    constexpr int PA = 3 * 2 * ROWS * 4, PB = 3 * 2 * kGsCols * 4;                 // dwords per stage image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 31, h = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;                            // 2 x 4 waves of 64 x 64
+    const int wm = wave >> 2, wn = wave & 3;
     const int n_stage = p.R / kGsK;
-    const unsigned n_tiles = (unsigned)p.n_row_tiles * (unsigned)p.n_col_tiles;
-    // staging roles: A -- thread (row = tid >> 2, kq = tid & 3) owns 4 consecutive r of one row; B -- three 16-byte
-    // elements of the stage's weight image per thread
+    // staging roles: A -- thread (row = tid >> 2 (+ 128 q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
+    // 16-byte elements of the stage's weight image per thread
     const int arow = tid >> 2, akq = tid & 3;
+    bool a_live[AQ], arow_ok[AQ];
+    const float *asrc[AQ];
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) {
+        a_live[q] = arow + 128 * q < ROWS;
+        const long long arow_g = m0 + arow + 128 * q;
+        arow_ok[q] = a_live[q] && arow_g < p.M;
+        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
+    }
 
+    gs_f32x16 acc[TA][2];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    gs_f32x4 ra[AQ];
+    gs_u32x4 rb[3];
+    auto fetch = [&](int stage) {
+#pragma unroll
+        for (int q = 0; q < AQ; ++q)
+            ra[q] = arow_ok[q] ? *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK) : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+        // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
+        // (piece, half) rows: element e = tid + 512 q  ->  (ph = e >> 8, col = e & 255)
+        const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + kGsThreads * q;
+            rb[q] = img[(size_t)(e >> 8) * p.Nc + (e & 255)];
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            if (!a_live[q]) continue;
+            unsigned h01, m01, l01, h23, m23, l23;
+            gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
+            gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
+            // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
+            unsigned *d = dA + (((akq >> 1) * ROWS) + arow + 128 * q) * 4 + 2 * (akq & 1);
+            *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * ROWS * 4) = gs_u32x2{h01, h23};
+            *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * ROWS * 4) = gs_u32x2{m01, m23};
+            *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + kGsThreads * q;
+            *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
+        }
+    };
+    auto multiply = [&](int buf) {
+        const gs_bf16x8 *aA = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB));
+        const gs_bf16x8 *bB = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB) + PA);
+        gs_bf16x8 b[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) b[u][pc] = bB[(pc * 2 + h) * kGsCols + wn * 64 + 32 * u + il];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            gs_bf16x8 a[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * ROWS + wm * 32 * TA + 32 * t + il];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                gs_f32x16 c16 = acc[t][u];
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][1], c16, 0, 0, 0);   // m m (smallest first)
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[u][0], c16, 0, 0, 0);   // l h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][2], c16, 0, 0, 0);   // h l
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][0], c16, 0, 0, 0);   // m h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][1], c16, 0, 0, 0);   // h m
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][0], c16, 0, 0, 0);   // h h
+                acc[t][u] = c16;
+            }
+        }
+    };
+
+    fetch(0);
+    stash(0);
+    if (n_stage > 1) fetch(1);
+    __syncthreads();
+    for (int c = 0; c < n_stage; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_stage) stash(buf ^ 1);      // rows of stage c + 1, requested a whole iteration ago
+        if (c + 2 < n_stage) fetch(c + 2);
+        multiply(buf);
+        __syncthreads();
+    }
+
+    // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + 8 (r >> 2) + 4 h + (r & 3),  column = n0 + 64 wn + 32 u + il
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + 32 * TA * wm + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (row < p.M) {
+                float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + il;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float v = acc[t][u][r];
+                    dst[32 * u] = RELU ? (v < 0.0f ? 0.0f : v) : v;   // (a NaN stays a NaN, as torch.relu)
+                }
+            }
+        }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
+    __shared__ unsigned s_tile;
+    const int tid = threadIdx.x;
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
         if (tid == 0) s_tile = atomicAdd(p.counter, 1u);
         __syncthreads();
         const unsigned tile = s_tile;
-        if (tile >= n_tiles) {
+        if (tile >= p.n_tiles) {
             // the last workgroup to leave re-arms the dispenser for the next launch (nobody takes a ticket after it)
             if (tid == 0 && atomicAdd(p.counter + 1, 1u) == gridDim.x - 1) {
                 p.counter[0] = 0u;
@@ -104,115 +218,18 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
             }
             break;
         }
-        // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2)
-        const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
-        const long long m0 = (long long)rt * kGsRows;
-        const int n0 = ct * kGsCols;
-        bool arow_ok[AQ];
-        const float *asrc[AQ];
-#pragma unroll
-        for (int q = 0; q < AQ; ++q) {
-            const long long arow_g = m0 + arow + 128 * q;
-            arow_ok[q] = arow_g < p.M;
-            asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
+        // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2).  Whole rounds of
+        // the chip take 256-row tiles (fewest LDS reads per matrix instruction); what is left over after the last whole
+        // round is cut into 64-row tiles so that it spreads over all CUs instead of giving a few of them a fourth big
+        // tile (100 000 x 512: 782 big tiles on 256 CUs were 4 tile times for 3.05 rounds of work).
+        if (tile < p.n_big) {
+            const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+            gs_tile<RELU, 4>(p, sbuf, (long long)rt * 256, ct * kGsCols);
+        } else {
+            const unsigned st = tile - p.n_big;
+            const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
+            gs_tile<RELU, 1>(p, sbuf, (long long)p.rt_big * 256 + (long long)rt * 64, ct * kGsCols);
         }
-
-        gs_f32x16 acc[TA][2];
-#pragma unroll
-        for (int t = 0; t < TA; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
-
-        gs_f32x4 ra[AQ];
-        gs_u32x4 rb[3];
-        auto fetch = [&](int stage) {
-#pragma unroll
-            for (int q = 0; q < AQ; ++q)
-                ra[q] = arow_ok[q] ? *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK) : gs_f32x4{0.f, 0.f, 0.f, 0.f};
-            // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
-            // (piece, half) rows: element e = tid + 512 q  ->  (ph = e >> 8, col = e & 255)
-            const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int e = tid + kGsThreads * q;
-                rb[q] = img[(size_t)(e >> 8) * p.Nc + (e & 255)];
-            }
-        };
-        auto stash = [&](int buf) {
-            unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
-#pragma unroll
-            for (int q = 0; q < AQ; ++q) {
-                unsigned h01, m01, l01, h23, m23, l23;
-                gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
-                gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
-                // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
-                unsigned *d = dA + (((akq >> 1) * kGsRows) + arow + 128 * q) * 4 + 2 * (akq & 1);
-                *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * kGsRows * 4) = gs_u32x2{h01, h23};
-                *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * kGsRows * 4) = gs_u32x2{m01, m23};
-                *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * kGsRows * 4) = gs_u32x2{l01, l23};
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int e = tid + kGsThreads * q;
-                *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
-            }
-        };
-        auto multiply = [&](int buf) {
-            const gs_bf16x8 *aA = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB));
-            const gs_bf16x8 *bB = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB) + PA);
-            gs_bf16x8 b[2][3];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) b[u][pc] = bB[(pc * 2 + h) * kGsCols + wn * 64 + 32 * u + il];
-#pragma unroll
-            for (int t = 0; t < TA; ++t) {
-                gs_bf16x8 a[3];
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * kGsRows + wm * 32 * TA + 32 * t + il];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    gs_f32x16 c16 = acc[t][u];
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][1], c16, 0, 0, 0);   // m m (smallest first)
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[u][0], c16, 0, 0, 0);   // l h
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][2], c16, 0, 0, 0);   // h l
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][0], c16, 0, 0, 0);   // m h
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][1], c16, 0, 0, 0);   // h m
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][0], c16, 0, 0, 0);   // h h
-                    acc[t][u] = c16;
-                }
-            }
-        };
-
-        fetch(0);
-        stash(0);
-        if (n_stage > 1) fetch(1);
-        __syncthreads();
-        for (int c = 0; c < n_stage; ++c) {
-            const int buf = c & 1;
-            if (c + 1 < n_stage) stash(buf ^ 1);      // rows of stage c + 1, requested a whole iteration ago
-            if (c + 2 < n_stage) fetch(c + 2);
-            multiply(buf);
-            __syncthreads();
-        }
-
-        // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + 8 (r >> 2) + 4 h + (r & 3),  column = n0 + 64 wn + 32 u + il
-#pragma unroll
-        for (int t = 0; t < TA; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long row = m0 + 32 * TA * wm + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (row < p.M) {
-                    float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + il;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const float v = acc[t][u][r];
-                        dst[32 * u] = RELU ? (v < 0.0f ? 0.0f : v) : v;   // (a NaN stays a NaN, as torch.relu)
-                    }
-                }
-            }
     }
 }
 
@@ -266,21 +283,29 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     GemmSplitParams p;
     p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
-    // 256-row tiles (8 waves of 128 x 64: fewer LDS reads per matrix instruction) when they fill the chip evenly, else 128
     const int cus = cu_count();
-    const long long t256 = ((M + 255) / 256) * (Nc / kGsCols), t128 = ((M + 127) / 128) * (Nc / kGsCols);
-    auto waste = [&](long long tiles, long long slots) { const long long rounds = (tiles + slots - 1) / slots; return (double)(rounds * slots) / (double)tiles; };
-    const bool big = (flags_tile == 256) || (flags_tile == 0 && waste(t256, cus) <= waste(t128, cus) * 1.05);
-    const int rows_per_wg = big ? 256 : 128;
-    p.n_row_tiles = (int)((M + rows_per_wg - 1) / rows_per_wg);
     p.n_col_tiles = Nc / kGsCols;
-    // the tile dispenser lives behind the weight image (rqhip_weight_planes_bytes reserves it); a kernel zeroes it
+    // whole rounds of 256-row tiles, the remainder as 64-row tiles (see the kernel); flags_tile (tools only): 256 = big
+    // tiles for every row, 64 = small tiles for every row
+    const long long rt256 = (M + 255) / 256;
+    long long rt_big = ((rt256 * p.n_col_tiles) / cus) * cus / p.n_col_tiles;   // row tiles of the whole rounds
+    if (rt_big * 256 > M) rt_big = M / 256;
+    // (measured at 100 000 rows: worth it when the leftover is a small part of a round -- Nc = 512: 14 of 256 slots, 517 ->
+    // 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
+    if ((rt256 * p.n_col_tiles) % cus > (3 * cus) / 10 && rt256 * p.n_col_tiles >= cus) rt_big = rt256;
+    if (flags_tile == 256) rt_big = rt256;
+    if (flags_tile == 64) rt_big = 0;
+    const long long rem_rows = M - rt_big * 256 > 0 ? M - rt_big * 256 : 0;
+    const long long rt_small = (rem_rows + 63) / 64;
+    p.rt_big = (int)rt_big;
+    p.n_big = (unsigned)(rt_big * p.n_col_tiles);
+    p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_planes, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 6 * Nc * 4;
-    const size_t lds = (size_t)2 * (3 * 2 * (rows_per_wg + kGsCols) * 16);
-    long long tiles = (long long)p.n_row_tiles * p.n_col_tiles;
-    const long long slots = (long long)cus;                // one workgroup per CU (163+ VGPRs x 512 threads)
+    const size_t lds = (size_t)2 * (3 * 2 * (256 + kGsCols) * 16);
+    const long long tiles = (long long)p.n_tiles;
+    const long long slots = (long long)cus;                // one workgroup per CU (240 VGPRs x 512 threads)
     const int grid = (int)(tiles < slots ? tiles : slots);
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
@@ -289,6 +314,5 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
         RQ_CHECK_LAUNCH("gemm_split_kernel");
         return 0;
     };
-    if (big) return relu ? go(gemm_split_kernel<true, 4>) : go(gemm_split_kernel<false, 4>);
-    return relu ? go(gemm_split_kernel<true, 2>) : go(gemm_split_kernel<false, 2>);
+    return relu ? go(gemm_split_kernel<true>) : go(gemm_split_kernel<false>);
 }

@@ -28,7 +28,7 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n * 1e3
 
 
-print(f"{'layer W [N,K]':>14} {'GFLOP':>6} | {'fwd lib(relu)':>13} {'fwd split 128/256':>17} | {'dgrad lib':>9} {'dgrad split 128/256':>19} | planes us")
+print(f"{'layer W [N,K]':>14} {'GFLOP':>6} | {'fwd lib(relu)':>13} {'fwd split 256/auto':>17} | {'dgrad lib':>9} {'dgrad split 256/auto':>19} | planes us")
 for N, K in [(512, 768), (256, 512), (512, 256), (768, 512)]:
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
@@ -38,13 +38,13 @@ for N, K in [(512, 768), (256, 512), (512, 256), (768, 512)]:
     t_lib_f = timeit(lambda: torch._addmm_activation(zb, x, w.t()))
     pf, pb = ops.weight_planes(w), None
     t_planes = timeit(lambda: ops.weight_planes(w))
-    t_spl_f = timeit(lambda: ops.gemm_split(x, pf, N, relu=True, tile_rows=128))
-    t_spl_f2 = timeit(lambda: ops.gemm_split(x, pf, N, relu=True, tile_rows=256))
+    t_spl_f = timeit(lambda: ops.gemm_split(x, pf, N, relu=True, tile_rows=256))
+    t_spl_f2 = timeit(lambda: ops.gemm_split(x, pf, N, relu=True))
     t_lib_b = timeit(lambda: g.mm(w))
     if ops.gemm_split_supported(K, N):
         pb = ops.weight_planes(w, transpose=True)
-        t_spl_b = timeit(lambda: ops.gemm_split(g, pb, K, tile_rows=128))
-        t_spl_b2 = timeit(lambda: ops.gemm_split(g, pb, K, tile_rows=256))
+        t_spl_b = timeit(lambda: ops.gemm_split(g, pb, K, tile_rows=256))
+        t_spl_b2 = timeit(lambda: ops.gemm_split(g, pb, K))
     else:
         t_spl_b = t_spl_b2 = float("nan")
     print(f"{str((N, K)):>14} {gf:6.1f} | {t_lib_f:13.1f} {t_spl_f:8.1f}/{t_spl_f2:8.1f} | {t_lib_b:9.1f} {t_spl_b:9.1f}/{t_spl_b2:9.1f} | {t_planes:6.1f}")
