@@ -22,33 +22,12 @@ def use_split_gemms(on: bool = True) -> bool:
     return before
 
 
-_PLANES = {}   # (id(weight), transpose) -> (weight version, weakref, image): the image is rebuilt when the weight changes
-
-
-def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool) -> bool:
-    if not (_SPLIT_GEMMS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= _SPLIT_MIN_ROWS
-            and x.is_contiguous() and ops.gemm_split_supported(n_cols, n_red)):
-        return False
-    return not (forward_relu and (n_cols, n_red) == (512, 768))
-
-
 def planes(w: Tensor, transpose: bool) -> Tensor:
-    """The bf16-piece image of `w` (or of its transpose), cached per weight VERSION: the optimizer's in-place update bumps
-    it, eval / tokenisation loops reuse the image.  While a hipGraph is being captured the image is always rebuilt -- the
-    replayed step updates the weights without running this Python code, so the rebuild has to be part of the graph."""
-    import weakref
-    wd = w.detach()
-    if torch.cuda.is_current_stream_capturing():
-        return ops.weight_planes(wd, transpose=transpose)
-    key = (id(w), transpose)
-    hit = _PLANES.get(key)
-    if hit is not None and hit[0] == w._version and hit[1]() is w and hit[2].device == w.device:
-        return hit[2]
-    img = ops.weight_planes(wd, transpose=transpose)
-    if len(_PLANES) > 64:
-        _PLANES.clear()
-    _PLANES[key] = (w._version, weakref.ref(w), img)
-    return img
+    """The bf16-piece image of `w` (or of its transpose) for csrc/gemm_split.hip, rebuilt at EVERY use (one 6 us kernel).
+    A first version cached it per `w._version` -- and trained on stale weights: the fused AdamW update (and any
+    `w.data` write) does not bump the version counter.  Nothing cheaper than the rebuild is safe, and it is 0.1 % of the
+    GEMM it feeds; inside a hipGraph capture the rebuild is part of the graph, as it has to be."""
+    return ops.weight_planes(w.detach(), transpose=transpose)
 
 
 def input_grad(g: Tensor, w: Tensor) -> Tensor:

@@ -462,3 +462,40 @@ def test_flat_reducer_attach_puts_gradients_in_the_flat_buffer_without_copies():
         for (name, p), q, v in zip(attached.named_parameters(), plain.parameters(), red._views):
             assert p.grad.untyped_storage().data_ptr() == base and p.grad.data_ptr() == v.data_ptr(), name
             assert torch.equal(p.grad, q.grad), name
+
+
+def test_split_gemms_follow_the_optimizer():
+    """The bf16-split GEMMs read the weights through an image that is rebuilt at every use: three optimiser steps with the
+    FUSED AdamW (whose in-place update does not bump `Parameter._version` -- a version-keyed cache of the images trained on
+    stale weights) must give the same losses as the same steps on the library GEMMs."""
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    from rqhip import linear
+
+    def run(split):
+        before = linear.use_split_gemms(split)
+        try:
+            torch.manual_seed(0)
+            m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
+                      n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.STE).cuda().train()
+            with torch.no_grad():
+                for l, layer in enumerate(m.layers):
+                    layer.embedding.weight.copy_(torch.randn(256, 32, device="cuda") * (0.05 / (l + 1)))
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=True)
+            x = torch.nn.functional.normalize(torch.randn(8192, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(1)), dim=-1)
+            losses = []
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                out = m(SeqBatch(None, None, None, x, None, None), 0.2)
+                out.loss.backward()
+                opt.step()
+                losses.append(float(out.reconstruction_loss))
+            return losses
+        finally:
+            linear.use_split_gemms(before)
+
+    a, b = run(True), run(False)
+    assert a[0] != a[-1]                                   # the model moved
+    for la, lb in zip(a, b):
+        assert abs(la - lb) <= 2e-5 * abs(lb), (a, b)
