@@ -7,9 +7,11 @@ from torch import Tensor
 from . import ops
 
 # ---- the large activation GEMMs on the bf16 matrix cores (csrc/gemm_split.hip) ------------------------------------------
-# Measured at 100 000 rows against the tuned library fp32 GEMM of the same layer (tools/bench_gemm_split.py):
-# every supported data gradient and every supported forward but the first encoder layer's (768 -> 512 with the ReLU
-# epilogue: 470 vs 445-489 us, a tie) is faster; small batches are launch-bound and stay with the library.
+# Measured at 100 000 rows against the tuned library fp32 GEMM of the same layer (tools/bench_gemm_split.py, and in the
+# step: profiles/r03_bench_kernel_stats_summary.txt): every supported forward and data gradient is faster -- the first
+# encoder layer's forward (768 -> 512 with the ReLU in the hipBLASLt epilogue) was a tie in isolation (456 vs 445-489 us)
+# but takes 626 us inside the step, where the chip runs at the clocks the other matrix kernels leave it.  Small batches
+# are launch-bound and stay with the library.
 _SPLIT_MIN_ROWS = 4096
 _SPLIT_GEMMS = True
 
