@@ -24,6 +24,13 @@ def use_split_gemms(on: bool = True) -> bool:
     return before
 
 
+def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool = False) -> bool:
+    """Does this GEMM (x [M, n_red] against a weight image of n_cols columns) take the bf16-split kernel?"""
+    del forward_relu   # (round 3 excluded the first encoder layer's forward here; see the note above)
+    return bool(_SPLIT_GEMMS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                and x.shape[0] >= _SPLIT_MIN_ROWS and x.is_contiguous() and ops.gemm_split_supported(n_cols, n_red))
+
+
 def planes(w: Tensor, transpose: bool) -> Tensor:
     """The bf16-piece image of `w` (or of its transpose) for csrc/gemm_split.hip, rebuilt at EVERY use (one 6 us kernel).
     A first version cached it per `w._version` -- and trained on stale weights: the fused AdamW update (and any
@@ -38,8 +45,6 @@ def input_grad(g: Tensor, w: Tensor) -> Tensor:
     if split_ok(g, w.shape[1], w.shape[0], False):
         return ops.gemm_split(g, planes(w, True), w.shape[1])
     return g.mm(w)
-
-
 
 
 def forward(x: Tensor, w: Tensor, relu: bool, zero_bias: Tensor = None) -> Tensor:
