@@ -29,8 +29,9 @@ for f in $(find "$OUT/stats" -name "*kernel_trace.csv"); do
     python - "$f" "$OUT/rq_forward_dispatches.json" <<'PY'
 import csv, json, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rq_forward_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [{"kernel": r["Kernel_Name"][:80], "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-      "grid": int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)} for r in rows]
+      "start_us": int(r["Start_Timestamp"]) / 1e3, "grid": int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)} for r in rows]
 json.dump(d, open(sys.argv[2], "w"))
 PY
 done

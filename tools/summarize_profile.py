@@ -83,6 +83,33 @@ if fwk:
 with open(os.path.join(DST, f"{TAG}_pmc_traffic_{cfg_name}.json"), "w") as f:
     json.dump(pmc, f, indent=1)
     f.write("\n")
+# per-dispatch durations of the forward kernel: launches INSIDE training steps (milliseconds apart) vs back-to-back ones
+disp = os.path.join(SRC, "rq_forward_dispatches.json")
+if os.path.exists(disp):
+    import statistics
+    alld = json.load(open(disp))
+    names = sorted({r["kernel"] for r in alld}, key=lambda n: -sum(r["kernel"] == n for r in alld))
+    d = [r for r in alld if r["kernel"] == names[0]]          # the training step's forward kernel (most launches)
+    in_step, back_to_back = [], []
+    for prev, cur in zip([None] + d[:-1], d):
+        gap = cur["start_us"] - prev["start_us"] if prev and "start_us" in cur else 1e9
+        (back_to_back if gap < 1000.0 else in_step).append(cur["us"])
+    out = {"kernel": names[0], "source": "rocprofv3 --kernel-trace of the bench run",
+           "in_step": {"launches": len(in_step), "median_us": statistics.median(in_step) if in_step else None,
+                       "min_us": min(in_step) if in_step else None, "max_us": max(in_step) if in_step else None,
+                       "note": "first launch of a burst: preceded by other kernels of the training step (or by the warm-up)"},
+           "back_to_back": {"launches": len(back_to_back),
+                            "median_us": statistics.median(back_to_back) if back_to_back else None},
+           "hip_event_mean_us_on_the_bench_line_of_the_same_run": None}
+    try:
+        br = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        out["hip_event_mean_us_on_the_bench_line_of_the_same_run"] = br["roofline"]["launch_ms_mean"] * 1e3
+    except Exception:  # noqa: BLE001
+        pass
+    with open(os.path.join(DST, f"{PRE}_rq_forward_dispatches.json"), "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+    print("forward kernel dispatches:", json.dumps(out))
 fw = [k for k in pmc["kernels"] if "rq_forward_kernel" in k]
 for k in fw:
     v = pmc["kernels"][k]
