@@ -85,6 +85,9 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
+    ap.add_argument("--mlp", choices=("split", "library"), default="split",
+                    help="A/B only: `library` runs the MLP GEMMs as library fp32 GEMMs and the weight gradients on the "
+                         "fp32-MFMA kernel (round 2's step); the product default is `split` (csrc/gemm_split.hip, wgrad_split.hip)")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="if the K timed steps took less, also time a longer region and report it as `long_run`")
     return ap.parse_args()
@@ -270,7 +273,13 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    tuned = tuning.enable_tuned_gemms()   # fp32 library-GEMM selections for the MLPs (rqhip/tuning.py)
+    tuned = tuning.enable_tuned_gemms()   # fp32 library-GEMM selections for the MLP layers the split kernels do not tile
+    if args.mlp == "library":             # A/B arm (tools/profile_mlp_ab.sh): round 2's step
+        from modules import encoder as _enc
+        from rqhip import linear as _lin
+        _lin.use_split_gemms(False)
+        _wg = ops.linear_wgrad
+        _enc.ops.linear_wgrad = ops.linear_wgrad = lambda *a, **k: _wg(*a, **dict(k, exact_fp32=True))
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)
     for lo in range(0, B, 250_000):        # generated in host chunks: 1.25 M x 768 fp32 is 3.8 GB
@@ -482,7 +491,12 @@ def main():
                           "tokenize_items_per_s": round(Bm / tok_ms * 1e3, 1), "tokenize_ms": round(tok_ms, 4),
                           "note": "per GPU; S-rq = HIP quantisation stack fwd+bwd on 32-d latents, tokenize = "
                                   "get_semantic_ids (encoder GEMMs + HIP RQ, eval)"},
-            "mlp_gemms": "PyTorch-ROCm fp32 (matmul precision highest), TunableOp selections " + ("loaded" if tuned else "off"),
+            "mlp_gemms": ("csrc/gemm_split.hip + csrc/wgrad_split.hip: every fp32 operand as three exact bf16 pieces, six piece "
+                          "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation (error against fp64 <= the library fp32 "
+                          "GEMM's on the same inputs: tests/test_gpu_gemm_split.py, test_gpu_wgrad.py); layers narrower "
+                          "than 256 columns: " if args.mlp == "split" else "A/B arm --mlp library: ")
+                         + "PyTorch-ROCm fp32 GEMMs (matmul precision highest), TunableOp selections "
+                         + ("loaded" if tuned else "off"),
             "final_loss": round(final_loss, 6), "p_unique_ids": round(p_unique, 6),
             "librqhip_sha256": lib_sha,
         }

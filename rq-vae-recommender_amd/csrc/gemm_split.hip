@@ -33,6 +33,13 @@ typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGsCols = 256, kGsThreads = 512, kGsK = 16;   // rows per tile: 64 TA (256 or 64)
+#ifndef GS_XCD_GROUP
+#define GS_XCD_GROUP 0
+#endif
+#ifndef GS_PROBE   // developer builds (tools/ab_build.sh): phase-skipping bit mask, results are WRONG with any bit set --
+#define GS_PROBE 0 // 1: no split arithmetic, 2: no LDS writes at all, 4: operand reads once per tile, 16: no global loads (32: none of A, 64: none of the weight image, 128: A always from the first two stages = cache hits,
+                   // 256: a tile's A stage is one contiguous 16 KB block (wrong data, same bytes), 512: no result stores)
+#endif
 
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
     const gs_bf16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_bf16x2);
@@ -97,7 +104,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         a_live[q] = arow + 128 * q < ROWS;
         const long long arow_g = m0 + arow + 128 * q;
         arow_ok[q] = a_live[q] && arow_g < p.M;
-        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
+        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * ((GS_PROBE & 256) ? 16 : p.R) + 4 * akq;
     }
 
     gs_f32x16 acc[TA][2];
@@ -108,29 +115,41 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
-    gs_f32x4 ra[AQ];
+    gs_f32x4 ra0[AQ], ra1[AQ];   // rows of A: two stages in flight (requested two iterations before they are split)
     gs_u32x4 rb[3];
-    auto fetch = [&](int stage) {
+    auto fetchA = [&](int stage, gs_f32x4 *dst) {
+        if ((GS_PROBE & 16) && stage > 1) return;
 #pragma unroll
         for (int q = 0; q < AQ; ++q)
-            ra[q] = arow_ok[q] ? *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK) : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!((GS_PROBE & 32) && stage > 1))
+                dst[q] = arow_ok[q] ? *reinterpret_cast<const gs_f32x4 *>(asrc[q] + ((GS_PROBE & 128) ? (stage & 1) : stage) * ((GS_PROBE & 256) ? 256 * 1024 : kGsK))
+                                    : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto fetchB = [&](int stage) {
+        if ((GS_PROBE & 16) && stage > 1) return;
         // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
         // (piece, half) rows: element e = tid + 512 q  ->  (ph = e >> 8, col = e & 255)
         const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int e = tid + kGsThreads * q;
-            rb[q] = img[(size_t)(e >> 8) * p.Nc + (e & 255)];
+            if (!((GS_PROBE & 64) && stage > 1)) rb[q] = img[(size_t)(e >> 8) * p.Nc + (e & 255)];
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const gs_f32x4 *ra) {
+        if ((GS_PROBE & 2) && buf) return;
         unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
             if (!a_live[q]) continue;
             unsigned h01, m01, l01, h23, m23, l23;
+            if (GS_PROBE & 1) {
+                h01 = __builtin_bit_cast(unsigned, ra[q].x); m01 = __builtin_bit_cast(unsigned, ra[q].y); l01 = h01 ^ m01;
+                h23 = __builtin_bit_cast(unsigned, ra[q].z); m23 = __builtin_bit_cast(unsigned, ra[q].w); l23 = h23 ^ m23;
+            } else {
             gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
             gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
+            }
             // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
             unsigned *d = dA + (((akq >> 1) * ROWS) + arow + 128 * q) * 4 + 2 * (akq & 1);
             *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * ROWS * 4) = gs_u32x2{h01, h23};
@@ -146,57 +165,84 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     auto multiply = [&](int buf) {
         const gs_bf16x8 *aA = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB));
         const gs_bf16x8 *bB = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB) + PA);
-        gs_bf16x8 b[2][3];
+        // column half outer, row block inner: 12 + 12 operand registers live (the row blocks are read once per column half:
+        // 30 instead of 18 LDS reads per stage, which the LDS has room for -- tools/gemm_probe.py, GS_PROBE 4)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+            gs_bf16x8 b[3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b[u][pc] = bB[(pc * 2 + h) * kGsCols + wn * 64 + 32 * u + il];
+            for (int pc = 0; pc < 3; ++pc)
+                b[pc] = bB[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * kGsCols + wn * 64 + ((GS_PROBE & 4) ? 0 : 32 * u) + il];
 #pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            gs_bf16x8 a[3];
+            for (int t = 0; t < TA; ++t) {
+                gs_bf16x8 a[3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * ROWS + wm * 32 * TA + 32 * t + il];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
+                for (int pc = 0; pc < 3; ++pc)
+                    a[pc] = aA[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * ROWS + wm * 32 * TA + ((GS_PROBE & 4) ? 0 : 32 * t) + il];
                 gs_f32x16 c16 = acc[t][u];
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][1], c16, 0, 0, 0);   // m m (smallest first)
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[u][0], c16, 0, 0, 0);   // l h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][2], c16, 0, 0, 0);   // h l
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[u][0], c16, 0, 0, 0);   // m h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][1], c16, 0, 0, 0);   // h m
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[u][0], c16, 0, 0, 0);   // h h
+                // the weight columns take the instruction's ROW role: the accumulator is the tile transposed, a lane holds
+                // four consecutive columns of one output row per register quad -> 16-byte result stores
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[1], c16, 0, 0, 0);   // m m (smallest first)
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[2], c16, 0, 0, 0);   // l h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], a[0], c16, 0, 0, 0);   // h l
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], c16, 0, 0, 0);   // m h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], c16, 0, 0, 0);   // h m
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], c16, 0, 0, 0);   // h h
                 acc[t][u] = c16;
             }
         }
     };
 
-    fetch(0);
-    stash(0);
-    if (n_stage > 1) fetch(1);
+    // A rows are requested TWO iterations before they are split (scattered 64-byte pieces of 256 rows: their latency is
+    // longer than one iteration's matrix work -- tools/gemm_probe.py: the kernel ran 17 % faster without them, 10 % with
+    // cache hits), the weight image (L2-resident) one iteration before.
+    fetchA(0, ra0);
+    fetchB(0);
+    if (n_stage > 1) fetchA(1, ra1);
+    stash(0, ra0);
+    if (n_stage > 2) fetchA(2, ra0);
+    if (n_stage > 1) fetchB(1);
     __syncthreads();
-    for (int c = 0; c < n_stage; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < n_stage) stash(buf ^ 1);      // rows of stage c + 1, requested a whole iteration ago
-        if (c + 2 < n_stage) fetch(c + 2);
-        multiply(buf);
+    const int n_pair = n_stage & ~1;
+    for (int c = 0; c < n_pair; c += 2) {
+        stash(1, ra1);                             // stage c + 1
+        if (c + 3 < n_stage) fetchA(c + 3, ra1);
+        if (c + 2 < n_stage) fetchB(c + 2);
+        multiply(0);
+        __syncthreads();
+        if (c + 2 < n_stage) stash(0, ra0);       // stage c + 2
+        if (c + 4 < n_stage) fetchA(c + 4, ra0);
+        if (c + 3 < n_stage) fetchB(c + 3);
+        multiply(1);
+        __syncthreads();
+    }
+    if (n_stage & 1) {                             // the last stage of an odd count lies in buffer 0
+        multiply(0);
         __syncthreads();
     }
 
-    // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + 8 (r >> 2) + 4 h + (r & 3),  column = n0 + 64 wn + 32 u + il
+    // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
+    // 32 16-byte stores per lane and tile (the untransposed accumulator needed 128 dword stores; same time: what the result
+    // costs is its write traffic, 7-11 % of the kernel while every CU reaches its epilogue in the same phase of a round --
+    // tools/gemm_probe.py, GS_PROBE 512)
 #pragma unroll
-    for (int t = 0; t < TA; ++t)
+    for (int t = 0; t < TA; ++t) {
+        const long long row = m0 + 32 * TA * wm + 32 * t + il;
+        if (row < p.M && !(GS_PROBE & 512)) {
+            float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long row = m0 + 32 * TA * wm + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (row < p.M) {
-                float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + il;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float v = acc[t][u][r];
-                    dst[32 * u] = RELU ? (v < 0.0f ? 0.0f : v) : v;   // (a NaN stays a NaN, as torch.relu)
+                for (int g = 0; g < 4; ++g) {
+                    gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+                    if (RELU) {       // (a NaN stays a NaN, as torch.relu)
+                        v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
+                        v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+                    }
+                    *reinterpret_cast<gs_f32x4 *>(dst + 32 * u + 8 * g) = v;
                 }
-            }
         }
+    }
 }
 
 template <bool RELU>
@@ -223,7 +269,12 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
         // round is cut into 64-row tiles so that it spreads over all CUs instead of giving a few of them a fourth big
         // tile (100 000 x 512: 782 big tiles on 256 CUs were 4 tile times for 3.05 rounds of work).
         if (tile < p.n_big) {
-            const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+            int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+#if GS_XCD_GROUP
+            // tickets t, t + 8, .. (the same XCD while tickets are taken in workgroup order) share one row tile's A strip
+            const unsigned grp = 8u * (unsigned)p.n_col_tiles, g = tile / grp, in = tile % grp;
+            if ((g + 1) * grp <= p.n_big) { rt = (int)(g * 8u + (in & 7u)); ct = (int)(in >> 3); }
+#endif
             gs_tile<RELU, 4>(p, sbuf, (long long)rt * 256, ct * kGsCols);
         } else {
             const unsigned st = tile - p.n_big;

@@ -1,62 +1,33 @@
 #!/usr/bin/env python3
-"""Developer probe: how fast are the PyTorch-ROCm fp32 GEMMs of the RQ-VAE MLPs (fwd + bwd) under the BLAS
-backends / TunableOp, at the bench shapes (B = 100 000)?"""
+"""Times gemm_split (768 -> 512 with ReLU and 512 -> 768 plain, 100 000 rows) in the library build given as argv[1]
+(default: the product build); one process per build (tools/ab_build.sh makes the phase-skipping variants)."""
 import os
 import sys
-import time
 
 import torch
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-dims = [768, 512, 256, 128, 32]
-torch.manual_seed(0)
-dev = "cuda"
-x = torch.randn(B, 768, device=dev)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")]
+from rqhip import _lib  # noqa: E402
 
+if len(sys.argv) > 1:
+    _lib.load(os.path.join(ROOT, sys.argv[1]))
+from rqhip import ops  # noqa: E402
 
-def mlp(ds):
-    layers = []
-    for i, (a, b) in enumerate(zip(ds[:-1], ds[1:])):
-        layers.append(torch.nn.Linear(a, b, bias=False))
-        if i != len(ds) - 2:
-            layers.append(torch.nn.ReLU())
-    return torch.nn.Sequential(*layers).to(dev)
-
-
-enc, dec = mlp(dims), mlp(dims[::-1])
-
-
-def step():
-    for p in list(enc.parameters()) + list(dec.parameters()):
-        p.grad = None
-    z = enc(x)
-    xh = dec(z)
-    ((xh - x) ** 2).sum(-1).mean().backward()
-
-
-def bench(tag):
-    for _ in range(3):
-        step()
+M = 100_000
+res = []
+for N, K, relu in ((512, 768, True), (768, 512, False), (256, 512, True)):
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / K ** 0.5
+    p = ops.weight_planes(w)
+    for _ in range(5):
+        ops.gemm_split(x, p, N, relu=relu)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 10
-    for _ in range(n):
-        step()
+    a.record()
+    for _ in range(30):
+        ops.gemm_split(x, p, N, relu=relu)
+    b.record()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    fl = 3 * 2 * 2 * sum(a * b for a, b in zip(dims[:-1], dims[1:])) * B
-    print(f"{tag:40s} {ms:8.3f} ms/step  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
-
-
-torch.set_float32_matmul_precision("high")
-for lib in ("default", "hipblaslt", "cublas"):
-    try:
-        if lib != "default":
-            torch.backends.cuda.preferred_blas_library(lib)
-        bench(f"blas={lib} precision=high")
-    except Exception as e:  # noqa
-        print(lib, "failed:", e)
-torch.set_float32_matmul_precision("highest")
-bench("blas=last precision=highest")
-if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1":
-    bench("tunableop (after tuning)")
+    res.append(f"{K}->{N}: {a.elapsed_time(b) / 30 * 1e3:7.1f} us")
+print(f"{(sys.argv[1] if len(sys.argv) > 1 else 'product'):36s}", "  ".join(res), flush=True)
