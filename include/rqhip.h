@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 300 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex */
+#define RQHIP_VERSION 301 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon */
 
 #define RQHIP_OK 0
 #define RQHIP_EARG (-1)         /* bad pointer / size / mode */
@@ -324,6 +324,15 @@ int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void 
                         rqhip_stream_t stream);
 int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
                      rqhip_stream_t stream);
+/* The last decoder layer fused with ReconstructionLoss (reference modules/rqvae.py:146,152 + modules/loss.py:5-10):
+ * x_hat = A . image^T is never stored; loss_rows[m] = sum_n (x_hat - X)^2 and G = (2 (x_hat - X)) * row_scale, the gradient
+ * `(reconstruction + quantize_loss).mean().backward()` sends back when row_scale = loss scale / B.
+ * rqhip_recon_rescale_rows is its backward fix-up: rows of g_out that are not row_scale (bit compare) get G * (g / row_scale).
+ * workspace: rqhip_gemm_split_recon_workspace_bytes(M, Nc) bytes (per-column-tile row sums, summed in tile order). */
+size_t rqhip_gemm_split_recon_workspace_bytes(int64_t M, int Nc);
+int rqhip_gemm_split_recon(const float *A, int64_t M, int R, const void *planes, int Nc, const float *X, float row_scale,
+                           float *G, float *loss_rows, void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
+int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_scale, float *g_spec, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every

@@ -83,10 +83,16 @@ struct GemmSplitParams {
     unsigned n_big, n_tiles;
     int rt_big;
     unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
+    // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
+    // rowsum[ct][m] the squared error of row m over column tile ct
+    const float *X;
+    float *rowsum;
+    float row_scale;
 };
 
 // one output tile of 64 TA rows x 256 columns: 8 waves of (32 TA) x 64
-template <bool RELU, int TA>
+// EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss (see GemmSplitParams)
+template <int EPI, int TA>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
     constexpr int ROWS = 64 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
     constexpr int PA = 3 * 2 * ROWS * 4, PB = 3 * 2 * kGsCols * 4;                 // dwords per stage image
@@ -225,27 +231,54 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // 32 16-byte stores per lane and tile (the untransposed accumulator needed 128 dword stores; same time: what the result
     // costs is its write traffic, 7-11 % of the kernel while every CU reaches its epilogue in the same phase of a round --
     // tools/gemm_probe.py, GS_PROBE 512)
+    float rowsq[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const long long row = m0 + 32 * TA * wm + 32 * t + il;
+        rowsq[t] = 0.0f;
         if (row < p.M && !(GS_PROBE & 512)) {
             float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + 4 * h;
+            const float *xs = EPI == 2 ? p.X + (size_t)row * p.Nc + n0 + 64 * wn + 4 * h : nullptr;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
-                    if (RELU) {       // (a NaN stays a NaN, as torch.relu)
+                    if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
                         v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
                         v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+                    }
+                    if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
+                        const gs_f32x4 xv = *reinterpret_cast<const gs_f32x4 *>(xs + 32 * u + 8 * g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = v[j] - xv[j];
+                            rowsq[t] = rowsq[t] + d * d;
+                            v[j] = (2.0f * d) * p.row_scale;
+                        }
                     }
                     *reinterpret_cast<gs_f32x4 *>(dst + 32 * u + 8 * g) = v;
                 }
         }
     }
+    if (EPI == 2) {
+        // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
+        // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
+        float *red = reinterpret_cast<float *>(sbuf);          // [4][ROWS]
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
+            if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
+        }
+        __syncthreads();
+        if (tid < ROWS && m0 + tid < p.M)
+            p.rowsum[(size_t)(n0 / kGsCols) * p.M + m0 + tid] =
+                ((red[tid] + red[ROWS + tid]) + red[2 * ROWS + tid]) + red[3 * ROWS + tid];
+        // (the persistent loop's barrier at its top keeps the next tile's staging off `red`)
+    }
 }
 
-template <bool RELU>
+template <int EPI>
 __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
@@ -275,13 +308,23 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
             const unsigned grp = 8u * (unsigned)p.n_col_tiles, g = tile / grp, in = tile % grp;
             if ((g + 1) * grp <= p.n_big) { rt = (int)(g * 8u + (in & 7u)); ct = (int)(in >> 3); }
 #endif
-            gs_tile<RELU, 4>(p, sbuf, (long long)rt * 256, ct * kGsCols);
+            gs_tile<EPI, 4>(p, sbuf, (long long)rt * 256, ct * kGsCols);
         } else {
             const unsigned st = tile - p.n_big;
             const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
-            gs_tile<RELU, 1>(p, sbuf, (long long)p.rt_big * 256 + (long long)rt * 64, ct * kGsCols);
+            gs_tile<EPI, 1>(p, sbuf, (long long)p.rt_big * 256 + (long long)rt * 64, ct * kGsCols);
         }
     }
+}
+
+// reconstruction loss of a row = its column tiles' sums in order
+__global__ __launch_bounds__(256) void recon_rows_finish_kernel(const float *__restrict__ rowsum, int nct, long long M,
+                                                                float *__restrict__ out) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = rowsum[m];
+    for (int c = 1; c < nct; ++c) s = s + rowsum[(size_t)c * M + m];
+    out[m] = s;
 }
 
 }  // namespace rqhip
@@ -311,16 +354,38 @@ extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int trans
     return RQHIP_OK;
 }
 
-static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C, int flags_tile,
-                             rqhip_stream_t stream);
+static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int epi, float *C, int flags_tile,
+                             const float *X, float row_scale, float *rowsum, rqhip_stream_t stream);
 
 extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
                                 rqhip_stream_t stream) {
-    return gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, (relu >> 8) & 0xfff, stream);   // (bits 8.. of `relu`: tile rows, A/B)
+    return gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, (relu >> 8) & 0xfff, nullptr, 0.0f, nullptr,
+                             stream);   // (bits 8.. of `relu`: tile rows, A/B)
 }
 
-static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C, int flags_tile,
-                             rqhip_stream_t stream) {
+extern "C" size_t rqhip_gemm_split_recon_workspace_bytes(int64_t M, int Nc) {
+    return (M > 0 && Nc > 0 && Nc % kGsCols == 0) ? (size_t)(Nc / kGsCols) * (size_t)M * sizeof(float) : 0;
+}
+
+extern "C" int rqhip_gemm_split_recon(const float *A, int64_t M, int R, const void *planes, int Nc, const float *X,
+                                      float row_scale, float *G, float *loss_rows, void *workspace, size_t workspace_bytes,
+                                      rqhip_stream_t stream) {
+    if (M > 0 && (!X || !G || !loss_rows || !workspace || workspace_bytes < rqhip_gemm_split_recon_workspace_bytes(M, Nc) ||
+                  (reinterpret_cast<uintptr_t>(X) & 15u) != 0)) {
+        set_error("gemm_split_recon: bad arguments (X, G, loss_rows, workspace of rqhip_gemm_split_recon_workspace_bytes)");
+        return RQHIP_EARG;
+    }
+    const int rc = gemm_split_launch(A, M, R, planes, Nc, 2, G, 0, X, row_scale, reinterpret_cast<float *>(workspace), stream);
+    if (rc != RQHIP_OK || M == 0) return rc;
+    hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(workspace), Nc / kGsCols,
+                       (long long)M, loss_rows);
+    RQ_CHECK_LAUNCH("recon_rows_finish_kernel");
+    return RQHIP_OK;
+}
+
+static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int epi, float *C, int flags_tile,
+                             const float *X, float row_scale, float *rowsum, rqhip_stream_t stream) {
     if (M < 0 || !planes || (M > 0 && (!A || !C)) || !rqhip_gemm_split_supported(Nc, R)) {
         set_error("gemm_split: bad arguments or unsupported shape (Nc = %d, R = %d)", Nc, R);
         return RQHIP_EARG;
@@ -334,6 +399,7 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     GemmSplitParams p;
     p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
+    p.X = X; p.rowsum = rowsum; p.row_scale = row_scale;
     const int cus = cu_count();
     p.n_col_tiles = Nc / kGsCols;
     // whole rounds of 256-row tiles, the remainder as 64-row tiles (see the kernel); flags_tile (tools only): 256 = big
@@ -365,5 +431,5 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
         RQ_CHECK_LAUNCH("gemm_split_kernel");
         return 0;
     };
-    return relu ? go(gemm_split_kernel<true>) : go(gemm_split_kernel<false>);
+    return epi == 2 ? go(gemm_split_kernel<2>) : epi == 1 ? go(gemm_split_kernel<1>) : go(gemm_split_kernel<0>);
 }

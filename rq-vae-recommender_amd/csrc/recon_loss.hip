@@ -134,6 +134,26 @@ __global__ __launch_bounds__(256) void recon_bwd_spec_kernel(const float *__rest
     }
 }
 
+// Backward of the reconstruction loss FUSED into the last decoder GEMM (csrc/gemm_split.hip, EPI 2): x_hat was never
+// stored, so a row whose upstream gradient is not row_scale is rescaled, g_spec * (g / row_scale), instead of recomputed
+// (one more rounding than (2 d) g; rows that match -- every row of a training step -- are not touched).
+__global__ __launch_bounds__(256) void recon_rescale_rows_kernel(const float *__restrict__ g, long long B, int N,
+                                                                 float row_scale, float *__restrict__ gs) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (long long row = gw; row < B; row += waves) {
+        const float gr = g[row];
+        if (__float_as_uint(gr) == __float_as_uint(row_scale)) continue;
+        const float f = gr / row_scale;
+        for (int i = lane; i < N / 4; i += 64) {
+            f32x4 o = *reinterpret_cast<const f32x4 *>(gs + row * (long long)N + 4 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = o[j] * f;
+            *reinterpret_cast<f32x4 *>(gs + row * (long long)N + 4 * i) = o;
+        }
+    }
+}
+
 // The three batch means RqVae.forward returns (modules/rqvae.py:154,171-172): mean(recon + quant), mean(recon),
 // mean(quant) -- one launch instead of an elementwise add and three two-stage reductions (3 x 16.6 us at 100 000 rows).
 // One workgroup; thread t adds the float4 groups t, t + 1024, ... in order, then a fixed LDS tree: deterministic.
@@ -267,6 +287,20 @@ extern "C" int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat
     hipLaunchKernelGGL(recon_bwd_spec_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        x_hat, (long long)ld_hat, x, (long long)ld_x, g_out, (long long)B, N, row_scale, g_spec);
     RQ_CHECK_LAUNCH("recon_bwd_spec_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
+                                        rqhip_stream_t stream) {
+    if (B < 0 || N < 4 || (N % 4) != 0 || (B > 0 && (!g_out || !g_spec)) || (reinterpret_cast<uintptr_t>(g_spec) & 15u) != 0 ||
+        !(row_scale != 0.0f)) {
+        set_error("recon_rescale_rows: bad arguments (N a multiple of 4, 16-byte aligned g_spec, non-zero row_scale)");
+        return RQHIP_EARG;
+    }
+    if (B == 0) return RQHIP_OK;
+    hipLaunchKernelGGL(recon_rescale_rows_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       g_out, (long long)B, N, row_scale, g_spec);
+    RQ_CHECK_LAUNCH("recon_rescale_rows_kernel");
     return RQHIP_OK;
 }
 

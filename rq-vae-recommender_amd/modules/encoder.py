@@ -90,6 +90,45 @@ class _LinearPlain(torch.autograd.Function):
         return gx, gw
 
 
+class _LinearRecon(torch.autograd.Function):
+    """reconstruction_loss(h @ w.T, x) per row (reference modules/rqvae.py:146,152 + modules/loss.py:5-10) with the LAST
+    decoder layer and the loss in ONE kernel (csrc/gemm_split.hip, epilogue 2): x_hat never reaches memory; the epilogue
+    reads x, sums the squared error of its row and writes the gradient the step is going to ask for, (2 (x_hat - x)) * s / B
+    (s: rqhip.autograd.loss_scale).  Backward compares the upstream rows with s / B on the device and rescales the rows
+    that differ (csrc/recon_loss.hip: recon_rescale_rows_kernel), then forms the two GEMM gradients from that matrix as
+    _LinearPlain does.  A second backward through a retained graph recomputes x_hat with the library."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, w: Tensor, x: Tensor) -> Tensor:
+        from rqhip import autograd as _ag
+        one = torch.tensor(1.0, dtype=torch.float32)   # fp32 (loss scale) * fp32 (1 / B), as ReconLossFunction
+        ctx.row_scale = float(torch.tensor(_ag._LOSS_SCALE, dtype=torch.float32) * (one / x.shape[0]))
+        g, rows = ops.gemm_split_recon(h, _lin.planes(w, False), w.shape[0], x, ctx.row_scale)
+        ctx.save_for_backward(h, w, x, g)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g_out: Tensor):
+        h, w, x, g = ctx.saved_tensors
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_out = g_out.contiguous()
+        if not getattr(ctx, "consumed", False):
+            ctx.consumed = True
+            g = ops.recon_rescale_rows(g, g_out, ctx.row_scale)        # in place; a no-op in a training step
+        else:
+            g = ops.recon_loss_backward(h.mm(w.t()), x, g_out, True, False)[0]
+        gw = None
+        if need_w:
+            sink = _grad_sink(w)
+            if _hip_wgrad_ok(g, w):
+                gw = ops.linear_wgrad(g, None, h, out=sink)[0]
+            else:
+                gw = torch.mm(g.t(), h, out=sink) if sink is not None else g.t().mm(h)
+            gw = _adopt(gw, sink)
+        gh = _lin.input_grad(g, w) if need_h else None
+        return gh, gw, None
+
+
 class MLP(nn.Module):
     def __init__(self, input_dim: int, hidden_dims: List[int], out_dim: int, dropout: float = 0.0,
                  normalize: bool = False) -> None:
@@ -120,7 +159,9 @@ class MLP(nn.Module):
         assert x.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {x.shape[-1]}"
         if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
             return self.mlp(x)
-        layers = list(self.mlp)
+        return self._run(x, list(self.mlp))
+
+    def _run(self, x: Tensor, layers) -> Tensor:
         as_ops = torch_ops.enabled()   # registered torch.library operators instead of the autograd Functions
         i = 0
         while i < len(layers):
@@ -137,3 +178,19 @@ class MLP(nn.Module):
                 x = layer(x)
                 i += 1
         return x
+
+    def reconstruction_rows(self, z: Tensor, target: Tensor):
+        """ReconstructionLoss(self(z), target) per row with the last layer and the loss fused (`_LinearRecon`), or None
+        when that kernel does not apply here (the caller then composes the two, as the reference does)."""
+        layers = list(self.mlp)
+        last = layers[-2] if len(layers) >= 2 else None
+        if not (isinstance(last, nn.Linear) and last.bias is None and isinstance(layers[-1], nn.Identity)
+                and not torch_ops.enabled() and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32
+                and target.is_cuda and target.dtype == torch.float32 and not target.requires_grad
+                and tuple(target.shape) == (z.shape[0], last.out_features) and target.is_contiguous()
+                and target.data_ptr() % 16 == 0
+                and _lin.split_shape_ok(z.shape[0], last.out_features, last.in_features)):
+            return None
+        assert z.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {z.shape[-1]}"
+        hdn = self._run(z, layers[:-2])
+        return _LinearRecon.apply(hdn if hdn.is_contiguous() else hdn.contiguous(), last.weight, target)

@@ -172,12 +172,17 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         x = batch.x
         xin = x.to(next(self.encoder.parameters()).dtype)
         st = self._quantize_stack(self.encode(xin), gumbel_t, want_levels=False)
-        x_hat = self.decode(st.emb_sum)                                   # embs.sum(axis=-1), rqvae.py:146
         n = self.n_cat_feats
-        # rqvae.py:147-150: with n == 0 the `[..., :-0]` slice is EMPTY, so nothing is normalised
-        x_hat = torch.cat([l2norm(x_hat[..., :-n]), x_hat[..., -n:]], dim=-1) if n != 0 else x_hat
-        # (the kernels are fp32: a float64 / fp16 batch is compared in the model's dtype, as it was encoded)
-        reconstruction = self.reconstruction_loss(x_hat, x if x.dtype == x_hat.dtype else x.to(x_hat.dtype))
+        reconstruction = None
+        if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and type(self.decoder) is MLP and x.dim() == 2:
+            # large batches: the last decoder layer and the loss are one kernel, x_hat is never stored (modules/encoder.py)
+            reconstruction = self.decoder.reconstruction_rows(st.emb_sum, xin)
+        if reconstruction is None:
+            x_hat = self.decode(st.emb_sum)                               # embs.sum(axis=-1), rqvae.py:146
+            # rqvae.py:147-150: with n == 0 the `[..., :-0]` slice is EMPTY, so nothing is normalised
+            x_hat = torch.cat([l2norm(x_hat[..., :-n]), x_hat[..., -n:]], dim=-1) if n != 0 else x_hat
+            # (the kernels are fp32: a float64 / fp16 batch is compared in the model's dtype, as it was encoded)
+            reconstruction = self.reconstruction_loss(x_hat, x if x.dtype == x_hat.dtype else x.to(x_hat.dtype))
         rqvae_loss = st.loss
         if (reconstruction.dim() == 1 and reconstruction.is_cuda and reconstruction.dtype == torch.float32
                 and reconstruction.numel() > 0):   # (an empty batch keeps the reference's expression: three NaN means)

@@ -69,6 +69,9 @@ SIGNATURES = {
     "rqhip_weight_planes_bytes": (_sz, [_int, _int]),
     "rqhip_weight_planes": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp]),
     "rqhip_gemm_split": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp]),
+    "rqhip_gemm_split_recon_workspace_bytes": (_sz, [_i64, _int]),
+    "rqhip_gemm_split_recon": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_recon_rescale_rows": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),
 }

@@ -31,6 +31,11 @@ def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool = False) -> 
                 and x.shape[0] >= _SPLIT_MIN_ROWS and x.is_contiguous() and ops.gemm_split_supported(n_cols, n_red))
 
 
+def split_shape_ok(rows: int, n_cols: int, n_red: int) -> bool:
+    """`split_ok` for a contiguous fp32 ROCm operand of `rows` rows that does not exist yet."""
+    return bool(_SPLIT_GEMMS and rows >= _SPLIT_MIN_ROWS and ops.gemm_split_supported(n_cols, n_red))
+
+
 def planes(w: Tensor, transpose: bool) -> Tensor:
     """The bf16-piece image of `w` (or of its transpose) for csrc/gemm_split.hip, rebuilt at EVERY use (one 6 us kernel).
     A first version cached it per `w._version` -- and trained on stale weights: the fused AdamW update (and any

@@ -543,3 +543,34 @@ def gemm_split(a: Tensor, planes: Tensor, n_cols: int, relu: bool = False, tile_
                                           _stream()),
               "rqhip_gemm_split")
     return c
+
+
+def gemm_split_recon(a: Tensor, planes: Tensor, n_cols: int, x: Tensor, row_scale: float):
+    """The last decoder layer fused with the reconstruction loss (rqhip_gemm_split_recon): with x_hat = a . image^T (never
+    stored) returns (g, loss_rows): g [M, n_cols] = (2 (x_hat - x)) * row_scale and loss_rows [M] = sum (x_hat - x)^2."""
+    _need_gpu(a, planes, x)
+    a, x = _f32c(a, "a"), _f32c(x, "x")
+    M, R = a.shape
+    if tuple(x.shape) != (M, n_cols):
+        raise RqHipError(f"gemm_split_recon: x is {tuple(x.shape)}, expected {(M, n_cols)}")
+    with torch.cuda.device(a.device):
+        l = _lib.lib()
+        g = torch.empty((M, n_cols), dtype=torch.float32, device=a.device)
+        rows = torch.empty((M,), dtype=torch.float32, device=a.device)
+        nbytes = l.rqhip_gemm_split_recon_workspace_bytes(M, int(n_cols))
+        ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=a.device)
+        check(l.rqhip_gemm_split_recon(_ptr(a), M, R, _ptr(planes), int(n_cols), _ptr(x), float(row_scale), _ptr(g), _ptr(rows),
+                                       _ptr(ws), nbytes, _stream()), "rqhip_gemm_split_recon")
+    return g, rows
+
+
+def recon_rescale_rows(g_spec: Tensor, g_out: Tensor, row_scale: float) -> Tensor:
+    """In place: rows of g_spec whose upstream gradient g_out[row] is not row_scale (bit compare) are multiplied by
+    g_out[row] / row_scale (rqhip_recon_rescale_rows); returns g_spec."""
+    _need_gpu(g_spec, g_out)
+    g_out = _f32c(g_out, "g_out")
+    B, N = g_spec.shape
+    with torch.cuda.device(g_spec.device):
+        check(_lib.lib().rqhip_recon_rescale_rows(_ptr(g_out), B, N, float(row_scale), _ptr(g_spec), _stream()),
+              "rqhip_recon_rescale_rows")
+    return g_spec

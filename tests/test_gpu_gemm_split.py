@@ -54,3 +54,44 @@ def test_gemm_split_ragged_rows_and_scales(M):
     assert ((c.double() - ref).abs() <= bound).all(), float(((c.double() - ref).abs() / bound).max())
     with pytest.raises(ops.RqHipError):
         ops.weight_planes(torch.zeros(100, 768, device="cuda"))          # Nc not a multiple of 256
+
+
+@pytest.mark.parametrize("M", [100_000, 5003, 77])
+def test_gemm_split_recon_equals_gemm_then_loss(M):
+    """Epilogue 2 (last decoder layer + ReconstructionLoss, reference modules/rqvae.py:146,152 + loss.py:5-10): the gradient
+    matrix has the bits of gemm_split followed by recon_loss_forward_spec (same x_hat, same arithmetic per element); the row
+    sums run in another order (column tiles, waves) -> relative 1e-6."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(M)
+    h = torch.relu(torch.randn(M, 512, generator=g)).cuda()
+    w = (torch.randn(768, 512, generator=g) / 512 ** 0.5).cuda()
+    x = torch.nn.functional.normalize(torch.randn(M, 768, generator=g), dim=-1).cuda()
+    scale = 1.0 / M
+    planes = ops.weight_planes(w)
+    x_hat = ops.gemm_split(h, planes, 768)
+    rows_ref, g_ref = ops.recon_loss_forward_spec(x_hat, x, scale)
+    g_fused, rows = ops.gemm_split_recon(h, planes, 768, x, scale)
+    assert torch.equal(g_fused, g_ref)
+    assert torch.allclose(rows, rows_ref, rtol=1e-6, atol=0.0)
+    ref64 = ((h.double() @ w.double().t()) - x.double()).pow(2).sum(-1)
+    assert torch.allclose(rows.double(), ref64, rtol=2e-6)
+    g2, rows2 = ops.gemm_split_recon(h, planes, 768, x, scale)
+    assert torch.equal(g2, g_fused) and torch.equal(rows2, rows)          # run-to-run
+
+
+def test_recon_rescale_rows():
+    from rqhip import ops
+    g = torch.Generator().manual_seed(5)
+    B, N = 4099, 768
+    d2 = torch.randn(B, N, generator=g).cuda()
+    s = 1.0 / B
+    g_out = torch.full((B,), s, device="cuda")
+    odd = torch.arange(B, device="cuda") % 3 == 1
+    g_out[odd] = torch.rand(int(odd.sum()), device="cuda") * 3.0
+    spec = d2 * s
+    want = torch.where(odd[:, None], d2 * g_out[:, None], spec)
+    got = ops.recon_rescale_rows(spec.clone(), g_out, s)
+    assert torch.equal(got[~odd], spec[~odd])                            # matching rows are not touched
+    assert torch.allclose(got[odd], want[odd], rtol=4e-7, atol=0.0)      # (one extra rounding on the rescaled rows)
+    with pytest.raises(ops.RqHipError):
+        ops.recon_rescale_rows(spec, g_out, 0.0)

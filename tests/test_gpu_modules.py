@@ -499,3 +499,53 @@ def test_split_gemms_follow_the_optimizer():
     assert a[0] != a[-1]                                   # the model moved
     for la, lb in zip(a, b):
         assert abs(la - lb) <= 2e-5 * abs(lb), (a, b)
+
+
+def _rqvae_768(seed=0):
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    torch.manual_seed(seed)
+    m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=256, n_layers=3,
+              n_cat_features=0, codebook_kmeans_init=False, codebook_mode=QuantizeForwardMode.STE).cuda().train()
+    with torch.no_grad():
+        for l, layer in enumerate(m.layers):
+            layer.embedding.weight.copy_(torch.randn(256, 32, device="cuda") * (0.05 / (l + 1)))
+    return m
+
+
+@pytest.mark.parametrize("case", ["mean", "half_without_hint", "second_backward"])
+def test_fused_last_layer_and_reconstruction_loss_equals_the_composed_pair(case, monkeypatch):
+    """RqVae.forward at a large batch runs the last decoder layer and ReconstructionLoss as one kernel (x_hat is never
+    stored; modules/encoder.py:_LinearRecon).  Losses and every parameter gradient must equal the composed path (decoder,
+    then the loss kernel) -- also when the upstream row gradient is not the announced one (rows are rescaled) and on a
+    second backward through a retained graph (x_hat is recomputed)."""
+    from data.schemas import SeqBatch
+    from modules.encoder import MLP, _LinearRecon
+    x = torch.nn.functional.normalize(torch.randn(8192, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(3)), dim=-1)
+    calls = []
+    real_apply = _LinearRecon.apply
+
+    def run(fused):
+        m = _rqvae_768()
+        if not fused:
+            monkeypatch.setattr(MLP, "reconstruction_rows", lambda self, z, t: None)
+        else:
+            monkeypatch.undo()
+            monkeypatch.setattr(_LinearRecon, "apply", lambda *a: (calls.append(1), real_apply(*a))[1])
+        out = m(SeqBatch(None, None, None, x, None, None), 0.2)
+        loss = out.loss * 0.5 if case == "half_without_hint" else out.loss
+        if case == "second_backward":
+            loss.backward(retain_graph=True)
+            for p in m.parameters():
+                p.grad = None
+        loss.backward()
+        return out, {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    out_f, g_f = run(True)
+    out_c, g_c = run(False)
+    assert calls, "the fused kernel did not run"
+    assert abs(float(out_f.reconstruction_loss) - float(out_c.reconstruction_loss)) <= 2e-6 * abs(float(out_c.reconstruction_loss))
+    assert abs(float(out_f.loss) - float(out_c.loss)) <= 2e-6 * abs(float(out_c.loss))
+    for n in g_c:
+        scale = g_c[n].abs().max().item() + 1e-30
+        assert (g_f[n] - g_c[n]).abs().max().item() <= 2e-6 * scale, n
