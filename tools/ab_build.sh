@@ -1,6 +1,8 @@
 #!/bin/bash
 # Developer A/B builds: recompile ONE kernel file with extra -D flags and link it with the product objects into
-# tools/_ab/librqhip_<name>.so (git-ignored); select it at run time with RQHIP_SO=<path>.
+# tools/_ab/librqhip_<name>.so (git-ignored); a tool loads it with rqhip._lib.load(<path>) before its first op
+# (tools/gemm_probe.py <path>, GS_LIB=<path> tools/pmc_gemm.py).
+#   tools/ab_build.sh gsp32 gemm_split.hip -DGS_PROBE=32      # gemm_split without its A loads (bit mask in the file)
 #   tools/ab_build.sh probe rq_backward.hip -DRQ_BWD_PROBE     # phase-skipping switches, $RQ_BWD_PROBE bit mask:
 #        1 = no table read/add/write, 2 = no accumulation scan, 4 = no staging / barriers / accumulation,
 #        8 = no partial-table flush (results are NOT correct with any bit set)
