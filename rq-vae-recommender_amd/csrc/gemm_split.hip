@@ -36,6 +36,9 @@ constexpr int kGsCols = 256, kGsThreads = 512, kGsK = 16;   // rows per tile: 64
 #ifndef GS_XCD_GROUP
 #define GS_XCD_GROUP 0
 #endif
+#ifndef GS_PHASE   // 1 (developer A/B builds): the two waves of a SIMD out of phase -- measured 5-7 % SLOWER
+#define GS_PHASE 0
+#endif
 #ifndef GS_PROBE   // developer builds (tools/ab_build.sh): phase-skipping bit mask, results are WRONG with any bit set --
 #define GS_PROBE 0 // 1: no split arithmetic, 2: no LDS writes at all, 4: operand reads once per tile, 16: no global loads (32: none of A, 64: none of the weight image, 128: A always from the first two stages = cache hits,
                    // 256: a tile's A stage is one contiguous 16 KB block (wrong data, same bytes), 512: no result stores)
@@ -209,17 +212,37 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     if (n_stage > 2) fetchA(2, ra0);
     if (n_stage > 1) fetchB(1);
     __syncthreads();
+    // The two waves of a SIMD work OUT OF PHASE inside the barrier interval of a stage (as in csrc/wgrad_split.hip): the
+    // first half of the workgroup's waves (one per SIMD) splits / stages first and multiplies second, the other half
+    // multiplies first -- one wave of every SIMD is on the matrix cores while its partner is on the VALU / LDS / memory
+    // pipes.  With every wave in the same phase the split and the LDS writes of a stage were matrix-idle time.  Both
+    // phases write the buffer everybody left at the last barrier and read the other one.
+    const bool stage_first = GS_PHASE ? __builtin_amdgcn_readfirstlane(wave) < 4 : true;   // (scalar: a real branch)
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
-        stash(1, ra1);                             // stage c + 1
-        if (c + 3 < n_stage) fetchA(c + 3, ra1);
-        if (c + 2 < n_stage) fetchB(c + 2);
+        if (stage_first) {
+            stash(1, ra1);                             // stage c + 1
+            if (c + 3 < n_stage) fetchA(c + 3, ra1);
+            if (c + 2 < n_stage) fetchB(c + 2);
+        }
         multiply(0);
+        if (!stage_first) {
+            stash(1, ra1);
+            if (c + 3 < n_stage) fetchA(c + 3, ra1);
+            if (c + 2 < n_stage) fetchB(c + 2);
+        }
         __syncthreads();
-        if (c + 2 < n_stage) stash(0, ra0);       // stage c + 2
-        if (c + 4 < n_stage) fetchA(c + 4, ra0);
-        if (c + 3 < n_stage) fetchB(c + 3);
+        if (stage_first) {
+            if (c + 2 < n_stage) stash(0, ra0);       // stage c + 2
+            if (c + 4 < n_stage) fetchA(c + 4, ra0);
+            if (c + 3 < n_stage) fetchB(c + 3);
+        }
         multiply(1);
+        if (!stage_first) {
+            if (c + 2 < n_stage) stash(0, ra0);
+            if (c + 4 < n_stage) fetchA(c + 4, ra0);
+            if (c + 3 < n_stage) fetchB(c + 3);
+        }
         __syncthreads();
     }
     if (n_stage & 1) {                             // the last stage of an odd count lies in buffer 0

@@ -13,6 +13,10 @@ from rqhip import ops, tuning  # noqa: E402
 tuning.enable_tuned_gemms()
 torch.set_float32_matmul_precision("highest")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+if len(sys.argv) > 2:   # another build of librqhip.so (tools/ab_build.sh)
+    from rqhip import _lib
+    _lib.load(os.path.abspath(sys.argv[2]))
+    print(f"# library: {sys.argv[2]}")
 
 
 def timeit(fn, n=20):

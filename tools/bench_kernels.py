@@ -48,8 +48,9 @@ def fwd(reps, shapes=None):
                   f"{fl/ms/1e9:7.1f} TFLOP/s  {B/ms/1e3:9.1f} M rows/s", flush=True)
 
 
-def bwd(reps):
-    for B, D, K, L in [(100000, 32, 256, 3), (1048576, 32, 256, 3), (262144, 32, 1024, 4), (8192, 32, 256, 3)]:
+def bwd(reps, shapes=None):
+    for B, D, K, L in shapes or [(100000, 32, 256, 3), (1048576, 32, 256, 3), (262144, 32, 1024, 4), (125000, 32, 1024, 4),
+                                 (8192, 32, 256, 3), (640, 32, 256, 3), (100000, 64, 256, 3)]:
         g = torch.Generator().manual_seed(0)
         x = (torch.randn(B, D, generator=g) * 0.5).cuda()
         cb = (torch.randn(L, K, D, generator=g) * 0.3).cuda()
@@ -77,8 +78,15 @@ if __name__ == "__main__":
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--one", type=str, default=None, help="B,D,K,L for a single forward shape")
+    ap.add_argument("--lib", type=str, default=None, help="another build of librqhip.so (tools/ab_build.sh) instead of the in-tree one")
     a = ap.parse_args()
-    if a.one:
+    if a.lib:
+        from rqhip import _lib
+        _lib.load(os.path.abspath(a.lib))
+        print(f"# library: {a.lib}")
+    if a.one and a.what == "bwd":
+        bwd(a.reps, [tuple(int(v) for v in a.one.split(","))])
+    elif a.one:
         fwd(a.reps, [tuple(int(v) for v in a.one.split(","))])
     else:
         if a.what in ("fwd", "all"):
@@ -89,7 +97,7 @@ if __name__ == "__main__":
             kmeans(a.reps)
 
 # tie-margin variant of the forward kernel (tokenisation with flags): what the runner-up tournament costs
-if True:
+if __name__ == "__main__" and a.what in ("fwd", "all") and not a.one:
     import torch as _t
     from rqhip import ops as _ops
     _g = _t.Generator().manual_seed(0)
