@@ -1,0 +1,1040 @@
+// rq_backward.hip -- backward of the fused residual-quantisation stack (gfx950).
+//
+// Closed form of what torch.autograd computes through the reference's level loop (modules/rqvae.py:
+// 125-132), the STE / rotation-trick / eval branches of Quantize.forward (modules/quantize.py:137-161),
+// the embedding lookup (:101-102) and QuantizeLoss (modules/loss.py:38-41); the recursion is written out
+// in oracle/rq_oracle.c:rqo_rq_backward.  HBM-bound: per row it reads res0, the L ids and the upstream
+// gradients once and writes g_res0 once; the codeword rows come from L2.
+//
+// Kernel 1 (rows): one wave owns 32 rows in the pair layout of rq_rowmath.h.  Pass 1 replays the residual
+//   chain (bit-identical to the forward) and parks res_l, l >= 1, in the workspace; pass 2 walks the levels
+//   backwards carrying G = dL/d res_l in registers, writes g_res0 (exact) and leaves each row's codeword-
+//   gradient vector V_l (what the embedding backward would index_add) in the workspace slot of level l.
+// Kernel 2 (scatter): the embedding backward proper.  Each workgroup owns a contiguous range of rows and
+//   accumulates V_l into an LDS-private [L,K,D+1] table with ds_add_f32 (row stride D+1 spreads codes over
+//   the banks), then stores the table as one partial; a direct global atomicAdd version of this (9.6 M
+//   atomics on 24 576 addresses at B = 100 k) measured 6.1 ms on MI355X, 60x the whole forward.
+// Kernel 3 (reduce): g_codebooks[j] = sum over workgroups of partial[g][j], fixed order.
+// When one level's table exceeds LDS (K (D+1) 4 B > 150 KiB) kernel 1 falls back to global atomics.
+#include <stdlib.h>
+#include "rq_rowmath.h"
+
+namespace rqhip {
+
+struct RqBwdParams {
+    const float *res0, *cb;
+    const int64_t *ids;
+    const float *g_embs, *g_embsum, *g_resid, *g_loss;
+    float *g_res0, *g_cb;
+    float *ws;  // [L, B, D]: slot l holds res_l (l >= 1) during pass 1, then V_l
+    int atomic_scatter;  // 1: scatter codeword gradients with global atomics (tables do not fit LDS)
+    long long B, n_tiles;
+    int D, L, K;
+    float beta;
+    // fused kernel only: this launch scatters the codeword gradients of levels [l_begin, l_end) (the ones whose tables
+    // fit LDS together) and writes g_res0 iff write_rows
+    int l_begin, l_end, write_rows;
+#ifdef RQ_BWD_PROBE
+    int probe;  // developer A/B build only (tools/probe_backward.sh): bit mask of phases to skip, from $RQ_BWD_PROBE
+#endif
+};
+#ifdef RQ_BWD_PROBE
+#define RQ_PROBE(bit) (p.probe & (bit))
+#else
+#define RQ_PROBE(bit) 0
+#endif
+
+template <int KSTEPS, int MODE>
+__global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int il = lane & 31, h = lane >> 5;
+    const int D = p.D, L = p.L, K = p.K;
+    const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const long long gw = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+
+    for (long long tile = gw; tile < p.n_tiles; tile += waves) {
+        const long long row = tile * 32 + il;
+        const bool ok = row < p.B;
+        const long long rc = ok ? row : p.B - 1;
+
+        float r[KSTEPS], e[KSTEPS], o[KSTEPS];
+        load_pair_row<KSTEPS>(p.res0 + (size_t)rc * D, D, h, r);
+        // pass 1: replay res_1 .. res_{L-1}
+        for (int l = 0; l + 1 < L; ++l) {
+            const long long id = p.ids[(size_t)l * p.B + rc];
+            load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + id) * D, D, h, e);
+            const float xsq = (MODE == RQHIP_MODE_ROTATION) ? pair_sumsq<KSTEPS>(r) : 0.0f;
+            level_output<KSTEPS, MODE>(r, e, xsq, o);
+            float *dst = p.ws + ((size_t)(l + 1) * p.B + rc) * D;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                r[kk] = r[kk] - o[kk];
+                const int d = 2 * kk + h;
+                if (ok && d < D) dst[d] = r[kk];
+            }
+        }
+        // r now holds res_{L-1}
+        const float gl = p.g_loss ? p.g_loss[rc] : 0.0f;
+        float G[KSTEPS];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) G[kk] = 0.0f;
+
+        for (int l = L - 1; l >= 0; --l) {
+            if (l != L - 1) {
+                const float *src = (l == 0) ? p.res0 + (size_t)rc * D : p.ws + ((size_t)l * p.B + rc) * D;
+                load_pair_row<KSTEPS>(src, D, h, r);
+            }
+            const long long id = p.ids[(size_t)l * p.B + rc];
+            load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + id) * D, D, h, e);
+            const size_t lrow = ((size_t)l * p.B + rc) * D;
+            float A[KSTEPS], gr[KSTEPS];
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 2 * kk + h;
+                float a = 0.0f;
+                if (p.g_embs && d < D) a = p.g_embs[lrow + d];
+                if (p.g_embsum) a = a + ((d < D) ? p.g_embsum[(size_t)rc * D + d] : 0.0f);
+                A[kk] = a - G[kk];
+                gr[kk] = (p.g_resid && d < D) ? p.g_resid[lrow + d] : 0.0f;
+            }
+            float *dE = (p.g_cb && p.atomic_scatter) ? p.g_cb + ((size_t)l * K + id) * D : nullptr;
+            float *V = (p.g_cb && !p.atomic_scatter) ? p.ws + lrow : nullptr;
+            if (MODE == RQHIP_MODE_ROTATION) {
+                float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
+                const float xsq = pair_sumsq<KSTEPS>(r);
+                rotation_lane<KSTEPS>(r, e, xsq, o, w, u, q, scale);
+                const float aw = pair_dot<KSTEPS>(A, w), aq = pair_dot<KSTEPS>(A, q);
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const float lin = ((A[kk] - 2.0f * (aw * w[kk])) + 2.0f * (aq * u[kk])) * scale;
+                    const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
+                    const float embg = (2.0f * (e[kk] - r[kk])) * gl;
+                    G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
+                    const int d = 2 * kk + h;
+                    if (ok && d < D) {
+                        if (dE) atomicAdd(dE + d, embg);
+                        if (V) V[d] = embg;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
+                    const float embg = (2.0f * (e[kk] - r[kk])) * gl;
+                    const int d = 2 * kk + h;
+                    if (MODE == RQHIP_MODE_EVAL) {
+                        const float contrib = A[kk] + embg;
+                        G[kk] = (gr[kk] + G[kk]) + commit;
+                        if (ok && d < D) {
+                            if (dE) atomicAdd(dE + d, contrib);
+                            if (V) V[d] = contrib;
+                        }
+                    } else {
+                        G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
+                        if (ok && d < D) {
+                            if (dE) atomicAdd(dE + d, embg);
+                            if (V) V[d] = embg;
+                        }
+                    }
+                }
+            }
+        }
+        if (ok && p.g_res0) {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 2 * kk + h;
+                if (d < D) p.g_res0[(size_t)row * D + d] = G[kk];
+            }
+        }
+    }
+}
+
+
+
+// ---- fused variant for L <= kFusedMaxL: rows + embedding backward in ONE kernel -------------------------------
+// Same arithmetic as rq_backward_kernel (g_res0 bit-identical), but the residual chain of a row stays in
+// registers (L * KSTEPS values per lane) and each row's codeword-gradient vectors go straight into the
+// workgroup's LDS tables: no [L,B,D] round trip through HBM.  Per row: reads res0, ids, upstream gradients
+// (12D + 8L bytes), writes g_res0 (4D) -- the algorithmic traffic of SURVEY.md 8d.
+constexpr int kFusedMaxL = 4;
+constexpr int kFusedThreads = 512;
+constexpr int kFusedWaves = kFusedThreads / 64;
+
+// Embedding backward inside the fused kernel WITHOUT atomics ("owner computes"): the workgroup keeps one
+// [levels, K, D] table in LDS; after a level's per-row vectors V are known, the waves park them (and the rows' ids) in
+// an LDS stage, and every code is then accumulated by exactly ONE wave -- wave (id mod 8) -- which walks the staged
+// rows in order (ballot of "mine", lowest set bit first) and adds V to its table row with plain LDS read / add / write.
+// One owner per address and in-order LDS execution make the sum order fixed: round, wave, row ascending -- restated by
+// oracle/rq_oracle.c:rqo_rq_backward_ordered, so the codebook gradient is bit-reproducible.  (The first version let
+// all waves ds_add_f32 into the table: 9.6 M LDS float atomics = 45 of the kernel's 76 us, and an unordered sum.)
+// `sg` waves are staged at a time (8, or 4 when a K = 1024 table leaves less LDS).
+__device__ __forceinline__ void cb_accumulate(float *__restrict__ tab_l, const float *__restrict__ stage,
+                                              const int *__restrict__ ids_s, int rows, int D, int wave, int lane) {
+    for (int base = 0; base < rows; base += 64) {
+        const int myid = (base + lane < rows) ? ids_s[base + lane] : -1;
+        const bool mine = myid >= 0 && (myid & (kFusedWaves - 1)) == wave;
+        unsigned long long m = __ballot(mine);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int id = __builtin_amdgcn_readlane(myid, j);
+            // the next row of this wave too, when it belongs to ANOTHER code: two independent read-add-write chains in
+            // flight instead of one (same code: strictly one after the other -- the order of the sum is the contract)
+            int j2 = -1, id2 = -1;
+            if (m) {
+                j2 = __builtin_ctzll(m);
+                id2 = __builtin_amdgcn_readlane(myid, j2);
+                if (id2 != id) m &= m - 1; else j2 = -1;
+            }
+            if (lane < D) {
+                float *t = tab_l + (size_t)id * D + lane;
+                if (j2 >= 0) {
+                    float *t2 = tab_l + (size_t)id2 * D + lane;
+                    const float a = *t, b = *t2;
+                    const float va = stage[(size_t)(base + j) * (D + 1) + lane];
+                    const float vb = stage[(size_t)(base + j2) * (D + 1) + lane];
+                    *t = a + va;
+                    *t2 = b + vb;
+                } else {
+                    *t = *t + stage[(size_t)(base + j) * (D + 1) + lane];
+                }
+            }
+        }
+    }
+}
+
+// VEC: D == 2*KSTEPS and every row pointer 16-byte aligned -> rows and codewords move as float4 half-rows +
+// v_permlane32_swap (rq_rowmath.h) instead of 4 bytes per lane and instruction.
+template <int KSTEPS, int MODE, bool VEC>
+__global__ __launch_bounds__(kFusedThreads) void rq_backward_fused_kernel(const RqBwdParams p, float *__restrict__ partial,
+                                                                         int LKD_total, int sg) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int D = p.D, L = p.L, K = p.K;
+    const int tbl = (p.l_end - p.l_begin) * K * D;           // [levels of this launch][K][D]
+    float *stage = acc + tbl;                               // [sg * 32][D + 1]
+    int *ids_s = reinterpret_cast<int *>(stage + sg * 32 * (D + 1));  // [sg * 32]
+    if (p.g_cb)
+        for (int e = threadIdx.x; e < tbl; e += kFusedThreads) acc[e] = 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    constexpr int kWaves = kFusedWaves;
+    const long long waves = (long long)gridDim.x * kWaves;
+    const long long gw = (long long)wave * gridDim.x + blockIdx.x;
+    // every wave of the workgroup runs the same number of rounds (the accumulation below has barriers)
+    const long long n_rounds = (p.n_tiles + waves - 1) / waves;
+
+    for (long long it = 0; it < n_rounds; ++it) {
+        const long long tile = it * waves + gw;
+        const long long row = tile * 32 + il;
+        const bool ok = tile < p.n_tiles && row < p.B;
+        const long long rc = ok ? row : p.B - 1;
+
+        float rl[kFusedMaxL][KSTEPS];
+        float el[kFusedMaxL][KSTEPS];  // the codeword of every level, gathered once
+        float o[KSTEPS];
+        int idl[kFusedMaxL];
+        auto fetch = [&](const float *row_base, float(&v)[KSTEPS]) {
+            if (VEC) load_pair_row_vec<KSTEPS>(row_base, h, v);
+            else load_pair_row<KSTEPS>(row_base, D, h, v);
+        };
+        fetch(p.res0 + (size_t)rc * D, rl[0]);
+#pragma unroll
+        for (int l = 0; l < kFusedMaxL; ++l) {
+            if (l < L) {
+                idl[l] = (int)p.ids[(size_t)l * p.B + rc];
+                fetch(p.cb + ((size_t)l * K + idl[l]) * D, el[l]);
+                if (l + 1 < L) {
+                    const float xsq = (MODE == RQHIP_MODE_ROTATION) ? pair_sumsq<KSTEPS>(rl[l]) : 0.0f;
+                    level_output<KSTEPS, MODE>(rl[l], el[l], xsq, o);
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk)
+                        if (l + 1 < kFusedMaxL) rl[(l + 1 < kFusedMaxL) ? l + 1 : 0][kk] = rl[l][kk] - o[kk];
+                }
+            }
+        }
+        const float gl = p.g_loss ? p.g_loss[rc] : 0.0f;
+        float G[KSTEPS], gs[KSTEPS];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            G[kk] = 0.0f;
+            gs[kk] = 0.0f;
+        }
+        if (p.g_embsum) fetch(p.g_embsum + (size_t)rc * D, gs);
+#pragma unroll
+        for (int l = kFusedMaxL - 1; l >= 0; --l) {
+            if (l < L) {
+                const float(&r)[KSTEPS] = rl[l];
+                const float(&e)[KSTEPS] = el[l];
+                const size_t lrow = ((size_t)l * p.B + rc) * D;
+                float A[KSTEPS], gr[KSTEPS];
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    A[kk] = 0.0f;
+                    gr[kk] = 0.0f;
+                }
+                if (p.g_embs) fetch(p.g_embs + lrow, A);
+                if (p.g_resid) fetch(p.g_resid + lrow, gr);
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    float a = A[kk];
+                    if (p.g_embsum) a = a + gs[kk];
+                    A[kk] = a - G[kk];
+                }
+                float cbv[KSTEPS];  // this row's contribution to dE_l[id] (features of this lane's parity)
+                if (MODE == RQHIP_MODE_ROTATION) {
+                    float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
+                    const float xsq = pair_sumsq<KSTEPS>(r);
+                    rotation_lane<KSTEPS>(r, e, xsq, o, w, u, q, scale);
+                    const float aw = pair_dot<KSTEPS>(A, w), aq = pair_dot<KSTEPS>(A, q);
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) {
+                        const float lin = ((A[kk] - 2.0f * (aw * w[kk])) + 2.0f * (aq * u[kk])) * scale;
+                        const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
+                        const float embg = (2.0f * (e[kk] - r[kk])) * gl;
+                        G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
+                        cbv[kk] = embg;
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) {
+                        const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
+                        const float embg = (2.0f * (e[kk] - r[kk])) * gl;
+                        if (MODE == RQHIP_MODE_EVAL) {
+                            const float contrib = A[kk] + embg;
+                            G[kk] = (gr[kk] + G[kk]) + commit;
+                            cbv[kk] = contrib;
+                        } else {
+                            G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
+                            cbv[kk] = embg;
+                        }
+                    }
+                }
+                if (p.g_cb && l >= p.l_begin && l < p.l_end) {  // uniform: this launch owns level l's table
+                    float *tab_l = acc + (size_t)(l - p.l_begin) * K * D;
+                    for (int g0 = 0; g0 < kWaves; g0 += sg) {
+                        if (wave >= g0 && wave < g0 + sg) {
+                            float *st = stage + (size_t)((wave - g0) * 32 + il) * (D + 1) + h;
+#pragma unroll
+                            for (int kk = 0; kk < KSTEPS; ++kk)
+                                if (2 * kk + h < D) st[2 * kk] = cbv[kk];
+                            if (h == 0) ids_s[(wave - g0) * 32 + il] = ok ? idl[l] : -1;
+                        }
+                        __syncthreads();
+                        cb_accumulate(tab_l, stage, ids_s, sg * 32, D, wave, lane);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        if (ok && p.g_res0 && p.write_rows) {
+            if (VEC) {
+                store_pair_row<KSTEPS>(p.g_res0 + (size_t)row * D, h, G);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const int d = 2 * kk + h;
+                    if (d < D) p.g_res0[(size_t)row * D + d] = G[kk];
+                }
+            }
+        }
+    }
+
+    if (p.g_cb) {
+        __syncthreads();
+        float *out = partial + (size_t)blockIdx.x * LKD_total;
+        for (int e2 = threadIdx.x; e2 < (p.l_end - p.l_begin) * K * D; e2 += kFusedThreads) {
+            out[e2] = acc[e2];
+        }
+    }
+}
+
+// ---- flat variant for EVAL / STE, D % 4 == 0, D <= 64: the backward of these two modes is purely elementwise ----------
+// Nothing in the EVAL / STE recursion crosses features (no dot products -- those belong to the rotation trick), so the
+// pair layout of the matrix kernels buys nothing here and costs L * KSTEPS registers per lane (247 VGPRs, two waves per
+// SIMD, two half-filled rounds at B = 100 000).  This kernel maps one lane to FOUR consecutive features of one row and
+// splits the workgroup's 16 waves into two roles that run concurrently (one workgroup per CU is all the LDS allows, so
+// the overlap of the HBM-bound and the LDS-bound half of the work has to happen INSIDE the workgroup):
+//   * waves 0-7, "rows": D/4 lanes per row, R = 512 / (D/4) rows per step; every global access is one 16-byte load /
+//     store and a wave touches whole consecutive rows.  The row data of step h+1 (res0, upstream gradients, gathered
+//     codewords) and the ids of step h+2 are in flight while step h is computed (software pipeline).  Each lane parks
+//     its 4 codeword-gradient values per level in the LDS stage [h & 1][levels][R][D] and the table row
+//     key = level * K + id in keys[h & 1][][];
+//   * waves 8-15, "owners": the embedding backward of the rows staged in step h-1, no float atomics.  The table
+//     [levels][K][D] is owned BY FEATURE CHUNK: owner wave w adds the 16-byte chunks c = w, w + OW, .. of every staged
+//     row, so no two waves ever touch the same table word and a wave needs no list of "its" rows -- one lane takes one
+//     staged row of a level (64 per instruction) and does ds_read_b128 / 4 adds / ds_write_b128 on table[key][c].
+//     Lanes of one instruction that carry the same key must add one after the other, lowest row first: the add loop
+//     runs in rounds r = 0, 1, .. and a lane adds in round rank(row) = the number of earlier rows of its step with the
+//     same key (2-3 rounds for 64 rows on 256 codes, 64 when every row hits one code).
+//   * the ranks are computed ONCE per step and level, one step ahead, by owner wave `level` (the keys of block h are
+//     in LDS a step before its stage: the rows waves write them when they request the codewords): every unranked lane
+//     offers (round, lane) to a tag slot of its key with an integer LDS min and reads the slot back; the lane that
+//     finds its own offer takes the round's number as its rank.  A newer round's offers are smaller than any older
+//     one, so the slots are never reset; distinct keys sharing a slot only cost a round.
+//   * what this replaced, and why (round 3, all measured at 1 M rows x 3 x 256 x 32): one half-wave per table row that
+//     listed and walked its rows (375 instructions per wave and step), 180 us; chunk owners that each ran the min /
+//     read-back rounds themselves, 175-183 us with or without a deeper load pipeline -- LDS atomics execute at about
+//     one LANE per 2.7 cycles and CU (the 9.6 M ds_add_f32 of round 1's scatter kernel: 45 us; ds_add_f32 owners here:
+//     540 us, although they did add conflicting lanes in ascending order), so eight waves each offering 250 lanes per
+//     step were 5 400 cycles of LDS atomic unit per 64-row step; ranking once is 250 lane-atomics per step.  With the
+//     owner role switched off the rows role alone streams 1 M rows in 92 us = 4.65 TB/s (three register sets in a
+//     ring, tools/gpu_probe.sh).
+//   * stage rows and table rows are rotated by (row index >> sh) chunks so that the 16 lanes of one ds_read_b128 group
+//     (same chunk, different rows) fall on different banks;
+//   * one barrier per step hands the stage buffer, the keys and the ranks over.
+// The sum order of a code is therefore: workgroup b of G, step h ascending (rows [(h G + b) R, (h G + b) R + R)), row
+// ascending -- oracle/rq_oracle.c:rqo_rq_backward_ordered with unit_rows = R, nw = 1 -- followed by the same 4-segment
+// reduce over workgroups.
+constexpr int kFlatRowThreads = 512;                    // waves 0-7
+// owner waves: 8-15 (the training shape of 3 x 256 x 32), or 8-11: a
+// 12-wave workgroup has 170 registers per lane instead of 128 (template parameter OW)
+constexpr int kFlatMaxD = 64;
+// tag slots of the ranking rounds: 256 words per level of the launch
+constexpr int kFlatTagSlots = 256;
+constexpr size_t kFlatTagBytesPerLevel = (size_t)kFlatTagSlots * sizeof(unsigned);
+
+// NL: number of levels when known at compile time (3, 4), 0 = p.L.  TRAIN: the upstream gradients are the training
+// step's -- g_embsum and g_loss given, g_embs and g_resid absent -- so their loads and tests are compiled out.  (The rows
+// role is bound by instruction issue, not by HBM: ~400 VALU instructions per lane and step in the first version, 64-bit
+// address chains, per-load predication, tests of L and of four optional pointers.)
+// NLP: levels of this launch (l_end - l_begin) when known at compile time, 0 = runtime.  CPW: most 16-byte chunks of a
+// row one lane of an owner wave adds; EXACT: every lane has exactly CPW.  OW: owner waves (8 or 4).
+template <int MODE, int NL, bool TRAIN, int NLP, int CPW, bool EXACT, int OW>
+__global__ __launch_bounds__(kFlatRowThreads + 64 * OW) void rq_backward_flat_kernel(const RqBwdParams p, float *__restrict__ partial,
+                                                                       int LKD_total, int R, int LPR) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    constexpr int kFlatThreads = kFlatRowThreads + 64 * OW, kFlatOwnerWaves = OW;
+    constexpr int LM = NL ? NL : kFusedMaxL;
+    const int D = p.D, L = NL ? NL : p.L, K = p.K;
+    constexpr int LMP = NLP ? NLP : 1;                       // levels whose owner rounds are interleaved (the rest one by one)
+    const int nl = NLP ? NLP : p.l_end - p.l_begin;
+    // level-by-level launches of the training step (4 x 1024: one table per launch): a launch that does not write g_res0
+    // needs only the residual chain up to its own levels -- the STE codeword gradient 2 (e - r) g_loss of a level does not
+    // involve the gradient that arrives from above -- so it skips g_embsum, the deeper levels' ids / codewords and the
+    // backward walk
+    constexpr bool kPartial = TRAIN && MODE == RQHIP_MODE_STE && NLP != 0 && NLP < NL;
+    const bool need_g = !kPartial || p.write_rows;           // uniform
+    const int Lneed = need_g ? L : p.l_end;
+    const int tbl = p.g_cb ? nl * K * D : 0;                 // [levels of this launch][K][D]
+    const int items = nl * R;                               // staged rows x levels per step
+    float *stage0 = acc + tbl;                              // [2][nl][R][D]
+    int *keys0 = reinterpret_cast<int *>(stage0 + 2 * (size_t)items * D);   // [3][nl][R] (written one step before the stage)
+    int *kr0 = keys0 + 3 * items;                                            // [3][nl][R]: rank << 16 | key, -1: no row
+    unsigned *tags0 = reinterpret_cast<unsigned *>(kr0 + 3 * items);        // [nl][kFlatTagSlots]
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int e = threadIdx.x * 4; e < tbl; e += kFlatThreads * 4) *reinterpret_cast<f32x4 *>(acc + e) = zero4;
+    if (p.g_cb)
+        for (int e = threadIdx.x; e < nl * kFlatTagSlots; e += kFlatThreads) tags0[e] = 0xffffffffu;
+    // bank rotation of the 16-byte chunks of a stage / table row: chunk c of row `idx` lies at position
+    // (c + (idx >> sh)) mod LPR, so that one chunk of 16 different rows covers all 64 banks (LPR a power of two; other
+    // widths keep the plain order)
+    const bool lpr_pow2 = (LPR & (LPR - 1)) == 0;
+    const int rot_sh = LPR >= 16 ? 0 : LPR == 8 ? 1 : LPR == 4 ? 2 : LPR == 2 ? 3 : 4;
+    const unsigned rot_mask = lpr_pow2 ? (unsigned)LPR - 1u : 0u, ch_mask = lpr_pow2 ? (unsigned)LPR - 1u : 0xffffffffu;
+    auto chunk_pos = [&](unsigned idx, unsigned c) -> unsigned { return (c + ((idx >> rot_sh) & rot_mask)) & ch_mask; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool row_role = tid < kFlatRowThreads;             // wave-uniform
+    const long long blocks = (p.B + R - 1) / R;
+    const long long n_steps = (blocks + gridDim.x - 1) / gridDim.x;   // same for every workgroup (barriers below)
+
+    // ---- state of the "rows" role ---------------------------------------------------------------------------------------
+    // Addresses are a uniform base (scalar registers) + a 32-bit byte offset per lane (the host checks B * D * 4 < 2^32).
+    // Lanes without a row (tail of the last step, idle slots) read row B-1 like everybody else and do not store.
+    const int rl = (tid & (kFlatRowThreads - 1)) / LPR, ch = (tid & (kFlatRowThreads - 1)) - rl * LPR;
+    const bool slot = rl < R;                                // row slot inside the step, 16-byte chunk inside the row
+    const unsigned Bm1 = (unsigned)(p.B - 1), chb = (unsigned)ch * 16u, rowb = (unsigned)D * 4u;
+    const int st_off = rl * D + 4 * (int)chunk_pos((unsigned)rl, (unsigned)ch);   // this lane's chunk inside a level's stage
+    auto at = [](const void *base, unsigned byte_off) { return reinterpret_cast<const char *>(base) + byte_off; };
+    auto ld4 = [&](const float *base, unsigned byte_off) { return *reinterpret_cast<const f32x4 *>(at(base, byte_off)); };
+    auto row_of = [&](long long h, bool &ok) -> unsigned {  // this lane's (clamped) row in step h; ok: it owns that row
+        const long long blk = h * gridDim.x + blockIdx.x;
+        const bool live = h < n_steps && blk < blocks;       // uniform
+        const unsigned row = (live ? (unsigned)(blk * R) : 0u) + (unsigned)rl;
+        ok = live && slot && row <= Bm1;
+        return row < Bm1 ? row : Bm1;
+    };
+    auto load_ids = [&](unsigned row, int(&id)[LM]) {
+#pragma unroll
+        for (int l = 0; l < LM; ++l)
+            if (kPartial ? l < Lneed : l < L) id[l] = *reinterpret_cast<const int *>(at(p.ids + (size_t)l * p.B, row * 8u));   // low dword
+    };
+    auto gather = [&](const int(&id)[LM], f32x4(&e)[LM]) {
+#pragma unroll
+        for (int l = 0; l < LM; ++l)
+            if (kPartial ? l < Lneed : l < L) e[l] = ld4(p.cb + (size_t)l * K * D, (unsigned)id[l] * rowb + chb);
+    };
+    // Three register sets in a ring: while step h is computed from set h % 3, the codewords of step h + 1 (its ids arrived
+    // during step h - 1) and the ids and row data of step h + 2 are in flight.  (Until round 3 the loads of step h + 1 were
+    // issued AFTER the arithmetic of step h and consumed right after the barrier: a step cost a whole HBM latency on top
+    // of its arithmetic, 2.7 us per 64-row step -- latency-bound at 18 KB in flight per CU, which is what made 1 M rows
+    // run at 2.4 TB/s no matter what the owner role cost.)
+    struct RowSet {
+        unsigned row;
+        bool ok;
+        int id[LM];
+        f32x4 e[LM], r0, gs;
+        float gl;
+    };
+    RowSet rs[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        rs[q].row = 0; rs[q].ok = false; rs[q].r0 = zero4; rs[q].gs = zero4; rs[q].gl = 0.0f;
+#pragma unroll
+        for (int l = 0; l < LM; ++l) { rs[q].id[l] = 0; rs[q].e[l] = zero4; }
+    }
+    auto issue_rows = [&](RowSet &t, long long h) {          // ids and row data of step h
+        t.row = row_of(h, t.ok);
+        load_ids(t.row, t.id);
+        const unsigned off = t.row * rowb + chb;
+        t.r0 = ld4(p.res0, off);
+        if ((TRAIN || p.g_embsum) && need_g) t.gs = ld4(p.g_embsum, off);
+        if (TRAIN || p.g_loss) t.gl = *reinterpret_cast<const float *>(at(p.g_loss, t.row * 4u));
+    };
+    // the table rows (level * K + id, -1: no row) of step h go to keys[h % 3] as soon as its ids are there -- the id
+    // registers of a set are free once its codewords are requested
+    auto put_keys = [&](const RowSet &t, int q) {            // q = h % 3, the set's place in the ring
+        if (p.g_cb && slot && ch == 0 && !RQ_PROBE(4)) {
+            int *keys = keys0 + q * items;
+#pragma unroll
+            for (int l = 0; l < LM; ++l)
+                if (l < L && l >= p.l_begin && l < p.l_end) keys[(l - p.l_begin) * R + rl] = t.ok ? (l - p.l_begin) * K + t.id[l] : -1;
+        }
+    };
+    if (row_role) {
+        issue_rows(rs[0], 0);
+        issue_rows(rs[1], 1);
+        gather(rs[0].id, rs[0].e);
+        put_keys(rs[0], 0);
+    }
+
+    // ---- state of the "owners" role -------------------------------------------------------------------------------------
+    const int ow = __builtin_amdgcn_readfirstlane(wave) - kFlatRowThreads / 64;   // owner wave 0..7 (< 0: a rows wave)
+    // a lane adds chunks c0 + cstep j (< LPR), j < CPW, of one staged row; with 32 or fewer rows per step (D = 64) the two
+    // halves of a wave take the same rows and alternate chunks
+    const bool split = R <= 32;
+    const int hsel = split ? lane >> 5 : 0;
+    const int c0 = ow + kFlatOwnerWaves * hsel, cstep = split ? 2 * kFlatOwnerWaves : kFlatOwnerWaves;
+    unsigned round_no = 0;                                   // ranking rounds this wave has played (newer offers are smaller)
+    constexpr unsigned kRoundMax = 0x03ffffffu;
+
+    const long long last = p.g_cb ? n_steps : n_steps - 1;
+    auto rows_step = [&](long long h, int qn, RowSet &sc, RowSet &sn, RowSet &snn) {   // qn = (h + 1) % 3
+        {
+            {
+                issue_rows(snn, h + 2);
+                gather(sn.id, sn.e);
+                put_keys(sn, qn);
+                const bool ok = sc.ok;
+                float *stage = stage0 + (size_t)(h & 1) * items * D;
+                const unsigned off_c = sc.row * rowb + chb;
+                // ---- this step's rows: residual chain forward, then the levels backwards carrying G = dL/d res_l ---------
+                f32x4 r[LM];
+                r[0] = sc.r0;
+#pragma unroll
+                for (int l = 0; l + 1 < LM; ++l) {
+                    if (kPartial ? l + 1 < Lneed : l + 1 < L) {
+                        const f32x4 o = (MODE == RQHIP_MODE_EVAL) ? sc.e[l] : r[l] + (sc.e[l] - r[l]);   // level_output<MODE>
+                        r[l + 1] = r[l] - o;
+                    }
+                }
+                f32x4 G = zero4;
+                if (kPartial && !need_g) {
+#pragma unroll
+                    for (int l = 0; l < LM; ++l) {
+                        if (p.g_cb && l >= p.l_begin && l < p.l_end && slot && !RQ_PROBE(4)) {
+                            const f32x4 embg = (2.0f * (sc.e[l] - r[l])) * sc.gl;
+                            *reinterpret_cast<f32x4 *>(stage + (l - p.l_begin) * R * D + st_off) = embg;
+                        }
+                    }
+                } else
+#pragma unroll
+                for (int l = LM - 1; l >= 0; --l) {
+                    if (l < L) {
+                        f32x4 A = zero4, gr = zero4;
+                        if (!TRAIN && p.g_embs) A = ld4(p.g_embs + (size_t)l * p.B * D, off_c);
+                        if (!TRAIN && p.g_resid) gr = ld4(p.g_resid + (size_t)l * p.B * D, off_c);
+                        if (TRAIN || p.g_embsum) A = A + sc.gs;
+                        A = A - G;
+                        const f32x4 commit = ((2.0f * p.beta) * (r[l] - sc.e[l])) * sc.gl;
+                        const f32x4 embg = (2.0f * (sc.e[l] - r[l])) * sc.gl;
+                        f32x4 cbv;
+                        if (MODE == RQHIP_MODE_EVAL) {
+                            cbv = A + embg;
+                            G = (gr + G) + commit;
+                        } else {
+                            G = ((gr + G) + A) + commit;
+                            cbv = embg;
+                        }
+                        if (p.g_cb && l >= p.l_begin && l < p.l_end && slot && !RQ_PROBE(4)) {   // (level test is uniform)
+                            const int li = l - p.l_begin;
+                            *reinterpret_cast<f32x4 *>(stage + li * R * D + st_off) = cbv;
+                        }
+                    }
+                }
+                if (ok && p.g_res0 && p.write_rows)
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(p.g_res0) + off_c) = G;
+            }
+        }
+    };
+    // ranks of block h (keys ring slot q): owner wave `level` plays the min / read-back rounds for its level's R rows
+    auto rank_block = [&](long long h, int q) {
+        if (!(p.g_cb && h < n_steps && ow < nl) || RQ_PROBE(4) || RQ_PROBE(2)) return;
+        const int *keys = keys0 + q * items + ow * R;
+        int *kr = kr0 + q * items + ow * R;
+        unsigned *tags = tags0 + ow * kFlatTagSlots;
+        if (round_no > kRoundMax - 4096u) {                  // (never in practice: 2^26 rounds) start the tags over
+            for (int e = lane; e < kFlatTagSlots; e += 64) tags[e] = 0xffffffffu;
+            round_no = 0;
+        }
+        for (int vb = 0; vb < R; vb += 64) {                 // rows of a later pass rank after every row of an earlier one:
+            const bool live = vb + lane < R;                 // their adds happen in a later pass of the add loop anyway
+            const int key = live ? keys[vb + lane] : -1;
+            bool pend = key >= 0;
+            unsigned *tslot = tags + ((unsigned)(key >= 0 ? key : 0) & (kFlatTagSlots - 1));
+            int rank = 0;
+            for (int r = 0; __any(pend); ++r) {
+                const unsigned mine = ((kRoundMax - round_no) << 6) | (unsigned)lane;
+                if (pend) atomicMin(tslot, mine);            // ds_min_u32
+                if (pend && __hip_atomic_load(tslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == mine) {
+                    rank = r;
+                    pend = false;
+                }
+                ++round_no;
+            }
+            if (live) kr[vb + lane] = key >= 0 ? (rank << 16) | key : -1;
+        }
+    };
+    auto owners_step = [&](long long h, int q) {             // adds block h - 1 (ring slot q = (h - 1) % 3)
+        if (h >= 1 && p.g_cb && !RQ_PROBE(4) && !RQ_PROBE(2) && ow < LPR) {
+            const float *stage = stage0 + (size_t)((h - 1) & 1) * items * D;
+            f32x4 *acc4 = reinterpret_cast<f32x4 *>(acc);
+            const int *kr = kr0 + q * items;
+            for (int vb = 0; vb < R; vb += 64) {             // one pass for D >= 32; staged rows ascending across passes
+                const int it = split ? (lane & 31) : vb + lane;
+                const bool live = it < R && c0 < LPR;
+                const int item = live ? it : 0;
+                const unsigned irot = ((unsigned)item >> rot_sh) & rot_mask;
+                for (int lg = 0; lg < nl; lg += LMP) {
+                    unsigned pm = 0;                         // bit li: this lane's row of level li still has to be added
+                    int rank[LMP];
+                    f32x4 val[LMP][CPW];
+                    unsigned tbase[LMP], trot[LMP];          // table row (index of its first 16-byte chunk) and its chunk rotation
+#pragma unroll
+                    for (int li = 0; li < LMP; ++li) {
+                        if (NLP || lg + li < nl) {
+                            const int e = live ? kr[(lg + li) * R + item] : -1;          // rank << 16 | level * K + id; -1: no row
+                            pm |= e >= 0 ? 1u << li : 0u;
+                            const unsigned k = e >= 0 ? (unsigned)e & 0xffffu : 0u;
+                            rank[li] = e >> 16;
+                            tbase[li] = k * (unsigned)LPR;
+                            trot[li] = (k >> rot_sh) & rot_mask;
+                            const f32x4 *srow = reinterpret_cast<const f32x4 *>(stage) + ((lg + li) * R + item) * LPR;
+#pragma unroll
+                            for (int j = 0; j < CPW; ++j)
+                                if (EXACT || c0 + cstep * j < LPR) val[li][j] = srow[((unsigned)(c0 + cstep * j) + irot) & ch_mask];
+                        }
+                    }
+                    if (RQ_PROBE(1)) pm = 0;
+                    // round r: the rows whose rank is r add (same-key rows of one instruction one after the other, lowest
+                    // row first); straight-line per round, so the LDS latencies of the levels overlap
+                    for (int r = 0; __any(pm != 0); ++r) {
+                        f32x4 tv[LMP][CPW];
+#pragma unroll
+                        for (int li = 0; li < LMP; ++li) {
+                            if ((NLP || lg + li < nl) && (pm >> li & 1u) && rank[li] == r) {
+#pragma unroll
+                                for (int j = 0; j < CPW; ++j)
+                                    if (EXACT || c0 + cstep * j < LPR) tv[li][j] = acc4[tbase[li] + (((unsigned)(c0 + cstep * j) + trot[li]) & ch_mask)];
+                            }
+                        }
+#pragma unroll
+                        for (int li = 0; li < LMP; ++li) {
+                            if ((NLP || lg + li < nl) && (pm >> li & 1u) && rank[li] == r) {
+#pragma unroll
+                                for (int j = 0; j < CPW; ++j)
+                                    if (EXACT || c0 + cstep * j < LPR)
+                                        acc4[tbase[li] + (((unsigned)(c0 + cstep * j) + trot[li]) & ch_mask)] = tv[li][j] + val[li][j];
+                                pm &= ~(1u << li);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // step h: the rows waves stage block h, the owner waves add block h-1; the last step only drains.  Each role runs its
+    // own loop (the rows loop unrolled by the three register sets); both pass the same last + 1 barriers.
+    if (p.g_cb) __syncthreads();                             // the keys of block 0 (and the zeroed table, the tags) are in LDS
+    if (row_role) {
+        for (long long h = 0; h <= last; h += 3) {
+            if (h < n_steps) rows_step(h, 1, rs[0], rs[1], rs[2]);
+            if (p.g_cb) __syncthreads();
+            if (h + 1 <= last) {
+                if (h + 1 < n_steps) rows_step(h + 1, 2, rs[1], rs[2], rs[0]);
+                if (p.g_cb) __syncthreads();
+            }
+            if (h + 2 <= last) {
+                if (h + 2 < n_steps) rows_step(h + 2, 0, rs[2], rs[0], rs[1]);
+                if (p.g_cb) __syncthreads();
+            }
+        }
+    } else {
+        int q = 2;                                           // (h - 1) % 3
+        for (long long h = 0; h <= last; ++h) {
+            owners_step(h, q);
+            q = q == 2 ? 0 : q + 1;                          // h % 3
+            rank_block(h, q);
+            if (p.g_cb) __syncthreads();
+        }
+    }
+
+    if (p.g_cb) {
+        float *out = partial + (size_t)blockIdx.x * LKD_total;
+        const int lpr_lg = 31 - __builtin_clz((unsigned)LPR);
+        for (int e = threadIdx.x * 4; e < (RQ_PROBE(8) ? 0 : tbl); e += kFlatThreads * 4) {
+            int dst = e;
+            if (lpr_pow2) {                                  // position -> chunk (see chunk_pos)
+                const unsigned q = (unsigned)e >> 2, trow_i = q >> lpr_lg, pos = q & ch_mask;
+                dst = (int)(((trow_i << lpr_lg) + ((pos - ((trow_i >> rot_sh) & rot_mask)) & ch_mask)) << 2);
+            }
+            *reinterpret_cast<f32x4 *>(out + dst) = *reinterpret_cast<const f32x4 *>(acc + e);
+        }
+    }
+}
+
+// ---- kernel 2: LDS-private scatter of V into per-workgroup codebook-gradient tables -----------------------
+// thread (rs, d): rs = row slot inside the workgroup's step, d = feature.  DR = D rounded up to a power of 2.
+__global__ __launch_bounds__(256) void rq_cbgrad_scatter_kernel(const float *__restrict__ V,
+                                                                const int64_t *__restrict__ ids, long long B, int D,
+                                                                int DR, int K, int l0, int nl, long long rows_per_wg,
+                                                                float *__restrict__ partial, int LKD_total) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int stride = D + 1;
+    const int tbl = nl * K * stride;
+    for (int e = threadIdx.x; e < tbl; e += 256) acc[e] = 0.0f;
+    __syncthreads();
+    const int d = threadIdx.x % DR, rs = threadIdx.x / DR, rstep = 256 / DR;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < B) ? r0 + rows_per_wg : B;
+    if (d < D) {
+        for (long long row = r0 + rs; row < r1; row += rstep) {
+            for (int l = 0; l < nl; ++l) {
+                const int id = (int)ids[(size_t)(l0 + l) * B + row];
+                const float v = V[((size_t)(l0 + l) * B + row) * D + d];
+                atomicAdd(&acc[(l * K + id) * stride + d], v);  // ds_add_f32
+            }
+        }
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * LKD_total + (size_t)l0 * K * D;
+    for (int e = threadIdx.x; e < nl * K * D; e += 256) {
+        const int kd = e / D, dd = e - kd * D;
+        out[e] = acc[kd * stride + dd];
+    }
+}
+
+// ---- kernel 3: fixed-order sum of the per-workgroup partials ------------------------------------------------
+// 64 outputs per 256-thread block; thread (seg, j) sums partials g = seg, seg+4, ... in ascending order, the four
+// segment sums are combined as ((s0 + s1) + (s2 + s3)).
+__global__ __launch_bounds__(256) void rq_cbgrad_reduce_kernel(const float *__restrict__ partial, int G, int n,
+                                                               float *__restrict__ out) {
+    __shared__ float seg_sum[4][64];
+    const int jl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    float s = 0.0f;
+    if (j < n) {
+#pragma unroll 8
+        for (int g = seg; g < G; g += 4) s = s + partial[(size_t)g * n + j];
+    }
+    seg_sum[seg][jl] = s;
+    __syncthreads();
+    if (seg == 0 && j < n) out[j] = (seg_sum[0][jl] + seg_sum[1][jl]) + (seg_sum[2][jl] + seg_sum[3][jl]);
+}
+
+constexpr size_t kScatterLdsBudget = 150 * 1024;
+constexpr int kMaxScatterWgs = 128;
+
+static int fused_wgs(long long B) {
+    long long g = ((B + 31) / 32 + 7) / 8;
+    const long long cap = cu_count();
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// fused kernel LDS: [levels of the launch][K][D] table + a stage of sg waves x 32 rows x (D+1) floats + their ids
+constexpr size_t kFusedLdsBudget = 160 * 1024;
+static size_t fused_stage_bytes(int D, int sg) { return (size_t)sg * 32 * (D + 1) * sizeof(float) + (size_t)sg * 32 * sizeof(int); }
+// register budget: L * KSTEPS residual values per lane -> D <= 32 (KSTEPS <= 16) only
+static bool fused_fits(int D, int K, int L) {
+    return D <= 32 && L <= kFusedMaxL && (size_t)K * D * sizeof(float) + fused_stage_bytes(D, 1) <= kFusedLdsBudget;
+}
+// waves staged at a time: as many as fit next to ONE level's table (8, 4, 2 or 1)
+static int fused_stage_waves(int D, int K) {
+    int sg = kFusedWaves;
+    while (sg > 1 && (size_t)K * D * sizeof(float) + fused_stage_bytes(D, sg) > kFusedLdsBudget) sg >>= 1;
+    return sg;
+}
+// levels whose LDS tables fit together: the fused kernel runs once per such group
+static int fused_levels_per_pass(int D, int K, int L) {
+    const size_t left = kFusedLdsBudget - fused_stage_bytes(D, fused_stage_waves(D, K));
+    int n = (int)(left / ((size_t)K * D * sizeof(float)));
+    return n < 1 ? 1 : (n > L ? L : n);
+}
+
+// flat kernel (EVAL / STE): rows per workgroup and round, LDS per level of the launch, launch geometry
+static bool flat_shape_ok(int D, int L) { return D % 4 == 0 && D <= kFlatMaxD && L <= kFusedMaxL; }
+// (the flat kernel addresses rows with 32-bit byte offsets)
+static bool flat_offsets_ok(long long B, int D) {
+    return (unsigned long long)B * 8ull <= 0xffffffffull && (unsigned long long)B * D * 4ull <= 0xffffffffull;
+}
+static int flat_rows(int D) { return kFlatRowThreads / (D / 4); }
+static size_t flat_level_bytes(int D, int K) {   // one level's table + its share of the two stage buffers and key arrays
+    const size_t R = flat_rows(D);
+    return (size_t)K * D * sizeof(float) + 2 * R * D * sizeof(float) + 6 * R * sizeof(int) + kFlatTagBytesPerLevel;
+}
+static bool flat_fits(int D, int K, int L) {
+    return flat_shape_ok(D, L) && flat_level_bytes(D, K) <= kFusedLdsBudget;
+}
+static int flat_levels_per_pass(int D, int K, int L) {
+    const int n = (int)(kFusedLdsBudget / flat_level_bytes(D, K));
+    return n < 1 ? 1 : (n > L ? L : n);
+}
+static int flat_wgs(long long B, int D) {
+    const long long R = flat_rows(D);
+    long long g = (B + R - 1) / R;
+    const long long cap = cu_count();
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int scatter_wgs(long long B) {
+    long long g = (B + 255) / 256;
+    if (g > kMaxScatterWgs) g = kMaxScatterWgs;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static bool scatter_fits_lds(int D, int K) { return (size_t)K * (D + 1) * sizeof(float) <= kScatterLdsBudget; }
+
+template <int KSTEPS>
+static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
+    switch (mode) {
+        case RQHIP_MODE_EVAL:
+            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_EVAL>), dim3(grid), dim3(256), 0, s, p);
+            break;
+        case RQHIP_MODE_STE:
+            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_STE>), dim3(grid), dim3(256), 0, s, p);
+            break;
+        case RQHIP_MODE_ROTATION:
+            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_ROTATION>), dim3(grid), dim3(256), 0, s, p);
+            break;
+        default:
+            set_error("rq_backward: unsupported mode %d", mode);
+            return RQHIP_EARG;
+    }
+    RQ_CHECK_LAUNCH("rq_backward_kernel");
+    return 0;
+}
+
+}  // namespace rqhip
+
+using namespace rqhip;
+
+// which path rqhip_rq_backward takes for 16-byte aligned tensors: returns 1 and the geometry that fixes the summation
+// order of the codebook gradient (workgroups, row units per workgroup and round, rows per unit) when it is accumulated
+// in the order restated by the oracle, 0 for the three-kernel path
+extern "C" int rqhip_rq_backward_plan(int64_t B, int D, int L, int K, int mode, int *n_wg, int *units_per_wg,
+                                      int *unit_rows) {
+    const bool ok = B > 0 && D >= 1 && K >= 1 && L >= 1;
+    const bool flat = ok && mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L) && flat_offsets_ok(B, D);
+    const bool fused = ok && !flat && fused_fits(D, K, L);
+    if (n_wg) *n_wg = flat ? flat_wgs(B, D) : fused ? fused_wgs(B) : 0;
+    if (units_per_wg) *units_per_wg = flat ? 1 : fused ? kFusedWaves : 0;
+    if (unit_rows) *unit_rows = flat ? flat_rows(D) : fused ? 32 : 0;
+    return (flat || fused) ? 1 : 0;
+}
+
+// layout: [L,B,D] row scratch | [G, L*K*D] per-workgroup partial tables (LDS scatter path only)
+extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int K) {
+    if (B <= 0 || D <= 0 || L <= 0 || K <= 0) return 16;
+    const size_t rows = (size_t)L * (size_t)B * (size_t)D * sizeof(float);
+    size_t g = 0;   // per-workgroup partial tables: the most any path of this shape launches
+    if (fused_fits(D, K, L)) g = (size_t)fused_wgs(B);
+    if (flat_fits(D, K, L) && (size_t)flat_wgs(B, D) > g) g = (size_t)flat_wgs(B, D);
+    if (scatter_fits_lds(D, K) && (size_t)scatter_wgs(B) > g) g = (size_t)scatter_wgs(B);
+    return rows + g * (size_t)L * K * D * sizeof(float);
+}
+
+extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                                 int mode, float beta, const int64_t *ids, const float *g_embs,
+                                 const float *g_embsum, const float *g_resid, const float *g_loss,
+                                 float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
+                                 rqhip_stream_t stream) {
+    if (B < 0 || !codebooks || (B > 0 && (!res0 || !ids))) {
+        set_error("rq_backward: null pointer or negative B");
+        return RQHIP_EARG;
+    }
+    if (D < 1 || D > 128 || K < 1 || K > 65536 || L < 1 || L > 16) {
+        set_error("rq_backward: unsupported shape D=%d K=%d L=%d", D, K, L);
+        return RQHIP_EUNSUPPORTED;
+    }
+    if (mode != RQHIP_MODE_EVAL && mode != RQHIP_MODE_STE && mode != RQHIP_MODE_ROTATION) {
+        set_error("rq_backward: mode %d is not EVAL/STE/ROTATION", mode);
+        return RQHIP_EARG;
+    }
+    if (B > 0 && (!workspace || workspace_bytes < rqhip_rq_backward_workspace_bytes(B, D, L, K))) {
+        set_error("rq_backward: workspace too small");
+        return RQHIP_EWORKSPACE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool lds_path = scatter_fits_lds(D, K);
+    if (g_codebooks && (B == 0 || !lds_path))
+        if (int rc = fill_words(g_codebooks, 0u, sizeof(float) * (size_t)L * K * D, s)) return rc;
+    if (B == 0) return RQHIP_OK;
+    RqBwdParams p;
+    p.res0 = res0; p.cb = codebooks; p.ids = ids; p.g_embs = g_embs; p.g_embsum = g_embsum;
+    p.g_resid = g_resid; p.g_loss = g_loss; p.g_res0 = g_res0; p.g_cb = g_codebooks;
+    p.ws = reinterpret_cast<float *>(workspace);
+    p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.beta = beta;
+    p.atomic_scatter = lds_path ? 0 : 1;
+#ifdef RQ_BWD_PROBE
+    p.probe = getenv("RQ_BWD_PROBE") ? atoi(getenv("RQ_BWD_PROBE")) : 0;
+#endif
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (mode != RQHIP_MODE_ROTATION && flat_fits(D, K, L) && flat_offsets_ok(B, D) && al16(res0) && al16(codebooks) &&
+        al16(g_embs) && al16(g_embsum) && al16(g_resid) && al16(g_res0) && al16(workspace)) {
+        const int R = flat_rows(D), LPR = D / 4;
+        const int G = flat_wgs(B, D);
+        float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
+        const int per_pass = g_codebooks ? flat_levels_per_pass(D, K, L) : L;
+        for (int l0 = 0; l0 < L; l0 += per_pass) {
+            p.l_begin = l0;
+            p.l_end = (l0 + per_pass < L) ? l0 + per_pass : L;
+            p.write_rows = (l0 == 0);
+            const int nl = p.l_end - p.l_begin;
+            const int LKD = nl * K * D;
+            const size_t lds = g_codebooks ? (size_t)nl * flat_level_bytes(D, K) : 0;
+            auto go = [&](auto kern, int owner_waves) -> int {
+                static LdsGrant grant;
+                RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kFusedLdsBudget));
+                hipLaunchKernelGGL(kern, dim3(G), dim3(kFlatRowThreads + 64 * owner_waves), lds, s, p, partial, LKD, R, LPR);
+                RQ_CHECK_LAUNCH("rq_backward_flat_kernel");
+                return 0;
+            };
+            // the training step's shape of upstream gradients and the two level counts of the named configurations get
+            // their own instantiations; everything else runs the generic one
+            const bool train = g_embsum && g_loss && !g_embs && !g_resid;
+            // (3 levels in one launch: 3 x 256 x 32; 4 levels, one per launch: 4 x 1024 x 32)
+            const int nlv = !train || !g_codebooks || D != 32 ? 0 : (L == 3 && nl == 3) ? 3 : (L == 4 && nl == 1) ? 4 : 0;
+            int rcf;
+            // <MODE, NL, TRAIN, NLP, CPW, EXACT, OW>: 8 owner waves with one chunk each where the rows role fits 128
+            // registers (three levels), 4 owner waves with two / up to four chunks per lane otherwise
+#define RQ_FLAT_GO(M)                                                                                                 \
+    (nlv == 3 ? go(rq_backward_flat_kernel<M, 3, true, 3, 1, true, 8>, 8)                                             \
+              : nlv == 4 ? go(rq_backward_flat_kernel<M, 4, true, 1, 2, true, 4>, 4)                                  \
+                         : go(rq_backward_flat_kernel<M, 0, false, 0, 4, false, 4>, 4))
+            rcf = mode == RQHIP_MODE_EVAL ? RQ_FLAT_GO(RQHIP_MODE_EVAL) : RQ_FLAT_GO(RQHIP_MODE_STE);
+#undef RQ_FLAT_GO
+            if (rcf) return rcf;
+            if (!g_codebooks) break;  // nothing to scatter: the first launch has written g_res0
+            hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD,
+                               g_codebooks + (size_t)l0 * K * D);
+            RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+        }
+        return RQHIP_OK;
+    }
+    if (fused_fits(D, K, L)) {
+        const int G = fused_wgs(B);
+        float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
+        const bool vec = D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) &&
+                         al16(g_resid) && al16(g_res0);
+        // one launch per group of levels whose tables fit LDS together (all of them for 3 x 256 x 32; one level at a
+        // time for K = 1024): every launch replays the cheap register chain, the first one writes g_res0
+        const int per_pass = g_codebooks ? fused_levels_per_pass(D, K, L) : L;
+        for (int l0 = 0; l0 < L; l0 += per_pass) {
+            p.l_begin = l0;
+            p.l_end = (l0 + per_pass < L) ? l0 + per_pass : L;
+            p.write_rows = (l0 == 0);
+            const int nl = p.l_end - p.l_begin;
+            const int LKD = nl * K * D;
+            const int sg = fused_stage_waves(D, K);
+            const size_t lds = g_codebooks ? (size_t)nl * K * D * sizeof(float) + fused_stage_bytes(D, sg) : 0;
+            auto go = [&](auto kern) -> int {
+                static LdsGrant grant;
+                RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kFusedLdsBudget));
+                hipLaunchKernelGGL(kern, dim3(G), dim3(kFusedThreads), lds, s, p, partial, LKD, sg);
+                RQ_CHECK_LAUNCH("rq_backward_fused_kernel");
+                return 0;
+            };
+            int rcf = RQHIP_EARG;
+#define RQ_FUSED_MODES(KS)                                                                                            \
+    switch (mode) {                                                                                                   \
+        case RQHIP_MODE_EVAL:                                                                                         \
+            rcf = vec ? go(rq_backward_fused_kernel<KS, RQHIP_MODE_EVAL, true>)                                       \
+                      : go(rq_backward_fused_kernel<KS, RQHIP_MODE_EVAL, false>);                                     \
+            break;                                                                                                    \
+        case RQHIP_MODE_STE:                                                                                          \
+            rcf = vec ? go(rq_backward_fused_kernel<KS, RQHIP_MODE_STE, true>)                                        \
+                      : go(rq_backward_fused_kernel<KS, RQHIP_MODE_STE, false>);                                      \
+            break;                                                                                                    \
+        default:                                                                                                      \
+            rcf = vec ? go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION, true>)                                   \
+                      : go(rq_backward_fused_kernel<KS, RQHIP_MODE_ROTATION, false>);                                 \
+            break;                                                                                                    \
+    }
+            switch (ksteps_for(D)) {
+                case 4: RQ_FUSED_MODES(4) break;
+                case 8: RQ_FUSED_MODES(8) break;
+                default: RQ_FUSED_MODES(16) break;
+            }
+#undef RQ_FUSED_MODES
+            if (rcf) return rcf;
+            if (!g_codebooks) break;  // nothing to scatter: the first launch has written g_res0
+            hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD,
+                               g_codebooks + (size_t)l0 * K * D);
+            RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+        }
+        return RQHIP_OK;
+    }
+
+    long long want = (p.n_tiles + 3) / 4;
+    long long cap = (long long)cu_count() * 8;
+    const int grid = (int)(want < cap ? want : cap);
+    int rc;
+    switch (ksteps_for(D)) {
+        case 4: rc = launch_bwd<4>(p, mode, grid, s); break;
+        case 8: rc = launch_bwd<8>(p, mode, grid, s); break;
+        case 16: rc = launch_bwd<16>(p, mode, grid, s); break;
+        case 32: rc = launch_bwd<32>(p, mode, grid, s); break;
+        default: rc = launch_bwd<64>(p, mode, grid, s); break;
+    }
+    if (rc || !g_codebooks || !lds_path) return rc;
+
+    // embedding backward: LDS-private scatter in groups of whole levels, then a fixed-order reduce
+    const int G = scatter_wgs(B);
+    const long long rows_per_wg = (B + G - 1) / G;
+    const int LKD = L * K * D;
+    float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
+    int DR = 1;
+    while (DR < D) DR <<= 1;
+    const size_t level_bytes = (size_t)K * (D + 1) * sizeof(float);
+    int per_pass = (int)(kScatterLdsBudget / level_bytes);
+    if (per_pass < 1) per_pass = 1;
+    static LdsGrant scatter_grant;
+    RQ_RETURN_IF_HIP(scatter_grant.ensure(reinterpret_cast<const void *>(rq_cbgrad_scatter_kernel), (int)kScatterLdsBudget));
+    for (int l0 = 0; l0 < L; l0 += per_pass) {
+        const int nl = (L - l0 < per_pass) ? L - l0 : per_pass;
+        hipLaunchKernelGGL(rq_cbgrad_scatter_kernel, dim3(G), dim3(256), nl * level_bytes, s, p.ws, ids, (long long)B,
+                           D, DR, K, l0, nl, rows_per_wg, partial, LKD);
+        RQ_CHECK_LAUNCH("rq_cbgrad_scatter_kernel");
+    }
+    hipLaunchKernelGGL(rq_cbgrad_reduce_kernel, dim3((LKD + 63) / 64), dim3(256), 0, s, partial, G, LKD, g_codebooks);
+    RQ_CHECK_LAUNCH("rq_cbgrad_reduce_kernel");
+    return RQHIP_OK;
+}

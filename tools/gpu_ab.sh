@@ -2,7 +2,7 @@
 # One gpurun call of a development round: the tests of the kernel that changed, then kernel durations (rocprofv3
 # --kernel-trace --stats) of the product build vs tools/_ab builds.   gpurun --timeout 600 -- 'bash tools/gpu_ab.sh'
 O=gpurun_out/ab; mkdir -p $O; R=$GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_gpu_parity.py -k "backward" -x -q > $O/pytest_bwd.log 2>&1; grep -E "passed|failed|error" $O/pytest_bwd.log | tail -2
+timeout 400 python -m pytest tests -m gpu -x -q > $O/pytest_all.log 2>&1; grep -E "passed|failed|error" $O/pytest_all.log | tail -3
 for lib in "" tools/_ab/librqhip_bwdold.so; do
   timeout 120 python tools/bench_kernels.py bwd --reps 50 ${lib:+--lib $lib} 2>&1 | grep -E "bwd|library"
 done | tee $O/bench_bwd.log
