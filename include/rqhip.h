@@ -314,7 +314,7 @@ int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_
  *   rqhip_weight_planes : split a weight matrix w [rows, cols] once per step into the kernel's image.  transpose = 0: the
  *       image of w itself (Nc = rows output columns, reduction R = cols: the forward, C = A w^T); transpose = 1: of w^T
  *       (Nc = cols, R = rows: the data gradient, C = A w).  `planes`: rqhip_weight_planes_bytes(Nc, R) bytes, caller-owned.
- *   rqhip_gemm_split    : C [M, Nc] = A [M, R] . image^T, optional ReLU.  Needs Nc % 256 == 0, R % 16 == 0
+ *   rqhip_gemm_split    : C [M, Nc] = A [M, R] . image^T, optional ReLU.  Needs Nc % 128 == 0 (256-column tiles when Nc % 256 == 0, else 128), R % 16 == 0
  *       (rqhip_gemm_split_supported), 16-byte aligned pointers; one launch at a time per image (it holds the kernel's
  *       tile dispenser).  Results are bit-reproducible; accuracy against fp64 is that of an fp32 GEMM (tests).
  */

@@ -17,7 +17,8 @@
 //     one row of A / one row of B): no transposition.  The weight is split ONCE per step by `weight_planes_kernel` into
 //     the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage is three contiguous 4 KB runs.
 //   * tile = 256 rows x 256 columns (8 waves of 128 x 64) for whole rounds of the chip, 64 x 256 (8 waves of 32 x 64) for
-//     what is left over; 16-deep stages through a double-buffered LDS image, loads two stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
+//     what is left over; layers with 128 (mod 256) output columns take 256 x 128 tiles (8 waves of 64 x 64) and 128 x 128
+//     for the leftover; 16-deep stages through a double-buffered LDS image, loads two stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
 //     tiles on 512 slots; a static round-robin would leave the last round a tenth full).
 //   * results do not depend on which workgroup computes a tile: bit-reproducible run to run.
 #include "rqhip_common.h"
@@ -32,7 +33,7 @@ typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsCols = 256, kGsThreads = 512, kGsK = 16;   // rows per tile: 64 TA (256 or 64)
+constexpr int kGsThreads = 512, kGsK = 16;   // tile: COLS = 256 or 128 columns, (8 / (COLS / 64)) * 32 * TA rows
 #ifndef GS_XCD_GROUP
 #define GS_XCD_GROUP 0
 #endif
@@ -93,15 +94,17 @@ struct GemmSplitParams {
     float row_scale;
 };
 
-// one output tile of 64 TA rows x 256 columns: 8 waves of (32 TA) x 64
+// one output tile of ROWS x COLS: 8 waves of (32 TA) x 64, WN = COLS / 64 of them side by side
 // EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss (see GemmSplitParams)
-template <int EPI, int TA>
+template <int EPI, int TA, int COLS>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
-    constexpr int ROWS = 64 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
+    constexpr int kGsCols = COLS, WN = COLS / 64, WM = 8 / WN;
+    constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
     constexpr int PA = 3 * 2 * ROWS * 4, PB = 3 * 2 * kGsCols * 4;                 // dwords per stage image
+    constexpr int BQ = (6 * kGsCols + kGsThreads - 1) / kGsThreads;                // 16-byte elements of B per thread and stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 31, h = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int n_stage = p.R / kGsK;
     // staging roles: A -- thread (row = tid >> 2 (+ 128 q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
     // 16-byte elements of the stage's weight image per thread
@@ -125,7 +128,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
     gs_f32x4 ra0[AQ], ra1[AQ];   // rows of A: two stages in flight (requested two iterations before they are split)
-    gs_u32x4 rb[3];
+    gs_u32x4 rb[BQ];
     auto fetchA = [&](int stage, gs_f32x4 *dst) {
         if ((GS_PROBE & 16) && stage > 1) return;
 #pragma unroll
@@ -137,12 +140,13 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     auto fetchB = [&](int stage) {
         if ((GS_PROBE & 16) && stage > 1) return;
         // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
-        // (piece, half) rows: element e = tid + 512 q  ->  (ph = e >> 8, col = e & 255)
+        // (piece, half) rows: element e = tid + 512 q  ->  (ph = e / COLS, col = e % COLS)
         const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < BQ; ++q) {
             const int e = tid + kGsThreads * q;
-            if (!((GS_PROBE & 64) && stage > 1)) rb[q] = img[(size_t)(e >> 8) * p.Nc + (e & 255)];
+            if ((6 * kGsCols) % kGsThreads != 0 && e >= 6 * kGsCols) continue;
+            if (!((GS_PROBE & 64) && stage > 1)) rb[q] = img[(size_t)(e / kGsCols) * p.Nc + (e % kGsCols)];
         }
     };
     auto stash = [&](int buf, const gs_f32x4 *ra) {
@@ -166,8 +170,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
             *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < BQ; ++q) {
             const int e = tid + kGsThreads * q;
+            if ((6 * kGsCols) % kGsThreads != 0 && e >= 6 * kGsCols) continue;
             *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
         }
     };
@@ -287,6 +292,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     if (EPI == 2) {
         // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
         // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
+        static_assert(EPI != 2 || WN == 4, "the reconstruction-loss epilogue sums four column waves");
         float *red = reinterpret_cast<float *>(sbuf);          // [4][ROWS]
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
@@ -301,8 +307,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     }
 }
 
-template <int EPI>
+template <int EPI, int COLS>
 __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
+    constexpr int kBigRows = 256, kSmallRows = (8 / (COLS / 64)) * 32;   // 64 (COLS = 256) or 128 (COLS = 128)
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
     __shared__ unsigned s_tile;
@@ -331,11 +338,11 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
             const unsigned grp = 8u * (unsigned)p.n_col_tiles, g = tile / grp, in = tile % grp;
             if ((g + 1) * grp <= p.n_big) { rt = (int)(g * 8u + (in & 7u)); ct = (int)(in >> 3); }
 #endif
-            gs_tile<EPI, 4>(p, sbuf, (long long)rt * 256, ct * kGsCols);
+            gs_tile<EPI, kBigRows / kSmallRows, COLS>(p, sbuf, (long long)rt * kBigRows, ct * COLS);
         } else {
             const unsigned st = tile - p.n_big;
             const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
-            gs_tile<EPI, 1>(p, sbuf, (long long)p.rt_big * 256 + (long long)rt * 64, ct * kGsCols);
+            gs_tile<EPI, 1, COLS>(p, sbuf, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
         }
     }
 }
@@ -354,7 +361,8 @@ __global__ __launch_bounds__(256) void recon_rows_finish_kernel(const float *__r
 
 using namespace rqhip;
 
-extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R > 0 && Nc % kGsCols == 0 && R % kGsK == 0) ? 1 : 0; }
+static int gs_cols(int Nc) { return Nc % 256 == 0 ? 256 : 128; }   // tile width
+extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R > 0 && Nc % 128 == 0 && R % kGsK == 0) ? 1 : 0; }
 
 extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) {
     if (!rqhip_gemm_split_supported(Nc, R)) return 0;
@@ -366,7 +374,7 @@ extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int trans
     // w is [rows, cols] row-major.  transpose == 0: B = w (Nc = rows, R = cols); transpose == 1: B = w^T (Nc = cols, R = rows)
     const int Nc = transpose ? cols : rows, R = transpose ? rows : cols;
     if (!w || !planes || !rqhip_gemm_split_supported(Nc, R) || planes_bytes < rqhip_weight_planes_bytes(Nc, R)) {
-        set_error("weight_planes: bad arguments or unsupported shape (Nc = %d must be a multiple of 256, R = %d of 16)", Nc, R);
+        set_error("weight_planes: bad arguments or unsupported shape (Nc = %d must be a multiple of 128, R = %d of 16)", Nc, R);
         return RQHIP_EARG;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -387,21 +395,21 @@ extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *pl
 }
 
 extern "C" size_t rqhip_gemm_split_recon_workspace_bytes(int64_t M, int Nc) {
-    return (M > 0 && Nc > 0 && Nc % kGsCols == 0) ? (size_t)(Nc / kGsCols) * (size_t)M * sizeof(float) : 0;
+    return (M > 0 && Nc > 0 && Nc % 256 == 0) ? (size_t)(Nc / 256) * (size_t)M * sizeof(float) : 0;
 }
 
 extern "C" int rqhip_gemm_split_recon(const float *A, int64_t M, int R, const void *planes, int Nc, const float *X,
                                       float row_scale, float *G, float *loss_rows, void *workspace, size_t workspace_bytes,
                                       rqhip_stream_t stream) {
-    if (M > 0 && (!X || !G || !loss_rows || !workspace || workspace_bytes < rqhip_gemm_split_recon_workspace_bytes(M, Nc) ||
-                  (reinterpret_cast<uintptr_t>(X) & 15u) != 0)) {
+    if (M > 0 && (!X || !G || !loss_rows || !workspace || Nc % 256 != 0 ||
+                  workspace_bytes < rqhip_gemm_split_recon_workspace_bytes(M, Nc) || (reinterpret_cast<uintptr_t>(X) & 15u) != 0)) {
         set_error("gemm_split_recon: bad arguments (X, G, loss_rows, workspace of rqhip_gemm_split_recon_workspace_bytes)");
         return RQHIP_EARG;
     }
     const int rc = gemm_split_launch(A, M, R, planes, Nc, 2, G, 0, X, row_scale, reinterpret_cast<float *>(workspace), stream);
     if (rc != RQHIP_OK || M == 0) return rc;
     hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(workspace), Nc / kGsCols,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(workspace), Nc / 256,
                        (long long)M, loss_rows);
     RQ_CHECK_LAUNCH("recon_rows_finish_kernel");
     return RQHIP_OK;
@@ -424,9 +432,10 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
     p.X = X; p.rowsum = rowsum; p.row_scale = row_scale;
     const int cus = cu_count();
-    p.n_col_tiles = Nc / kGsCols;
-    // whole rounds of 256-row tiles, the remainder as 64-row tiles (see the kernel); flags_tile (tools only): 256 = big
-    // tiles for every row, 64 = small tiles for every row
+    const int cols = gs_cols(Nc), small_rows = cols == 256 ? 64 : 128;
+    p.n_col_tiles = Nc / cols;
+    // whole rounds of 256-row tiles, the remainder as 64-row (128-row for the 128-column tile) tiles (see the kernel);
+    // flags_tile (tools only): 256 = big tiles for every row, 64 = small tiles for every row
     const long long rt256 = (M + 255) / 256;
     long long rt_big = ((rt256 * p.n_col_tiles) / cus) * cus / p.n_col_tiles;   // row tiles of the whole rounds
     if (rt_big * 256 > M) rt_big = M / 256;
@@ -436,14 +445,14 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     if (flags_tile == 256) rt_big = rt256;
     if (flags_tile == 64) rt_big = 0;
     const long long rem_rows = M - rt_big * 256 > 0 ? M - rt_big * 256 : 0;
-    const long long rt_small = (rem_rows + 63) / 64;
+    const long long rt_small = (rem_rows + small_rows - 1) / small_rows;
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_planes, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 6 * Nc * 4;
-    const size_t lds = (size_t)2 * (3 * 2 * (256 + kGsCols) * 16);
+    const size_t lds = (size_t)2 * (3 * 2 * (256 + cols) * 16);
     const long long tiles = (long long)p.n_tiles;
     const long long slots = (long long)cus;                // one workgroup per CU (240 VGPRs x 512 threads)
     const int grid = (int)(tiles < slots ? tiles : slots);
@@ -454,5 +463,12 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
         RQ_CHECK_LAUNCH("gemm_split_kernel");
         return 0;
     };
-    return epi == 2 ? go(gemm_split_kernel<2>) : epi == 1 ? go(gemm_split_kernel<1>) : go(gemm_split_kernel<0>);
+    if (cols == 128) {
+        if (epi == 2) {
+            set_error("gemm_split: the reconstruction-loss epilogue needs Nc %% 256 == 0 (Nc = %d)", Nc);
+            return RQHIP_EARG;
+        }
+        return epi == 1 ? go(gemm_split_kernel<1, 128>) : go(gemm_split_kernel<0, 128>);
+    }
+    return epi == 2 ? go(gemm_split_kernel<2, 256>) : epi == 1 ? go(gemm_split_kernel<1, 256>) : go(gemm_split_kernel<0, 256>);
 }

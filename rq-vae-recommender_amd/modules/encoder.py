@@ -189,6 +189,7 @@ class MLP(nn.Module):
                 and target.is_cuda and target.dtype == torch.float32 and not target.requires_grad
                 and tuple(target.shape) == (z.shape[0], last.out_features) and target.is_contiguous()
                 and target.data_ptr() % 16 == 0
+                and last.out_features % 256 == 0   # (the fused epilogue sums four 64-column waves: 256-column tiles only)
                 and _lin.split_shape_ok(z.shape[0], last.out_features, last.in_features)):
             return None
         assert z.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {z.shape[-1]}"

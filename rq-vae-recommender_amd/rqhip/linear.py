@@ -28,12 +28,21 @@ def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool = False) -> 
     """Does this GEMM (x [M, n_red] against a weight image of n_cols columns) take the bf16-split kernel?"""
     del forward_relu   # (round 3 excluded the first encoder layer's forward here; see the note above)
     return bool(_SPLIT_GEMMS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
-                and x.shape[0] >= _SPLIT_MIN_ROWS and x.is_contiguous() and ops.gemm_split_supported(n_cols, n_red))
+                and x.shape[0] >= _SPLIT_MIN_ROWS and x.is_contiguous() and _wide(n_cols)
+                and ops.gemm_split_supported(n_cols, n_red))
+
+
+def _wide(n_cols: int) -> bool:
+    """Layers of 256 (mod 256) output columns only.  The kernel also has a 256 x 128 tile for 128 (mod 256) columns
+    (csrc/gemm_split.hip, tested), but the layers that would take it are HBM-bound at these widths and the library is as
+    fast: 100 000 x 256 -> 128 forward 58 us vs 67, its data gradient 59 vs 56, 100 000 x 32 -> 128 24 vs 25 -- and every use
+    adds the 6 us image rebuild (round 3, tools/bench_gemm_split.py)."""
+    return n_cols % 256 == 0
 
 
 def split_shape_ok(rows: int, n_cols: int, n_red: int) -> bool:
     """`split_ok` for a contiguous fp32 ROCm operand of `rows` rows that does not exist yet."""
-    return bool(_SPLIT_GEMMS and rows >= _SPLIT_MIN_ROWS and ops.gemm_split_supported(n_cols, n_red))
+    return bool(_SPLIT_GEMMS and rows >= _SPLIT_MIN_ROWS and _wide(n_cols) and ops.gemm_split_supported(n_cols, n_red))
 
 
 def planes(w: Tensor, transpose: bool) -> Tensor:

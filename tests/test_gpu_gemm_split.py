@@ -6,7 +6,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(512, 768), (768, 512), (256, 512), (512, 256)]     # (Nc, R) of the large layers, both directions
+SHAPES = [(512, 768), (768, 512), (256, 512), (512, 256),    # (Nc, R) of the large layers, both directions
+          (128, 256), (128, 32), (384, 64)]                   # 128 (mod 256) columns: the 256 x 128 tile
 
 
 def _check(a, w, transpose, relu):
@@ -53,7 +54,13 @@ def test_gemm_split_ragged_rows_and_scales(M):
     bound = a.double().abs() @ w.double().abs().t() * (768 ** 0.5 + 8) * 2.0 ** -24 + 1e-30
     assert ((c.double() - ref).abs() <= bound).all(), float(((c.double() - ref).abs() / bound).max())
     with pytest.raises(ops.RqHipError):
-        ops.weight_planes(torch.zeros(100, 768, device="cuda"))          # Nc not a multiple of 256
+        ops.weight_planes(torch.zeros(100, 768, device="cuda"))          # Nc not a multiple of 128
+    # the 128-column tile (its leftover tiles are 128 rows high), same bound
+    w2 = (torch.randn(128, 768, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (128, 1), generator=g).float())).cuda()
+    c2 = ops.gemm_split(a, ops.weight_planes(w2), 128, relu=True)
+    ref2 = torch.relu(a.double() @ w2.double().t())
+    bound2 = a.double().abs() @ w2.double().abs().t() * (768 ** 0.5 + 8) * 2.0 ** -24 + 1e-30
+    assert ((c2.double() - ref2).abs() <= bound2).all()
 
 
 @pytest.mark.parametrize("M", [100_000, 5003, 77])

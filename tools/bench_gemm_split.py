@@ -33,17 +33,21 @@ def timeit(fn, n=20):
 
 
 print(f"{'layer W [N,K]':>14} {'GFLOP':>6} | {'fwd lib(relu)':>13} {'fwd split 256/auto':>17} | {'dgrad lib':>9} {'dgrad split 256/auto':>19} | planes us")
-for N, K in [(512, 768), (256, 512), (512, 256), (768, 512)]:
+for N, K in [(512, 768), (256, 512), (512, 256), (768, 512), (128, 256), (256, 128), (128, 32)]:
     x = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     g = torch.randn(M, N, device="cuda")
     zb = torch.zeros(N, device="cuda")
     gf = 2.0 * M * N * K / 1e9
     t_lib_f = timeit(lambda: torch._addmm_activation(zb, x, w.t()))
-    pf, pb = ops.weight_planes(w), None
-    t_planes = timeit(lambda: ops.weight_planes(w))
-    t_spl_f = timeit(lambda: ops.gemm_split(x, pf, N, relu=True, tile_rows=256))
-    t_spl_f2 = timeit(lambda: ops.gemm_split(x, pf, N, relu=True))
+    pb = None
+    if ops.gemm_split_supported(N, K):
+        pf = ops.weight_planes(w)
+        t_planes = timeit(lambda: ops.weight_planes(w))
+        t_spl_f = timeit(lambda: ops.gemm_split(x, pf, N, relu=True, tile_rows=256))
+        t_spl_f2 = timeit(lambda: ops.gemm_split(x, pf, N, relu=True))
+    else:
+        t_planes = t_spl_f = t_spl_f2 = float("nan")
     t_lib_b = timeit(lambda: g.mm(w))
     if ops.gemm_split_supported(K, N):
         pb = ops.weight_planes(w, transpose=True)
