@@ -33,7 +33,11 @@ typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsThreads = 512, kGsK = 16;   // tile: COLS = 256 or 128 columns, (8 / (COLS / 64)) * 32 * TA rows
+#ifndef GS_WAVES   // 4 (developer A/B builds): one wave per SIMD with 128-column wave tiles and a 512-register budget
+#define GS_WAVES 8
+#endif
+constexpr int kGsWaves = GS_WAVES, kGsUB = 16 / GS_WAVES;   // a wave's tile is (32 TA) x (32 UB): UB = 2 (8 waves) or 4 (4 waves)
+constexpr int kGsThreads = 64 * kGsWaves, kGsK = 16;   // tile: COLS = 256 or 128 columns, (waves / (COLS / (32 UB))) * 32 * TA rows
 #ifndef GS_XCD_GROUP
 #define GS_XCD_GROUP 0
 #endif
@@ -98,7 +102,7 @@ struct GemmSplitParams {
 // EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss (see GemmSplitParams)
 template <int EPI, int TA, int COLS>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
-    constexpr int kGsCols = COLS, WN = COLS / 64, WM = 8 / WN;
+    constexpr int kGsCols = COLS, UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
     constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
     constexpr int PA = 3 * 2 * ROWS * 4, PB = 3 * 2 * kGsCols * 4;                 // dwords per stage image
     constexpr int BQ = (6 * kGsCols + kGsThreads - 1) / kGsThreads;                // 16-byte elements of B per thread and stage
@@ -106,24 +110,25 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     const int il = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int n_stage = p.R / kGsK;
-    // staging roles: A -- thread (row = tid >> 2 (+ 128 q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
+    constexpr int APASS = kGsThreads / 4;                  // rows one staging pass of the workgroup covers
+    // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
     // 16-byte elements of the stage's weight image per thread
     const int arow = tid >> 2, akq = tid & 3;
     bool a_live[AQ], arow_ok[AQ];
     const float *asrc[AQ];
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
-        a_live[q] = arow + 128 * q < ROWS;
-        const long long arow_g = m0 + arow + 128 * q;
+        a_live[q] = arow + APASS * q < ROWS;
+        const long long arow_g = m0 + arow + APASS * q;
         arow_ok[q] = a_live[q] && arow_g < p.M;
         asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * ((GS_PROBE & 256) ? 16 : p.R) + 4 * akq;
     }
 
-    gs_f32x16 acc[TA][2];
+    gs_f32x16 acc[TA][UB];
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < UB; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
@@ -164,7 +169,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
             gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
             }
             // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
-            unsigned *d = dA + (((akq >> 1) * ROWS) + arow + 128 * q) * 4 + 2 * (akq & 1);
+            unsigned *d = dA + (((akq >> 1) * ROWS) + arow + APASS * q) * 4 + 2 * (akq & 1);
             *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * ROWS * 4) = gs_u32x2{h01, h23};
             *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * ROWS * 4) = gs_u32x2{m01, m23};
             *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
@@ -182,11 +187,11 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         // column half outer, row block inner: 12 + 12 operand registers live (the row blocks are read once per column half:
         // 30 instead of 18 LDS reads per stage, which the LDS has room for -- tools/gemm_probe.py, GS_PROBE 4)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UB; ++u) {
             gs_bf16x8 b[3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
-                b[pc] = bB[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * kGsCols + wn * 64 + ((GS_PROBE & 4) ? 0 : 32 * u) + il];
+                b[pc] = bB[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * kGsCols + wn * 32 * UB + ((GS_PROBE & 4) ? 0 : 32 * u) + il];
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
                 gs_bf16x8 a[3];
@@ -265,10 +270,10 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         const long long row = m0 + 32 * TA * wm + 32 * t + il;
         rowsq[t] = 0.0f;
         if (row < p.M && !(GS_PROBE & 512)) {
-            float *dst = p.C + (size_t)row * p.Nc + n0 + 64 * wn + 4 * h;
-            const float *xs = EPI == 2 ? p.X + (size_t)row * p.Nc + n0 + 64 * wn + 4 * h : nullptr;
+            float *dst = p.C + (size_t)row * p.Nc + n0 + 32 * UB * wn + 4 * h;
+            const float *xs = EPI == 2 ? p.X + (size_t)row * p.Nc + n0 + 32 * UB * wn + 4 * h : nullptr;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < UB; ++u)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
@@ -292,17 +297,20 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     if (EPI == 2) {
         // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
         // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
-        static_assert(EPI != 2 || WN == 4, "the reconstruction-loss epilogue sums four column waves");
-        float *red = reinterpret_cast<float *>(sbuf);          // [4][ROWS]
+        float *red = reinterpret_cast<float *>(sbuf);          // [WN][ROWS]
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
             if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
         }
         __syncthreads();
-        if (tid < ROWS && m0 + tid < p.M)
-            p.rowsum[(size_t)(n0 / kGsCols) * p.M + m0 + tid] =
-                ((red[tid] + red[ROWS + tid]) + red[2 * ROWS + tid]) + red[3 * ROWS + tid];
+        for (int r = tid; r < ROWS; r += kGsThreads) {
+            if (m0 + r >= p.M) continue;
+            float sum = red[r];
+#pragma unroll
+            for (int w = 1; w < WN; ++w) sum = sum + red[w * ROWS + r];
+            p.rowsum[(size_t)(n0 / kGsCols) * p.M + m0 + r] = sum;
+        }
         // (the persistent loop's barrier at its top keeps the next tile's staging off `red`)
     }
 }
