@@ -134,7 +134,10 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 
     gs_f32x4 ra0[AQ], ra1[AQ];   // rows of A: two stages in flight (requested two iterations before they are split)
     gs_u32x4 rb[BQ];
+    // (both fetches are UNCONDITIONAL: past the last stage they re-read it.  A load inside `if (stage < n_stage)` makes the
+    // compiler's s_waitcnt insertion assume it may not have been issued, and the wait for the weight image then drains it)
     auto fetchA = [&](int stage, gs_f32x4 *dst) {
+        stage = stage < n_stage ? stage : n_stage - 1;
         if ((GS_PROBE & 16) && stage > 1) return;
 #pragma unroll
         for (int q = 0; q < AQ; ++q)
@@ -143,6 +146,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                          : *reinterpret_cast<const gs_f32x4 *>(asrc[q] + ((GS_PROBE & 128) ? (stage & 1) : stage) * ((GS_PROBE & 256) ? 256 * 1024 : kGsK));
     };
     auto fetchB = [&](int stage) {
+        stage = stage < n_stage ? stage : n_stage - 1;
         if ((GS_PROBE & 16) && stage > 1) return;
         // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
         // (piece, half) rows: element e = tid + 512 q  ->  (ph = e / COLS, col = e % COLS)
@@ -212,15 +216,21 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         }
     };
 
+    // Order of the requests inside an iteration: the weight image FIRST, then the A rows.  Loads complete in order
+    // (vmcnt): the next iteration waits for the image it stages, and with the A rows requested before it that wait also
+    // drained the A rows of the stage after -- their latency had ONE iteration to hide in, not two (phase-skipping probes:
+    // the kernel ran 86 us faster without its global loads although every one of them is issued 1-2 iterations early).
+    // (A third register set and LDS buffer -- A rows three iterations ahead -- do not fit: 8 more registers spill inside
+    // the stage loop, 535 vs 476 us.)
     // A rows are requested TWO iterations before they are split (scattered 64-byte pieces of 256 rows: their latency is
     // longer than one iteration's matrix work -- tools/gemm_probe.py: the kernel ran 17 % faster without them, 10 % with
     // cache hits), the weight image (L2-resident) one iteration before.
     fetchA(0, ra0);
     fetchB(0);
-    if (n_stage > 1) fetchA(1, ra1);
+    fetchA(1, ra1);
     stash(0, ra0);
-    if (n_stage > 2) fetchA(2, ra0);
-    if (n_stage > 1) fetchB(1);
+    fetchB(1);
+    fetchA(2, ra0);
     __syncthreads();
     // The two waves of a SIMD work OUT OF PHASE inside the barrier interval of a stage (as in csrc/wgrad_split.hip): the
     // first half of the workgroup's waves (one per SIMD) splits / stages first and multiplies second, the other half
@@ -232,32 +242,32 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     for (int c = 0; c < n_pair; c += 2) {
         if (stage_first) {
             stash(1, ra1);                             // stage c + 1
-            if (c + 3 < n_stage) fetchA(c + 3, ra1);
-            if (c + 2 < n_stage) fetchB(c + 2);
+            fetchB(c + 2);
+            fetchA(c + 3, ra1);
         }
         multiply(0);
         if (!stage_first) {
             stash(1, ra1);
-            if (c + 3 < n_stage) fetchA(c + 3, ra1);
-            if (c + 2 < n_stage) fetchB(c + 2);
+            fetchB(c + 2);
+            fetchA(c + 3, ra1);
         }
-        __syncthreads();
+        if (!(GS_PROBE & 1024)) __syncthreads();
         if (stage_first) {
-            if (c + 2 < n_stage) stash(0, ra0);       // stage c + 2
-            if (c + 4 < n_stage) fetchA(c + 4, ra0);
-            if (c + 3 < n_stage) fetchB(c + 3);
+            stash(0, ra0);                             // stage c + 2 (past the end: the last stage again, never multiplied)
+            fetchB(c + 3);
+            fetchA(c + 4, ra0);
         }
         multiply(1);
         if (!stage_first) {
-            if (c + 2 < n_stage) stash(0, ra0);
-            if (c + 4 < n_stage) fetchA(c + 4, ra0);
-            if (c + 3 < n_stage) fetchB(c + 3);
+            stash(0, ra0);
+            fetchB(c + 3);
+            fetchA(c + 4, ra0);
         }
-        __syncthreads();
+        if (!(GS_PROBE & 1024)) __syncthreads();
     }
     if (n_stage & 1) {                             // the last stage of an odd count lies in buffer 0
         multiply(0);
-        __syncthreads();
+        if (!(GS_PROBE & 1024)) __syncthreads();
     }
 
     // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
