@@ -275,13 +275,27 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // costs is its write traffic, 7-11 % of the kernel while every CU reaches its epilogue in the same phase of a round --
     // tools/gemm_probe.py, GS_PROBE 512)
     float rowsq[TA];
+    // EPI == 2 reads x beside every result it stores.  The compiler may not move a load above a store that could alias
+    // it, so with load / compute / store per 16 bytes every one of the 32 loads of a lane waited for its own latency AND
+    // for the store before it (the recon GEMM ran 547 us against 440 for the plain one).  The x values of a whole row
+    // block are therefore requested first, and those of the next block before this block's stores.
+    gs_f32x4 xv[2][UB * 4];
+    auto load_x = [&](int t, gs_f32x4 *dst) {
+        const long long row = m0 + 32 * TA * wm + 32 * t + il;
+        const float *xs = p.X + (size_t)(row < p.M ? row : p.M - 1) * p.Nc + n0 + 32 * UB * wn + 4 * h;
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dst[u * 4 + g] = *reinterpret_cast<const gs_f32x4 *>(xs + 32 * u + 8 * g);
+    };
+    if (EPI == 2 && !(GS_PROBE & 512)) load_x(0, xv[0]);
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const long long row = m0 + 32 * TA * wm + 32 * t + il;
         rowsq[t] = 0.0f;
+        if (EPI == 2 && t + 1 < TA && !(GS_PROBE & 512)) load_x(t + 1, xv[(t + 1) & 1]);
         if (row < p.M && !(GS_PROBE & 512)) {
             float *dst = p.C + (size_t)row * p.Nc + n0 + 32 * UB * wn + 4 * h;
-            const float *xs = EPI == 2 ? p.X + (size_t)row * p.Nc + n0 + 32 * UB * wn + 4 * h : nullptr;
 #pragma unroll
             for (int u = 0; u < UB; ++u)
 #pragma unroll
@@ -292,10 +306,10 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                         v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
                     }
                     if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
-                        const gs_f32x4 xv = *reinterpret_cast<const gs_f32x4 *>(xs + 32 * u + 8 * g);
+                        const gs_f32x4 x4 = xv[t & 1][u * 4 + g];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float d = v[j] - xv[j];
+                            const float d = v[j] - x4[j];
                             rowsq[t] = rowsq[t] + d * d;
                             v[j] = (2.0f * d) * p.row_scale;
                         }
