@@ -232,11 +232,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     fetchB(1);
     fetchA(2, ra0);
     __syncthreads();
-    // The two waves of a SIMD work OUT OF PHASE inside the barrier interval of a stage (as in csrc/wgrad_split.hip): the
-    // first half of the workgroup's waves (one per SIMD) splits / stages first and multiplies second, the other half
-    // multiplies first -- one wave of every SIMD is on the matrix cores while its partner is on the VALU / LDS / memory
-    // pipes.  With every wave in the same phase the split and the LDS writes of a stage were matrix-idle time.  Both
-    // phases write the buffer everybody left at the last barrier and read the other one.
+    // Every wave stages the next stage first, then multiplies the current one.  GS_PHASE = 1 (developer builds) puts the two
+    // waves of a SIMD OUT OF PHASE inside the barrier interval (one half of the waves stages first, the other multiplies
+    // first -- what helped csrc/wgrad_split.hip): measured 5-7 % slower here at every shape.
     const bool stage_first = GS_PHASE ? __builtin_amdgcn_readfirstlane(wave) < 4 : true;   // (scalar: a real branch)
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
