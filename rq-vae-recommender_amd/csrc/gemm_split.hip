@@ -49,6 +49,20 @@ constexpr int kGsThreads = 64 * kGsWaves, kGsK = 16;   // tile: COLS = 256 or 12
                    // 256: a tile's A stage is one contiguous 16 KB block (wrong data, same bytes), 512: no result stores)
 #endif
 
+#ifdef GS_TIMING
+// developer-only s_memtime stamps of every wave of workgroup 0 during its FIRST tile (tools/gemm_timing.py --build):
+// slot 0 tile start, 1 prologue barrier passed, then per half-iteration i (stage i multiplied): 2 + 4 i staged,
+// 3 + 4 i requests issued, 4 + 4 i multiplied, 5 + 4 i barrier passed
+__device__ unsigned long long gs_dbg[8 * 64];
+__device__ unsigned gs_dbg_armed = 1;
+#define GS_STAMP(i)                                                                                                   \
+    do {                                                                                                              \
+        if (gs_timed && (threadIdx.x & 63) == 0 && (i) < 64) gs_dbg[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GS_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
     const gs_bf16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_bf16x2);
     h = __builtin_bit_cast(unsigned, hh);
@@ -109,6 +123,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+#ifdef GS_TIMING
+    const bool gs_timed = blockIdx.x == 0 && TA == 4 && m0 < 256 * (long long)gridDim.x && gs_dbg_armed;   // the workgroup's first big tile
+#endif
     const int n_stage = p.R / kGsK;
     constexpr int APASS = kGsThreads / 4;                  // rows one staging pass of the workgroup covers
     // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
@@ -225,6 +242,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // A rows are requested TWO iterations before they are split (scattered 64-byte pieces of 256 rows: their latency is
     // longer than one iteration's matrix work -- tools/gemm_probe.py: the kernel ran 17 % faster without them, 10 % with
     // cache hits), the weight image (L2-resident) one iteration before.
+    GS_STAMP(0);
     fetchA(0, ra0);
     fetchB(0);
     fetchA(1, ra1);
@@ -232,6 +250,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     fetchB(1);
     fetchA(2, ra0);
     __syncthreads();
+    GS_STAMP(1);
     // Every wave stages the next stage first, then multiplies the current one.  GS_PHASE = 1 (developer builds) puts the two
     // waves of a SIMD OUT OF PHASE inside the barrier interval (one half of the waves stages first, the other multiplies
     // first -- what helped csrc/wgrad_split.hip): measured 5-7 % slower here at every shape.
@@ -240,28 +259,36 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     for (int c = 0; c < n_pair; c += 2) {
         if (stage_first) {
             stash(1, ra1);                             // stage c + 1
+            GS_STAMP(2 + 4 * c);
             fetchB(c + 2);
             fetchA(c + 3, ra1);
+            GS_STAMP(3 + 4 * c);
         }
         multiply(0);
+        GS_STAMP(4 + 4 * c);
         if (!stage_first) {
             stash(1, ra1);
             fetchB(c + 2);
             fetchA(c + 3, ra1);
         }
         if (!(GS_PROBE & 1024)) __syncthreads();
+        GS_STAMP(5 + 4 * c);
         if (stage_first) {
             stash(0, ra0);                             // stage c + 2 (past the end: the last stage again, never multiplied)
+            GS_STAMP(6 + 4 * c);
             fetchB(c + 3);
             fetchA(c + 4, ra0);
+            GS_STAMP(7 + 4 * c);
         }
         multiply(1);
+        GS_STAMP(8 + 4 * c);
         if (!stage_first) {
             stash(0, ra0);
             fetchB(c + 3);
             fetchA(c + 4, ra0);
         }
         if (!(GS_PROBE & 1024)) __syncthreads();
+        GS_STAMP(9 + 4 * c);
     }
     if (n_stage & 1) {                             // the last stage of an odd count lies in buffer 0
         multiply(0);
@@ -502,3 +529,9 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     }
     return epi == 2 ? go(gemm_split_kernel<2, 256>) : epi == 1 ? go(gemm_split_kernel<1, 256>) : go(gemm_split_kernel<0, 256>);
 }
+
+#ifdef GS_TIMING
+extern "C" int rqhip_gs_debug_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rqhip::gs_dbg), sizeof(unsigned long long) * 8 * 64);
+}
+#endif
