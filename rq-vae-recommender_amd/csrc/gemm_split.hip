@@ -36,8 +36,13 @@ typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef GS_WAVES   // 4 (developer A/B builds): one wave per SIMD with 128-column wave tiles and a 512-register budget
 #define GS_WAVES 8
 #endif
+#ifndef GS_PC      // 1 (developer A/B builds): four more waves (one per SIMD) do ALL the staging -- global requests, the split, the
+#define GS_PC 0    // LDS writes -- and the eight tile waves only read the LDS and multiply (12 waves: 170 registers each)
+#endif
 constexpr int kGsWaves = GS_WAVES, kGsUB = 16 / GS_WAVES;   // a wave's tile is (32 TA) x (32 UB): UB = 2 (8 waves) or 4 (4 waves)
-constexpr int kGsThreads = 64 * kGsWaves, kGsK = 16;   // tile: COLS = 256 or 128 columns, (waves / (COLS / (32 UB))) * 32 * TA rows
+constexpr int kGsStageWaves = GS_PC ? 4 : kGsWaves;         // waves that stage (GS_PC: waves kGsWaves .. kGsWaves + 3)
+constexpr int kGsThreads = 64 * (kGsWaves + (GS_PC ? kGsStageWaves : 0)), kGsStageThreads = 64 * kGsStageWaves;
+constexpr int kGsK = 16;   // tile: COLS = 256 or 128 columns, (waves / (COLS / (32 UB))) * 32 * TA rows
 #ifndef GS_XCD_GROUP
 #define GS_XCD_GROUP 0
 #endif
@@ -57,7 +62,7 @@ __device__ unsigned long long gs_dbg[8 * 64];
 __device__ unsigned gs_dbg_armed = 1;
 #define GS_STAMP(i)                                                                                                   \
     do {                                                                                                              \
-        if (gs_timed && (threadIdx.x & 63) == 0 && (i) < 64) gs_dbg[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if (gs_timed && (threadIdx.x & 63) == 0 && threadIdx.x < 512 && (i) < 64) gs_dbg[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define GS_STAMP(i) do { } while (0)
@@ -117,20 +122,24 @@ struct GemmSplitParams {
 template <int EPI, int TA, int COLS>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
     constexpr int kGsCols = COLS, UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
-    constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
+    constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsStageThreads - 1) / kGsStageThreads;   // float4s of A per staging thread and stage
     constexpr int PA = 3 * 2 * ROWS * 4, PB = 3 * 2 * kGsCols * 4;                 // dwords per stage image
-    constexpr int BQ = (6 * kGsCols + kGsThreads - 1) / kGsThreads;                // 16-byte elements of B per thread and stage
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int BQ = (6 * kGsCols + kGsStageThreads - 1) / kGsStageThreads;      // 16-byte elements of B per staging thread and stage
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // GS_PC: waves 0 .. 7 multiply (`tiler`), waves 8 .. 11 stage (`stager`); otherwise every wave does both
+    const bool stager = GS_PC ? __builtin_amdgcn_readfirstlane(wave) >= kGsWaves : true;
+    const bool tiler = GS_PC ? !stager : true;
+    const int tid = GS_PC ? (int)threadIdx.x - 64 * kGsWaves : (int)threadIdx.x;   // staging thread number (negative: a tile wave)
     const int il = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 #ifdef GS_TIMING
     const bool gs_timed = blockIdx.x == 0 && TA == 4 && m0 < 256 * (long long)gridDim.x && gs_dbg_armed;   // the workgroup's first big tile
 #endif
     const int n_stage = p.R / kGsK;
-    constexpr int APASS = kGsThreads / 4;                  // rows one staging pass of the workgroup covers
+    constexpr int APASS = kGsStageThreads / 4;             // rows one staging pass of the workgroup covers
     // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
     // 16-byte elements of the stage's weight image per thread
-    const int arow = tid >> 2, akq = tid & 3;
+    const int arow = (tid < 0 ? 0 : tid) >> 2, akq = tid & 3;
     bool a_live[AQ], arow_ok[AQ];
     const float *asrc[AQ];
 #pragma unroll
@@ -142,12 +151,14 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     }
 
     gs_f32x16 acc[TA][UB];
+#if !GS_PC   // (GS_PC zeroes them in the tile waves' own branch, so that the accumulators are not live beside the staging registers)
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+#endif
 
     gs_f32x4 ra0[AQ], ra1[AQ];   // rows of A: two stages in flight (requested two iterations before they are split)
     gs_u32x4 rb[BQ];
@@ -170,8 +181,8 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
-            const int e = tid + kGsThreads * q;
-            if ((6 * kGsCols) % kGsThreads != 0 && e >= 6 * kGsCols) continue;
+            const int e = tid + kGsStageThreads * q;
+            if ((6 * kGsCols) % kGsStageThreads != 0 && e >= 6 * kGsCols) continue;
             if (!((GS_PROBE & 64) && stage > 1)) rb[q] = img[(size_t)(e / kGsCols) * p.Nc + (e % kGsCols)];
         }
     };
@@ -197,8 +208,8 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         }
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
-            const int e = tid + kGsThreads * q;
-            if ((6 * kGsCols) % kGsThreads != 0 && e >= 6 * kGsCols) continue;
+            const int e = tid + kGsStageThreads * q;
+            if ((6 * kGsCols) % kGsStageThreads != 0 && e >= 6 * kGsCols) continue;
             *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
         }
     };
@@ -229,6 +240,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], c16, 0, 0, 0);   // h m
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], c16, 0, 0, 0);   // h h
                 acc[t][u] = c16;
+                // GS_PC: 170 registers hold the accumulators and ONE block's operands; keep the scheduler from hoisting the
+                // next block's LDS reads above this block's matrix instructions (it spills the accumulators otherwise)
+                if (GS_PC) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -243,14 +257,53 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // longer than one iteration's matrix work -- tools/gemm_probe.py: the kernel ran 17 % faster without them, 10 % with
     // cache hits), the weight image (L2-resident) one iteration before.
     GS_STAMP(0);
-    fetchA(0, ra0);
-    fetchB(0);
-    fetchA(1, ra1);
-    stash(0, ra0);
-    fetchB(1);
-    fetchA(2, ra0);
+    if (stager) {
+        fetchA(0, ra0);
+        fetchB(0);
+        fetchA(1, ra1);
+        stash(0, ra0);
+        fetchB(1);
+        fetchA(2, ra0);
+    }
     __syncthreads();
     GS_STAMP(1);
+#if GS_PC
+    // each role runs its own loop (registers of the two roles are then never live together); both pass the same barriers
+    if (stager) {
+        for (int c = 0; c < (n_stage & ~1); c += 2) {
+            stash(1, ra1);                             // stage c + 1
+            fetchB(c + 2);
+            fetchA(c + 3, ra1);
+            __syncthreads();
+            stash(0, ra0);                             // stage c + 2
+            fetchB(c + 3);
+            fetchA(c + 4, ra0);
+            __syncthreads();
+        }
+        if (n_stage & 1) __syncthreads();
+    } else {
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+        for (int c = 0; c < (n_stage & ~1); c += 2) {
+            multiply(0);
+            GS_STAMP(4 + 4 * c);
+            __syncthreads();
+            GS_STAMP(5 + 4 * c);
+            multiply(1);
+            GS_STAMP(8 + 4 * c);
+            __syncthreads();
+            GS_STAMP(9 + 4 * c);
+        }
+        if (n_stage & 1) {
+            multiply(0);
+            __syncthreads();
+        }
+    }
+#else
     // Every wave stages the next stage first, then multiplies the current one.  GS_PHASE = 1 (developer builds) puts the two
     // waves of a SIMD OUT OF PHASE inside the barrier interval (one half of the waves stages first, the other multiplies
     // first -- what helped csrc/wgrad_split.hip): measured 5-7 % slower here at every shape.
@@ -294,6 +347,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         multiply(0);
         if (!(GS_PROBE & 1024)) __syncthreads();
     }
+#endif
 
     // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
     // 32 16-byte stores per lane and tile (the untransposed accumulator needed 128 dword stores; same time: what the result
@@ -313,13 +367,13 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
             for (int g = 0; g < 4; ++g) dst[u * 4 + g] = *reinterpret_cast<const gs_f32x4 *>(xs + 32 * u + 8 * g);
     };
-    if (EPI == 2 && !(GS_PROBE & 512)) load_x(0, xv[0]);
+    if (EPI == 2 && tiler && !(GS_PROBE & 512)) load_x(0, xv[0]);
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const long long row = m0 + 32 * TA * wm + 32 * t + il;
         rowsq[t] = 0.0f;
-        if (EPI == 2 && t + 1 < TA && !(GS_PROBE & 512)) load_x(t + 1, xv[(t + 1) & 1]);
-        if (row < p.M && !(GS_PROBE & 512)) {
+        if (EPI == 2 && tiler && t + 1 < TA && !(GS_PROBE & 512)) load_x(t + 1, xv[(t + 1) & 1]);
+        if (tiler && row < p.M && !(GS_PROBE & 512)) {
             float *dst = p.C + (size_t)row * p.Nc + n0 + 32 * UB * wn + 4 * h;
 #pragma unroll
             for (int u = 0; u < UB; ++u)
@@ -350,10 +404,10 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
-            if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
+            if (h == 0 && tiler) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
         }
         __syncthreads();
-        for (int r = tid; r < ROWS; r += kGsThreads) {
+        for (int r = (int)threadIdx.x; r < ROWS; r += kGsThreads) {
             if (m0 + r >= p.M) continue;
             float sum = red[r];
 #pragma unroll
