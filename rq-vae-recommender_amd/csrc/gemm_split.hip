@@ -133,7 +133,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     const int il = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 #ifdef GS_TIMING
-    const bool gs_timed = blockIdx.x == 0 && TA == 4 && m0 < 256 * (long long)gridDim.x && gs_dbg_armed;   // the workgroup's first big tile
+    const bool gs_timed = blockIdx.x == 0 && TA >= 3 && m0 < 256 * (long long)gridDim.x && gs_dbg_armed;   // the workgroup's first big tile
 #endif
     const int n_stage = p.R / kGsK;
     constexpr int APASS = kGsStageThreads / 4;             // rows one staging pass of the workgroup covers
@@ -240,10 +240,12 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], c16, 0, 0, 0);   // h m
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], c16, 0, 0, 0);   // h h
                 acc[t][u] = c16;
-                // GS_PC: 170 registers hold the accumulators and ONE block's operands; keep the scheduler from hoisting the
-                // next block's LDS reads above this block's matrix instructions (it spills the accumulators otherwise)
-                if (GS_PC) __builtin_amdgcn_sched_barrier(0);
+                // GS_PC, 128 accumulators: 170 registers hold them and ONE block's operands; keep the scheduler from hoisting
+                // the next block's LDS reads above this block's matrix instructions (it spills the accumulators otherwise)
+                if (GS_PC && TA * UB * 16 > 96) __builtin_amdgcn_sched_barrier(0);
             }
+            // GS_PC, 96 accumulators: one column half's operands (12 + 36 registers) at a time
+            if (GS_PC && TA * UB * 16 <= 96) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -420,7 +422,8 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 
 template <int EPI, int COLS>
 __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
-    constexpr int kBigRows = 256, kSmallRows = (8 / (COLS / 64)) * 32;   // 64 (COLS = 256) or 128 (COLS = 128)
+    constexpr int kSmallRows = (8 / (COLS / 64)) * 32;   // 64 (COLS = 256) or 128 (COLS = 128)
+    constexpr int kBigRows = (GS_PC && COLS == 256) ? 192 : 256;   // (GS_PC: 96 accumulators per lane leave room for a stage's operands in 170 registers)
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
     __shared__ unsigned s_tile;
@@ -547,15 +550,16 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     p.n_col_tiles = Nc / cols;
     // whole rounds of 256-row tiles, the remainder as 64-row (128-row for the 128-column tile) tiles (see the kernel);
     // flags_tile (tools only): 256 = big tiles for every row, 64 = small tiles for every row
-    const long long rt256 = (M + 255) / 256;
+    const int big_rows = (GS_PC && cols == 256) ? 192 : 256;
+    const long long rt256 = (M + big_rows - 1) / big_rows;
     long long rt_big = ((rt256 * p.n_col_tiles) / cus) * cus / p.n_col_tiles;   // row tiles of the whole rounds
-    if (rt_big * 256 > M) rt_big = M / 256;
+    if (rt_big * big_rows > M) rt_big = M / big_rows;
     // (measured at 100 000 rows: worth it when the leftover is a small part of a round -- Nc = 512: 14 of 256 slots, 517 ->
     // 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
     if ((rt256 * p.n_col_tiles) % cus > (3 * cus) / 10 && rt256 * p.n_col_tiles >= cus) rt_big = rt256;
     if (flags_tile == 256) rt_big = rt256;
     if (flags_tile == 64) rt_big = 0;
-    const long long rem_rows = M - rt_big * 256 > 0 ? M - rt_big * 256 : 0;
+    const long long rem_rows = M - rt_big * big_rows > 0 ? M - rt_big * big_rows : 0;
     const long long rt_small = (rem_rows + small_rows - 1) / small_rows;
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
