@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: where a stage of gemm_split goes, per wave of workgroup 0 (s_memtime stamps, csrc/gemm_split.hip GS_TIMING).
-Build HERE (no GPU needed):   bash tools/ab_build.sh timing gemm_split.hip -DGS_TIMING
+Build HERE (no GPU needed):   bash tools/ab_build.sh timing gemm_split.hip -DGS_TIMING      (add -DGS_PC=1 for the staging-wave variant)
 Run on the GPU box:           python tools/gemm_timing.py [Nc,R]          (default 512,768; 100 000 rows)
 Prints, for every wave, the shader-clock cycles of each phase of the first 14 stages of the workgroup's first tile:
 stage = split + LDS writes of the next stage, req = issuing the requests, mult = 48 matrix instructions + their LDS reads,
@@ -38,5 +38,8 @@ for wv in range(8):
         if b + 3 >= 64 or not t[b + 3]:
             break
         prev = t[b - 1]
+        if not t[b]:      # GS_PC build: a tile wave only multiplies and waits
+            print(f"   stage {st:2d}: mult {t[b + 2] - prev:5d}  bar {t[b + 3] - t[b + 2]:5d}   total {t[b + 3] - prev:5d}")
+            continue
         print(f"   stage {st:2d}: stage {t[b] - prev:5d}  req {t[b + 1] - t[b]:5d}  mult {t[b + 2] - t[b + 1]:5d}  bar {t[b + 3] - t[b + 2]:5d}"
               f"   total {t[b + 3] - prev:5d}")
