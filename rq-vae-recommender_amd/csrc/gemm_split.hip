@@ -39,6 +39,9 @@ typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef GS_PC      // 1 (developer A/B builds): four more waves (one per SIMD) do ALL the staging -- global requests, the split, the
 #define GS_PC 0    // LDS writes -- and the eight tile waves only read the LDS and multiply (12 waves: 170 registers each)
 #endif
+#ifndef GS_BL2     // 1 (with GS_PC): the tile waves take their weight-image operands straight from L2 into registers (refilled for
+#define GS_BL2 0   // the next stage right after their last use); the image never passes through the LDS or the staging waves
+#endif
 constexpr int kGsWaves = GS_WAVES, kGsUB = 16 / GS_WAVES;   // a wave's tile is (32 TA) x (32 UB): UB = 2 (8 waves) or 4 (4 waves)
 constexpr int kGsStageWaves = GS_PC ? 4 : kGsWaves;         // waves that stage (GS_PC: waves kGsWaves .. kGsWaves + 3)
 constexpr int kGsThreads = 64 * (kGsWaves + (GS_PC ? kGsStageWaves : 0)), kGsStageThreads = 64 * kGsStageWaves;
@@ -123,7 +126,7 @@ template <int EPI, int TA, int COLS>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
     constexpr int kGsCols = COLS, UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
     constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsStageThreads - 1) / kGsStageThreads;   // float4s of A per staging thread and stage
-    constexpr int PA = 3 * 2 * ROWS * 4, PB = 3 * 2 * kGsCols * 4;                 // dwords per stage image
+    constexpr int PA = 3 * 2 * ROWS * 4, PB = GS_BL2 ? 0 : 3 * 2 * kGsCols * 4;    // dwords per stage image
     constexpr int BQ = (6 * kGsCols + kGsStageThreads - 1) / kGsStageThreads;      // 16-byte elements of B per staging thread and stage
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // GS_PC: waves 0 .. 7 multiply (`tiler`), waves 8 .. 11 stage (`stager`); otherwise every wave does both
@@ -174,6 +177,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                          : *reinterpret_cast<const gs_f32x4 *>(asrc[q] + ((GS_PROBE & 128) ? (stage & 1) : stage) * ((GS_PROBE & 256) ? 256 * 1024 : kGsK));
     };
     auto fetchB = [&](int stage) {
+        if (GS_BL2) return;
         stage = stage < n_stage ? stage : n_stage - 1;
         if ((GS_PROBE & 16) && stage > 1) return;
         // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
@@ -209,11 +213,24 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
             const int e = tid + kGsStageThreads * q;
-            if ((6 * kGsCols) % kGsStageThreads != 0 && e >= 6 * kGsCols) continue;
+            if (GS_BL2 || ((6 * kGsCols) % kGsStageThreads != 0 && e >= 6 * kGsCols)) continue;
             *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
         }
     };
+#if GS_BL2
+    // this lane's image operands of the current stage, [column half][piece]; element (piece, half h, column) of stage s is
+    // planes[((s 6 + piece 2 + h) Nc + column) x 16 bytes]
+    gs_bf16x8 breg[UB][3];
+    auto load_b = [&](int stage, int u) {
+        stage = stage < n_stage ? stage : n_stage - 1;
+        const gs_bf16x8 *img = reinterpret_cast<const gs_bf16x8 *>(p.planes) + ((size_t)stage * 6 + h) * p.Nc + n0 + wn * 32 * UB + 32 * u + il;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) breg[u][pc] = img[(size_t)pc * 2 * p.Nc];
+    };
+    auto multiply = [&](int buf, int next_stage) {
+#else
     auto multiply = [&](int buf) {
+#endif
         const gs_bf16x8 *aA = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB));
         const gs_bf16x8 *bB = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB) + PA);
         // column half outer, row block inner: 12 + 12 operand registers live (the row blocks are read once per column half:
@@ -223,7 +240,11 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
             gs_bf16x8 b[3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
+#if GS_BL2
+                b[pc] = breg[u][pc];
+#else
                 b[pc] = bB[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * kGsCols + wn * 32 * UB + ((GS_PROBE & 4) ? 0 : 32 * u) + il];
+#endif
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
                 gs_bf16x8 a[3];
@@ -246,6 +267,10 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
             }
             // GS_PC, 96 accumulators: one column half's operands (12 + 36 registers) at a time
             if (GS_PC && TA * UB * 16 <= 96) __builtin_amdgcn_sched_barrier(0);
+#if GS_BL2
+            load_b(next_stage, u);                 // this column half's operands of the next stage, into the registers just used
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
 
@@ -267,9 +292,20 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         fetchB(1);
         fetchA(2, ra0);
     }
+#if GS_BL2
+    if (tiler) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) load_b(0, u);
+    }
+#endif
     __syncthreads();
     GS_STAMP(1);
 #if GS_PC
+#if GS_BL2
+#define GS_MUL(buf, next) multiply(buf, next)
+#else
+#define GS_MUL(buf, next) multiply(buf)
+#endif
     // each role runs its own loop (registers of the two roles are then never live together); both pass the same barriers
     if (stager) {
         for (int c = 0; c < (n_stage & ~1); c += 2) {
@@ -291,17 +327,17 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
         for (int c = 0; c < (n_stage & ~1); c += 2) {
-            multiply(0);
+            GS_MUL(0, c + 1);
             GS_STAMP(4 + 4 * c);
             __syncthreads();
             GS_STAMP(5 + 4 * c);
-            multiply(1);
+            GS_MUL(1, c + 2);
             GS_STAMP(8 + 4 * c);
             __syncthreads();
             GS_STAMP(9 + 4 * c);
         }
         if (n_stage & 1) {
-            multiply(0);
+            GS_MUL(0, n_stage);
             __syncthreads();
         }
     }
