@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""CPU study for DESIGN section 9 item 0(a): could the activation GEMMs use TWO fp16 pieces per fp32 operand (products
+hh + hm + mh: 3 matrix instructions instead of the 6 of the three-piece bf16 split) and still be no less exact than the
+library's fp32 GEMM?  Every piece product of two fp16 values is exact in fp32 (11 + 11 bits), accumulation is fp32 -- what
+decides is the representation error of the split (22 bits at best) and fp16's narrow exponent range (subnormals below 6.1e-5).
+Emulated with torch on the CPU: pieces are formed exactly as a kernel would (round to nearest fp16 / bf16), each piece GEMM is an
+fp32 matmul of exactly representable values, the piece GEMMs are added smallest first.
+Operands: (1) the model's own shapes -- unit-norm 768-d rows against randn / sqrt(K) weights, post-ReLU hidden activations;
+(2) rows and weight rows scaled over twelve decades (tests/test_gpu_gemm_split.py's second gate), with and without a power-of-two
+normalisation of every row of A and of B (exact, undone in the epilogue).
+usage: python tools/fp16_split_study.py"""
+import torch
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def bf16_pieces(v, n):
+    out, r = [], v.clone()
+    for _ in range(n):
+        p = r.to(torch.bfloat16).to(torch.float32)
+        out.append(p)
+        r = r - p
+    return out
+
+
+def fp16_pieces(v, n, low_shift=0):
+    """v = h + m (+ l); pieces after the first are stored multiplied by 2^low_shift (exactly) to stay out of fp16's subnormals"""
+    out, r = [], v.clone()
+    for i in range(n):
+        s = 2.0 ** (low_shift * i)
+        p = (r * s).to(torch.float16).to(torch.float32) / s
+        out.append(p)
+        r = r - p
+    return out
+
+
+def mm(a, b):   # fp32 GEMM of exactly representable pieces (what the matrix instruction accumulates)
+    return a @ b.t()
+
+
+def row_pow2(x):   # exact power-of-two scale per row: largest |value| of the row in [1, 2)
+    m = x.abs().amax(dim=1, keepdim=True).clamp_min(1e-38)
+    return torch.exp2(torch.floor(torch.log2(m)))
+
+
+def study(name, A, B):
+    ref = A.double() @ B.double().t()
+    scale = ref.abs().max().item()
+    bound = (A.double().abs() @ B.double().abs().t()) * ((A.shape[1] ** 0.5 + 8) * 2.0 ** -24) + 1e-300
+    res = {}
+
+    def rec(tag, C):
+        e = (C.double() - ref).abs()
+        res[tag] = (e.max().item() / scale, (e / bound).max().item())
+
+    rec("library fp32", A @ B.t())
+    a3, b3 = bf16_pieces(A, 3), bf16_pieces(B, 3)
+    rec("bf16 x3, 6 products (ships)", ((((mm(a3[1], b3[1]) + mm(a3[2], b3[0])) + mm(a3[0], b3[2])) + mm(a3[1], b3[0])) + mm(a3[0], b3[1])) + mm(a3[0], b3[0]))
+    for norm in (False, True):
+        sa, sb = (row_pow2(A), row_pow2(B)) if norm else (torch.ones(A.shape[0], 1), torch.ones(B.shape[0], 1))
+        An, Bn = A / sa, B / sb
+        for shift in (0, 8, 11):
+            a2, b2 = fp16_pieces(An, 2, shift), fp16_pieces(Bn, 2, shift)
+            c3 = ((mm(a2[1], b2[0]) + mm(a2[0], b2[1])) + mm(a2[0], b2[0])) * sa * sb.t()
+            c4 = (((mm(a2[1], b2[1]) + mm(a2[1], b2[0])) + mm(a2[0], b2[1])) + mm(a2[0], b2[0])) * sa * sb.t()
+            tag = f"fp16 x2 {'row-normalised' if norm else 'raw'}, low piece x 2^{shift}"
+            rec(tag + ", 3 products", c3)
+            rec(tag + ", 4 products", c4)
+    print(f"== {name}: A {tuple(A.shape)}, B {tuple(B.shape)}   (max err / max|C|,  max err / |A||B| bound of the test)")
+    for k, (e, b) in res.items():
+        print(f"   {k:58s} {e:10.3e}   {b:8.3f}")
+
+
+M, K, N = 4096, 768, 512
+x = torch.nn.functional.normalize(torch.randn(M, K), dim=-1)
+w = torch.randn(N, K) / K ** 0.5
+study("encoder layer 1 (unit-norm rows)", x, w)
+h = torch.relu(x @ w.t())
+w2 = torch.randn(256, N) / N ** 0.5
+study("encoder layer 2 (post-ReLU activations)", h, w2)
+g = torch.randn(M, N) * 1e-5 * (torch.rand(M, N) > 0.5)      # a masked, small data gradient
+study("data gradient (1e-5-scale, half masked)", g, w.t().contiguous())
+a = torch.randn(M, K) * torch.pow(10.0, torch.randint(-6, 7, (M, 1)).float())
+b = torch.randn(N, K) * torch.pow(10.0, torch.randint(-3, 4, (N, 1)).float())
+study("twelve decades of row scales", a, b)
+c = torch.randn(M, K) * torch.pow(10.0, torch.randint(-4, 1, (M, K)).float())   # wide dynamic range INSIDE a row
+study("five decades inside every row", c, w)
