@@ -67,6 +67,22 @@ def study(name, A, B):
             tag = f"fp16 x2 {'row-normalised' if norm else 'raw'}, low piece x 2^{shift}"
             rec(tag + ", 3 products", c3)
             rec(tag + ", 4 products", c4)
+    # block fixed point: every row scaled by an exact power of two to |value| < 1/2, rounded to 23 fractional bits, cut into three
+    # signed 8-bit limbs (balanced digits); limb products are exact in int32 (v_mfma_i32_32x32x32_i8 runs at twice the bf16
+    # rate), the six limb pairs of weight >= 2^-32 are kept (as the bf16 split keeps six piece pairs)
+    def limbs(x):
+        s = row_pow2(x) * 4.0                                     # |x| < s / 2: the top limb stays within a signed byte
+        q = torch.round((x / s).double() * 2.0 ** 23)            # |q| <= 2^23
+        out = []
+        for _ in range(3):
+            d = torch.remainder(q + 128, 256) - 128               # balanced digit in [-128, 127]
+            out.append(d)
+            q = (q - d) / 256
+        return out, s                                              # x ~ s 2^-23 (d0 + 256 d1 + 65536 d2)
+    (a0, a1, a2), sa = limbs(A)
+    (b0, b1, b2), sb = limbs(B)
+    acc = (a2 @ b2.t()) * 2.0 ** 32 + (a2 @ b1.t() + a1 @ b2.t()) * 2.0 ** 24 + (a2 @ b0.t() + a0 @ b2.t() + a1 @ b1.t()) * 2.0 ** 16
+    rec("int8 x3 limbs per row exponent, 6 limb products", (acc * 2.0 ** -46 * sa.double() * sb.double().t()).float())
     print(f"== {name}: A {tuple(A.shape)}, B {tuple(B.shape)}   (max err / max|C|,  max err / |A||B| bound of the test)")
     for k, (e, b) in res.items():
         print(f"   {k:58s} {e:10.3e}   {b:8.3f}")
