@@ -39,12 +39,16 @@ typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef GS_PC      // 1 (developer A/B builds): four more waves (one per SIMD) do ALL the staging -- global requests, the split, the
 #define GS_PC 0    // LDS writes -- and the eight tile waves only read the LDS and multiply (12 waves: 170 registers each)
 #endif
+#ifndef GS_F16     // 1 (developer A/B builds, TIMING ONLY: no row scaling yet): two fp16 pieces per operand and the three products
+#define GS_F16 0   // hh + hm + mh instead of three bf16 pieces and six products (tools/fp16_split_study.py)
+#endif
 #ifndef GS_BL2     // 1 (with GS_PC): the tile waves take their weight-image operands straight from L2 into registers (refilled for
 #define GS_BL2 0   // the next stage right after their last use); the image never passes through the LDS or the staging waves
 #endif
 constexpr int kGsWaves = GS_WAVES, kGsUB = 16 / GS_WAVES;   // a wave's tile is (32 TA) x (32 UB): UB = 2 (8 waves) or 4 (4 waves)
 constexpr int kGsStageWaves = GS_PC ? 4 : kGsWaves;         // waves that stage (GS_PC: waves kGsWaves .. kGsWaves + 3)
 constexpr int kGsThreads = 64 * (kGsWaves + (GS_PC ? kGsStageWaves : 0)), kGsStageThreads = 64 * kGsStageWaves;
+constexpr int kGsNP = GS_F16 ? 2 : 3;   // pieces per operand
 constexpr int kGsK = 16;   // tile: COLS = 256 or 128 columns, (waves / (COLS / (32 UB))) * 32 * TA rows
 #ifndef GS_XCD_GROUP
 #define GS_XCD_GROUP 0
@@ -82,24 +86,40 @@ __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigne
     l = __builtin_bit_cast(unsigned, ll);
 }
 
+#if GS_F16
+typedef _Float16 gs_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gs_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gs_split2_f16(float a, float b, unsigned &h, unsigned &m) {
+    const gs_f16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const gs_f32x2 hf = __builtin_convertvector(hh, gs_f32x2);
+    const gs_f16x2 mm = __builtin_convertvector(gs_f32x2{a - hf.x, b - hf.y}, gs_f16x2);
+    m = __builtin_bit_cast(unsigned, mm);
+}
+#endif
+
 // planes[s][piece][half][n] (16 bytes: r = 16 s + 8 half + j, j < 8) of src[n][r] (transpose == 0, src is [Nc, R]) or of
 // src[r][n] (transpose == 1, src is [R, Nc]: the data gradient multiplies by W, i.e. B = W^T).  One thread per element.
 __global__ __launch_bounds__(256) void weight_planes_kernel(const float *__restrict__ src, int Nc, int R, int transpose,
                                                             unsigned *__restrict__ planes) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;     // (n, r pair): r = 2 rp, 2 rp + 1
     const long long total = (long long)Nc * (R / 2);
-    if (e < 4) planes[(size_t)(R / kGsK) * 6 * Nc * 4 + e] = 0u;        // the tile dispenser behind the image
+    if (e < 4) planes[(size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + e] = 0u;        // the tile dispenser behind the image
     if (e >= total) return;
     const int n = (int)(e % Nc), rp = (int)(e / Nc), r = 2 * rp;
     const float a = transpose ? src[(size_t)r * Nc + n] : src[(size_t)n * R + r];
     const float b = transpose ? src[(size_t)(r + 1) * Nc + n] : src[(size_t)n * R + r + 1];
-    unsigned h, m, l;
+    unsigned h, m, l = 0u;
+#if GS_F16
+    gs_split2_f16(a, b, h, m);
+#else
     gs_split2(a, b, h, m, l);
+#endif
     const int s = r >> 4, half = (r >> 3) & 1, j2 = (r & 7) >> 1;      // dword j2 of the 16-byte element
-    const size_t base = ((size_t)(s * 3) * 2 + half) * Nc + n;
+    const size_t base = ((size_t)(s * kGsNP) * 2 + half) * Nc + n;
     planes[(base + 0 * 2 * (size_t)Nc) * 4 + j2] = h;
     planes[(base + 1 * 2 * (size_t)Nc) * 4 + j2] = m;
-    planes[(base + 2 * 2 * (size_t)Nc) * 4 + j2] = l;
+    if (kGsNP == 3) planes[(base + 2 * 2 * (size_t)Nc) * 4 + j2] = l;
 }
 
 struct GemmSplitParams {
@@ -126,8 +146,8 @@ template <int EPI, int TA, int COLS>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
     constexpr int kGsCols = COLS, UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
     constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsStageThreads - 1) / kGsStageThreads;   // float4s of A per staging thread and stage
-    constexpr int PA = 3 * 2 * ROWS * 4, PB = GS_BL2 ? 0 : 3 * 2 * kGsCols * 4;    // dwords per stage image
-    constexpr int BQ = (6 * kGsCols + kGsStageThreads - 1) / kGsStageThreads;      // 16-byte elements of B per staging thread and stage
+    constexpr int PA = kGsNP * 2 * ROWS * 4, PB = GS_BL2 ? 0 : kGsNP * 2 * kGsCols * 4;    // dwords per stage image
+    constexpr int BQ = (2 * kGsNP * kGsCols + kGsStageThreads - 1) / kGsStageThreads;      // 16-byte elements of B per staging thread and stage
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // GS_PC: waves 0 .. 7 multiply (`tiler`), waves 8 .. 11 stage (`stager`); otherwise every wave does both
     const bool stager = GS_PC ? __builtin_amdgcn_readfirstlane(wave) >= kGsWaves : true;
@@ -182,11 +202,11 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         if ((GS_PROBE & 16) && stage > 1) return;
         // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
         // (piece, half) rows: element e = tid + 512 q  ->  (ph = e / COLS, col = e % COLS)
-        const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 6 * p.Nc + n0;
+        const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 2 * kGsNP * p.Nc + n0;
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
             const int e = tid + kGsStageThreads * q;
-            if ((6 * kGsCols) % kGsStageThreads != 0 && e >= 6 * kGsCols) continue;
+            if ((2 * kGsNP * kGsCols) % kGsStageThreads != 0 && e >= 2 * kGsNP * kGsCols) continue;
             if (!((GS_PROBE & 64) && stage > 1)) rb[q] = img[(size_t)(e / kGsCols) * p.Nc + (e % kGsCols)];
         }
     };
@@ -201,31 +221,37 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                 h01 = __builtin_bit_cast(unsigned, ra[q].x); m01 = __builtin_bit_cast(unsigned, ra[q].y); l01 = h01 ^ m01;
                 h23 = __builtin_bit_cast(unsigned, ra[q].z); m23 = __builtin_bit_cast(unsigned, ra[q].w); l23 = h23 ^ m23;
             } else {
+#if GS_F16
+            gs_split2_f16(ra[q].x, ra[q].y, h01, m01);
+            gs_split2_f16(ra[q].z, ra[q].w, h23, m23);
+            l01 = l23 = 0u;
+#else
             gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
             gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
+#endif
             }
             // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
             unsigned *d = dA + (((akq >> 1) * ROWS) + arow + APASS * q) * 4 + 2 * (akq & 1);
             *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * ROWS * 4) = gs_u32x2{h01, h23};
             *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * ROWS * 4) = gs_u32x2{m01, m23};
-            *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
+            if (kGsNP == 3) *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
         }
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
             const int e = tid + kGsStageThreads * q;
-            if (GS_BL2 || ((6 * kGsCols) % kGsStageThreads != 0 && e >= 6 * kGsCols)) continue;
+            if (GS_BL2 || ((2 * kGsNP * kGsCols) % kGsStageThreads != 0 && e >= 2 * kGsNP * kGsCols)) continue;
             *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
         }
     };
 #if GS_BL2
     // this lane's image operands of the current stage, [column half][piece]; element (piece, half h, column) of stage s is
     // planes[((s 6 + piece 2 + h) Nc + column) x 16 bytes]
-    gs_bf16x8 breg[UB][3];
+    gs_bf16x8 breg[UB][kGsNP];
     auto load_b = [&](int stage, int u) {
         stage = stage < n_stage ? stage : n_stage - 1;
-        const gs_bf16x8 *img = reinterpret_cast<const gs_bf16x8 *>(p.planes) + ((size_t)stage * 6 + h) * p.Nc + n0 + wn * 32 * UB + 32 * u + il;
+        const gs_bf16x8 *img = reinterpret_cast<const gs_bf16x8 *>(p.planes) + ((size_t)stage * 2 * kGsNP + h) * p.Nc + n0 + wn * 32 * UB + 32 * u + il;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) breg[u][pc] = img[(size_t)pc * 2 * p.Nc];
+        for (int pc = 0; pc < kGsNP; ++pc) breg[u][pc] = img[(size_t)pc * 2 * p.Nc];
     };
     auto multiply = [&](int buf, int next_stage) {
 #else
@@ -237,9 +263,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         // 30 instead of 18 LDS reads per stage, which the LDS has room for -- tools/gemm_probe.py, GS_PROBE 4)
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            gs_bf16x8 b[3];
+            gs_bf16x8 b[kGsNP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < kGsNP; ++pc)
 #if GS_BL2
                 b[pc] = breg[u][pc];
 #else
@@ -247,19 +273,30 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #endif
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
-                gs_bf16x8 a[3];
+                gs_bf16x8 a[kGsNP];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < kGsNP; ++pc)
                     a[pc] = aA[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * ROWS + wm * 32 * TA + ((GS_PROBE & 4) ? 0 : 32 * t) + il];
                 gs_f32x16 c16 = acc[t][u];
                 // the weight columns take the instruction's ROW role: the accumulator is the tile transposed, a lane holds
                 // four consecutive columns of one output row per register quad -> 16-byte result stores
+#if GS_F16
+                {
+                    gs_f16x8 fa[2], fb[2];
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) { fa[pc] = __builtin_bit_cast(gs_f16x8, a[pc]); fb[pc] = __builtin_bit_cast(gs_f16x8, b[pc]); }
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0], fa[1], c16, 0, 0, 0);   // m h (smallest first)
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1], fa[0], c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0], fa[0], c16, 0, 0, 0);   // h h
+                }
+#else
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[1], c16, 0, 0, 0);   // m m (smallest first)
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[2], c16, 0, 0, 0);   // l h
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], a[0], c16, 0, 0, 0);   // h l
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], c16, 0, 0, 0);   // m h
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], c16, 0, 0, 0);   // h m
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], c16, 0, 0, 0);   // h h
+#endif
                 acc[t][u] = c16;
                 // GS_PC, 128 accumulators: 170 registers hold them and ONE block's operands; keep the scheduler from hoisting
                 // the next block's LDS reads above this block's matrix instructions (it spills the accumulators otherwise)
@@ -516,7 +553,7 @@ extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R >
 
 extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) {
     if (!rqhip_gemm_split_supported(Nc, R)) return 0;
-    return (size_t)(R / kGsK) * 6 * Nc * 16 + 64;    // + the tile counter behind the image
+    return (size_t)(R / kGsK) * 2 * kGsNP * Nc * 16 + 64;    // + the tile counter behind the image
 }
 
 extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void *planes, size_t planes_bytes,
@@ -602,8 +639,8 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_planes, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
-    p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 6 * Nc * 4;
-    const size_t lds = (size_t)2 * (3 * 2 * (256 + cols) * 16);
+    p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4;
+    const size_t lds = (size_t)2 * (kGsNP * 2 * (256 + cols) * 16);
     const long long tiles = (long long)p.n_tiles;
     const long long slots = (long long)cus;                // one workgroup per CU (240 VGPRs x 512 threads)
     const int grid = (int)(tiles < slots ? tiles : slots);
