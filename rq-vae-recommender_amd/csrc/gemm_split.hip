@@ -98,6 +98,41 @@ __device__ __forceinline__ void gs_split2_f16(float a, float b, unsigned &h, uns
 }
 #endif
 
+#if GS_F16
+// Exact power-of-two scaling (PROTOTYPE, not validated on the GPU yet): fp16 pieces only carry 11 + 11 bits between 6.1e-5 and
+// 65 504, so every row of A and every weight row is multiplied by 2^-e, e = exponent of its largest |value| (the scaled row then
+// has its maximum in [1, 2)), and the result is multiplied back by 2^(e_row + e_column) in the epilogue -- all three exact.
+__device__ __forceinline__ int gs_exp_of(float m) {   // floor(log2 m) of a positive finite float; 0 for 0 / inf / nan
+    const unsigned b = __builtin_bit_cast(unsigned, m) & 0x7fffffffu;
+    const int e = (int)(b >> 23);
+    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127);
+}
+// exps[m] for the rows of A [M, R] (16-byte aligned rows): four rows per 256-thread block, one wave per row
+__global__ __launch_bounds__(256) void row_exps_kernel(const float *__restrict__ A, long long M, int R, int *__restrict__ exps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    float m = 0.0f;
+    const gs_f32x4 *src = reinterpret_cast<const gs_f32x4 *>(A + (size_t)row * R);
+    for (int i = lane; i < R / 4; i += 64) {
+        const gs_f32x4 v = src[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));   // (fmaxf drops NaNs: they stay NaN in the product)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) exps[row] = gs_exp_of(m);
+}
+// exps[n] for the rows of B: src[n][r] (transpose == 0) or src[r][n] (transpose == 1); one wave per n
+__global__ __launch_bounds__(64) void weight_exps_kernel(const float *__restrict__ src, int Nc, int R, int transpose, int *__restrict__ exps) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float m = 0.0f;
+    for (int r = lane; r < R; r += 64) m = fmaxf(m, fabsf(transpose ? src[(size_t)r * Nc + n] : src[(size_t)n * R + r]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) exps[n] = gs_exp_of(m);
+}
+#endif
+
 // planes[s][piece][half][n] (16 bytes: r = 16 s + 8 half + j, j < 8) of src[n][r] (transpose == 0, src is [Nc, R]) or of
 // src[r][n] (transpose == 1, src is [R, Nc]: the data gradient multiplies by W, i.e. B = W^T).  One thread per element.
 __global__ __launch_bounds__(256) void weight_planes_kernel(const float *__restrict__ src, int Nc, int R, int transpose,
@@ -111,7 +146,10 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float *__restr
     const float b = transpose ? src[(size_t)(r + 1) * Nc + n] : src[(size_t)n * R + r + 1];
     unsigned h, m, l = 0u;
 #if GS_F16
-    gs_split2_f16(a, b, h, m);
+    {   // the exponents lie behind the tile dispenser (16 words): see rqhip_weight_planes
+        const int e_n = reinterpret_cast<const int *>(planes + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16)[n];
+        gs_split2_f16(ldexpf(a, -e_n), ldexpf(b, -e_n), h, m);
+    }
 #else
     gs_split2(a, b, h, m, l);
 #endif
@@ -138,6 +176,10 @@ struct GemmSplitParams {
     const float *X;
     float *rowsum;
     float row_scale;
+#if GS_F16
+    const int *a_exp;        // [M] exponents of the rows of A (row_exps_kernel), or nullptr: A is used as it is
+    const int *b_exp;        // [Nc] exponents of the weight rows (inside the image, written by rqhip_weight_planes)
+#endif
 };
 
 // one output tile of ROWS x COLS: 8 waves of (32 TA) x 64, WN = COLS / 64 of them side by side
@@ -172,6 +214,11 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         arow_ok[q] = a_live[q] && arow_g < p.M;
         asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * ((GS_PROBE & 256) ? 16 : p.R) + 4 * akq;
     }
+#if GS_F16
+    int a_e[AQ];             // exponents of this thread's rows of A
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) a_e[q] = (p.a_exp && arow_ok[q]) ? p.a_exp[m0 + arow + APASS * q] : 0;
+#endif
 
     gs_f32x16 acc[TA][UB];
 #if !GS_PC   // (GS_PC zeroes them in the tile waves' own branch, so that the accumulators are not live beside the staging registers)
@@ -222,8 +269,8 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                 h23 = __builtin_bit_cast(unsigned, ra[q].z); m23 = __builtin_bit_cast(unsigned, ra[q].w); l23 = h23 ^ m23;
             } else {
 #if GS_F16
-            gs_split2_f16(ra[q].x, ra[q].y, h01, m01);
-            gs_split2_f16(ra[q].z, ra[q].w, h23, m23);
+            gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
+            gs_split2_f16(ldexpf(ra[q].z, -a_e[q]), ldexpf(ra[q].w, -a_e[q]), h23, m23);
             l01 = l23 = 0u;
 #else
             gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
@@ -455,6 +502,14 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+#if GS_F16
+                    {   // undo the row and column scales (exact)
+                        const int er = p.a_exp ? p.a_exp[row] : 0;
+                        const int *ec = p.b_exp + n0 + 32 * UB * wn + 4 * h + 32 * u + 8 * g;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er + ec[j]);
+                    }
+#endif
                     if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
                         v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
                         v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
@@ -553,7 +608,7 @@ extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R >
 
 extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) {
     if (!rqhip_gemm_split_supported(Nc, R)) return 0;
-    return (size_t)(R / kGsK) * 2 * kGsNP * Nc * 16 + 64;    // + the tile counter behind the image
+    return (size_t)(R / kGsK) * 2 * kGsNP * Nc * 16 + 64 + (GS_F16 ? (size_t)Nc * sizeof(int) : 0);    // + the tile counter (+ GS_F16: the weight rows' exponents) behind the image
 }
 
 extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void *planes, size_t planes_bytes,
@@ -566,6 +621,11 @@ extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int trans
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long total = (long long)Nc * (R / 2);
+#if GS_F16
+    hipLaunchKernelGGL(weight_exps_kernel, dim3(Nc), dim3(64), 0, s, w, Nc, R, transpose,
+                       reinterpret_cast<int *>(reinterpret_cast<unsigned *>(planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16));
+    RQ_CHECK_LAUNCH("weight_exps_kernel");
+#endif
     hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, Nc, R, transpose,
                        reinterpret_cast<unsigned *>(planes));
     RQ_CHECK_LAUNCH("weight_planes_kernel");
@@ -574,6 +634,30 @@ extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int trans
 
 static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int epi, float *C, int flags_tile,
                              const float *X, float row_scale, float *rowsum, rqhip_stream_t stream);
+
+#if GS_F16
+static const int *g_gs_a_exp = nullptr;   // (prototype plumbing: the row exponents of the next gemm_split_launch)
+// exponents of the rows of A for rqhip_gemm_split_f16; A rows must be 16-byte aligned (R % 4 == 0)
+extern "C" int rqhip_row_exponents(const float *A, int64_t M, int R, int *exps, rqhip_stream_t stream) {
+    if (M < 0 || R <= 0 || (R % 4) != 0 || (M > 0 && (!A || !exps))) {
+        set_error("row_exponents: bad arguments");
+        return RQHIP_EARG;
+    }
+    if (M == 0) return RQHIP_OK;
+    hipLaunchKernelGGL(row_exps_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
+                       (long long)M, R, exps);
+    RQ_CHECK_LAUNCH("row_exps_kernel");
+    return RQHIP_OK;
+}
+// rqhip_gemm_split with the rows of A scaled by 2^-a_exp[row] before the fp16 split (a_exp from rqhip_row_exponents)
+extern "C" int rqhip_gemm_split_f16(const float *A, const int *a_exp, int64_t M, int R, const void *planes, int Nc, int relu,
+                                    float *C, rqhip_stream_t stream) {
+    g_gs_a_exp = a_exp;
+    const int rc = gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, 0, nullptr, 0.0f, nullptr, stream);
+    g_gs_a_exp = nullptr;
+    return rc;
+}
+#endif
 
 extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
                                 rqhip_stream_t stream) {
@@ -618,6 +702,10 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     GemmSplitParams p;
     p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
     p.X = X; p.rowsum = rowsum; p.row_scale = row_scale;
+#if GS_F16
+    p.a_exp = g_gs_a_exp;    // (set by rqhip_gemm_split_f16 around this call; nullptr otherwise)
+    p.b_exp = reinterpret_cast<const int *>(reinterpret_cast<const unsigned *>(planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16);
+#endif
     const int cus = cu_count();
     const int cols = gs_cols(Nc), small_rows = cols == 256 ? 64 : 128;
     p.n_col_tiles = Nc / cols;

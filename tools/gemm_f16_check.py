@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Developer tool for the two-piece fp16 GEMM prototype (csrc/gemm_split.hip, GS_F16=1):
+error against fp64 next to the library's fp32 GEMM on the operand families of tools/fp16_split_study.py, and timing of
+row exponents + GEMM against the shipped three-piece bf16 kernel.
+Build HERE:  bash tools/ab_build.sh f16 gemm_split.hip -DGS_F16=1        Run on the GPU box:  python tools/gemm_f16_check.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")]
+from rqhip import _lib  # noqa: E402
+from rqhip import ops as ops_ship  # noqa: E402  (the in-tree build, for the timing comparison)
+
+vp = C.c_void_p
+f16 = C.CDLL(os.path.join(ROOT, "tools", "_ab", "librqhip_f16.so"))
+f16.rqhip_weight_planes_bytes.restype = C.c_size_t
+f16.rqhip_last_error.restype = C.c_char_p
+
+
+def chk(rc):
+    assert rc == 0, (rc, f16.rqhip_last_error())
+
+
+def gemm_f16(a, w, relu=False, scaled=True):
+    M, R = a.shape
+    Nc = w.shape[0]
+    nb = f16.rqhip_weight_planes_bytes(Nc, R)
+    planes = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    chk(f16.rqhip_weight_planes(vp(w.data_ptr()), Nc, R, 0, vp(planes.data_ptr()), C.c_size_t(nb), None))
+    c = torch.empty((M, Nc), device="cuda")
+    ex = torch.empty((M,), dtype=torch.int32, device="cuda")
+
+    def run():
+        if scaled:
+            chk(f16.rqhip_row_exponents(vp(a.data_ptr()), C.c_int64(M), R, vp(ex.data_ptr()), None))
+            chk(f16.rqhip_gemm_split_f16(vp(a.data_ptr()), vp(ex.data_ptr()), C.c_int64(M), R, vp(planes.data_ptr()), Nc, int(relu), vp(c.data_ptr()), None))
+        else:
+            chk(f16.rqhip_gemm_split(vp(a.data_ptr()), C.c_int64(M), R, vp(planes.data_ptr()), Nc, int(relu), vp(c.data_ptr()), None))
+    run()
+    return c, run
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+def report(name, A, B):
+    A, B = A.cuda().contiguous(), B.cuda().contiguous()
+    ref = A.double() @ B.double().t()
+    sc = ref.abs().max().item()
+    bound = (A.double().abs() @ B.double().abs().t()) * ((A.shape[1] ** 0.5 + 8) * 2.0 ** -24) + 1e-300
+    out = [name]
+    for tag, Cm in (("library", A @ B.t()), ("ships", ops_ship.gemm_split(A, ops_ship.weight_planes(B), B.shape[0])),
+                    ("f16 scaled", gemm_f16(A, B)[0]), ("f16 unscaled A", gemm_f16(A, B, scaled=False)[0])):
+        e = (Cm.double() - ref).abs()
+        out.append(f"{tag}: {e.max().item() / sc:.2e} (bound x {(e / bound).max().item():.2f})")
+    print("  |  ".join(out), flush=True)
+
+
+torch.manual_seed(0)
+M, K, N = 8192, 768, 512
+x = torch.nn.functional.normalize(torch.randn(M, K), dim=-1)
+w = torch.randn(N, K) / K ** 0.5
+report("unit-norm rows", x, w)
+hdn = torch.relu(x @ w.t())
+report("post-ReLU activations", hdn, torch.randn(256, N) / N ** 0.5)
+report("1e-5-scale masked gradient", torch.randn(M, N) * 1e-5 * (torch.rand(M, N) > 0.5), w.t().contiguous())
+report("twelve decades of row scales", torch.randn(M, K) * torch.pow(10.0, torch.randint(-6, 7, (M, 1)).float()),
+       torch.randn(N, K) * torch.pow(10.0, torch.randint(-3, 4, (N, 1)).float()))
+report("five decades inside every row", torch.randn(M, K) * torch.pow(10.0, torch.randint(-4, 1, (M, K)).float()), w)
+for (Nc, R) in ((512, 768), (768, 512), (256, 512)):
+    a = torch.randn(100_000, R, device="cuda")
+    ww = torch.randn(Nc, R, device="cuda") / R ** 0.5
+    p = ops_ship.weight_planes(ww)
+    t_ship = timeit(lambda: ops_ship.gemm_split(a, p, Nc, relu=True))
+    _, run_s = gemm_f16(a, ww, relu=True)
+    _, run_u = gemm_f16(a, ww, relu=True, scaled=False)
+    print(f"{R} -> {Nc}, 100000 rows: ships {t_ship:.1f} us, f16 with row exponents (incl. their pass) {timeit(run_s):.1f} us, f16 unscaled A {timeit(run_u):.1f} us")
