@@ -179,6 +179,9 @@ struct GemmSplitParams {
 #if GS_F16
     const int *a_exp;        // [M] exponents of the rows of A (row_exps_kernel), or nullptr: A is used as it is
     const int *b_exp;        // [Nc] exponents of the weight rows (inside the image, written by rqhip_weight_planes)
+    int a_is_max;            // a_exp holds the bit patterns of the rows' largest |value| (another GEMM's rowmax_out) instead
+    unsigned *rowmax_out;    // [M] or nullptr: unsigned max of the bit patterns of |C[row, :]| (zeroed by the caller; the maximum
+                             // does not depend on the order of the atomics) -- the row exponents of the GEMM that reads C next
 #endif
 };
 
@@ -217,7 +220,10 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #if GS_F16
     int a_e[AQ];             // exponents of this thread's rows of A
 #pragma unroll
-    for (int q = 0; q < AQ; ++q) a_e[q] = (p.a_exp && arow_ok[q]) ? p.a_exp[m0 + arow + APASS * q] : 0;
+    for (int q = 0; q < AQ; ++q) {
+        a_e[q] = (p.a_exp && arow_ok[q]) ? p.a_exp[m0 + arow + APASS * q] : 0;
+        if (p.a_is_max) a_e[q] = gs_exp_of(__builtin_bit_cast(float, a_e[q]));
+    }
 #endif
 
     gs_f32x16 acc[TA][UB];
@@ -476,6 +482,11 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // costs is its write traffic, 7-11 % of the kernel while every CU reaches its epilogue in the same phase of a round --
     // tools/gemm_probe.py, GS_PROBE 512)
     float rowsq[TA];
+#if GS_F16
+    float rowmx[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) rowmx[t] = 0.0f;
+#endif
     // EPI == 2 reads x beside every result it stores.  The compiler may not move a load above a store that could alias
     // it, so with load / compute / store per 16 bytes every one of the 32 loads of a lane waited for its own latency AND
     // for the store before it (the recon GEMM ran 547 us against 440 for the plain one).  The x values of a whole row
@@ -504,7 +515,8 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                     gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
 #if GS_F16
                     {   // undo the row and column scales (exact)
-                        const int er = p.a_exp ? p.a_exp[row] : 0;
+                        int er = p.a_exp ? p.a_exp[row] : 0;
+                        if (p.a_is_max) er = gs_exp_of(__builtin_bit_cast(float, er));
                         const int *ec = p.b_exp + n0 + 32 * UB * wn + 4 * h + 32 * u + 8 * g;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er + ec[j]);
@@ -523,10 +535,23 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
                             v[j] = (2.0f * d) * p.row_scale;
                         }
                     }
+#if GS_F16
+                    if (EPI != 2) rowmx[t] = fmaxf(fmaxf(rowmx[t], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+#endif
                     *reinterpret_cast<gs_f32x4 *>(dst + 32 * u + 8 * g) = v;   // (non-temporal stores: +2 ... +36 %)
                 }
         }
     }
+#if GS_F16
+    if (EPI != 2 && p.rowmax_out && tiler) {   // this wave's 32 UB columns of a row: both lane halves, then one atomic per row
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const long long row = m0 + 32 * TA * wm + 32 * t + il;
+            const float mx = fmaxf(rowmx[t], __shfl_xor(rowmx[t], 32, 64));
+            if (h == 0 && row < p.M) atomicMax(p.rowmax_out + row, __builtin_bit_cast(unsigned, mx));
+        }
+    }
+#endif
     if (EPI == 2) {
         // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
         // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
@@ -637,6 +662,8 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
 
 #if GS_F16
 static const int *g_gs_a_exp = nullptr;   // (prototype plumbing: the row exponents of the next gemm_split_launch)
+static int g_gs_a_is_max = 0;
+static unsigned *g_gs_rowmax_out = nullptr;
 // exponents of the rows of A for rqhip_gemm_split_f16; A rows must be 16-byte aligned (R % 4 == 0)
 extern "C" int rqhip_row_exponents(const float *A, int64_t M, int R, int *exps, rqhip_stream_t stream) {
     if (M < 0 || R <= 0 || (R % 4) != 0 || (M > 0 && (!A || !exps))) {
@@ -655,6 +682,19 @@ extern "C" int rqhip_gemm_split_f16(const float *A, const int *a_exp, int64_t M,
     g_gs_a_exp = a_exp;
     const int rc = gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, 0, nullptr, 0.0f, nullptr, stream);
     g_gs_a_exp = nullptr;
+    return rc;
+}
+// the chained form: a_max = the row maxima another GEMM left in its rowmax_out (bit patterns; used in place of exponents), and
+// rowmax_out (zeroed by the caller, or nullptr) receives this GEMM's for the next one.  NOT validated on the GPU yet.
+extern "C" int rqhip_gemm_split_f16_chain(const float *A, const unsigned *a_max, int64_t M, int R, const void *planes, int Nc,
+                                          int relu, float *C, unsigned *rowmax_out, rqhip_stream_t stream) {
+    g_gs_a_exp = reinterpret_cast<const int *>(a_max);
+    g_gs_a_is_max = a_max ? 1 : 0;
+    g_gs_rowmax_out = rowmax_out;
+    const int rc = gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, 0, nullptr, 0.0f, nullptr, stream);
+    g_gs_a_exp = nullptr;
+    g_gs_a_is_max = 0;
+    g_gs_rowmax_out = nullptr;
     return rc;
 }
 #endif
@@ -704,6 +744,8 @@ static int gemm_split_launch(const float *A, int64_t M, int R, const void *plane
     p.X = X; p.rowsum = rowsum; p.row_scale = row_scale;
 #if GS_F16
     p.a_exp = g_gs_a_exp;    // (set by rqhip_gemm_split_f16 around this call; nullptr otherwise)
+    p.a_is_max = g_gs_a_is_max;
+    p.rowmax_out = g_gs_rowmax_out;
     p.b_exp = reinterpret_cast<const int *>(reinterpret_cast<const unsigned *>(planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16);
 #endif
     const int cus = cu_count();

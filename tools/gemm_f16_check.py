@@ -88,3 +88,36 @@ for (Nc, R) in ((512, 768), (768, 512), (256, 512)):
     _, run_s = gemm_f16(a, ww, relu=True)
     _, run_u = gemm_f16(a, ww, relu=True, scaled=False)
     print(f"{R} -> {Nc}, 100000 rows: ships {t_ship:.1f} us, f16 with row exponents (incl. their pass) {timeit(run_s):.1f} us, f16 unscaled A {timeit(run_u):.1f} us")
+
+# ---- chained form (NOT validated in round 3): layer 1 emits the row maxima of its output, layer 2 scales by them ----------------
+if hasattr(f16, "rqhip_gemm_split_f16_chain"):
+    M, K, N, N2 = 100_000, 768, 512, 256
+    x = torch.nn.functional.normalize(torch.randn(M, K), dim=-1).cuda()
+    w1 = (torch.randn(N, K) / K ** 0.5).cuda()
+    w2 = (torch.randn(N2, N) / N ** 0.5).cuda()
+
+    def planes_of(w):
+        nb = f16.rqhip_weight_planes_bytes(w.shape[0], w.shape[1])
+        pl = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+        chk(f16.rqhip_weight_planes(vp(w.data_ptr()), w.shape[0], w.shape[1], 0, vp(pl.data_ptr()), C.c_size_t(nb), None))
+        return pl
+    p1, p2 = planes_of(w1), planes_of(w2)
+    ex = torch.empty((M,), dtype=torch.int32, device="cuda")
+    h1 = torch.empty((M, N), device="cuda")
+    h2 = torch.empty((M, N2), device="cuda")
+    mx1 = torch.zeros((M,), dtype=torch.int32, device="cuda")
+
+    def two_layers():
+        mx1.zero_()
+        chk(f16.rqhip_row_exponents(vp(x.data_ptr()), C.c_int64(M), K, vp(ex.data_ptr()), None))   # (the input batch: once per batch)
+        chk(f16.rqhip_gemm_split_f16_chain(vp(x.data_ptr()), None, C.c_int64(M), K, vp(p1.data_ptr()), N, 1, vp(h1.data_ptr()), vp(mx1.data_ptr()), None))
+        chk(f16.rqhip_gemm_split_f16_chain(vp(h1.data_ptr()), vp(mx1.data_ptr()), C.c_int64(M), N, vp(p2.data_ptr()), N2, 1, vp(h2.data_ptr()), None, None))
+    two_layers()
+    ref1 = torch.relu(x.double() @ w1.double().t())
+    assert torch.equal(mx1.view(torch.float32), h1.abs().amax(dim=1)), "row maxima of layer 1"
+    ref2 = torch.relu(h1.double() @ w2.double().t())          # layer 2 against ITS OWN input
+    lib2 = torch.relu(h1 @ w2.t())
+    sc = ref2.abs().max().item()
+    print(f"chained layer 2: err {(h2.double() - ref2).abs().max().item() / sc:.2e}  library {(lib2.double() - ref2).abs().max().item() / sc:.2e};"
+          f"  layer 1 (unscaled unit-norm A) err {(h1.double() - ref1).abs().max().item() / ref1.abs().max().item():.2e};  two layers {timeit(two_layers):.1f} us")
+
