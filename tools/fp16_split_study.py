@@ -102,3 +102,35 @@ b = torch.randn(N, K) * torch.pow(10.0, torch.randint(-3, 4, (N, 1)).float())
 study("twelve decades of row scales", a, b)
 c = torch.randn(M, K) * torch.pow(10.0, torch.randint(-4, 1, (M, K)).float())   # wide dynamic range INSIDE a row
 study("five decades inside every row", c, w)
+
+
+# ---- the weight gradient dW = g^T x: the reduction runs over the rows, so the power-of-two scale has to be per COLUMN -----------
+def study_wgrad(name, G, X):
+    ref = G.double().t() @ X.double()
+    scale = ref.abs().max().item()
+    res = {}
+
+    def rec(tag, Cm):
+        res[tag] = (Cm.double() - ref).abs().max().item() / scale
+
+    rec("library fp32", G.t() @ X)
+    g3, x3 = bf16_pieces(G, 3), bf16_pieces(X, 3)
+    t = lambda a, b: a.t() @ b   # noqa: E731
+    rec("bf16 x3, 6 products (ships)", ((((t(g3[1], x3[1]) + t(g3[2], x3[0])) + t(g3[0], x3[2])) + t(g3[1], x3[0])) + t(g3[0], x3[1])) + t(g3[0], x3[0]))
+    for norm in (False, True):
+        sg = row_pow2(G.t().contiguous()).t() if norm else torch.ones(1, G.shape[1])     # [1, N]: per column of G
+        sx = row_pow2(X.t().contiguous()).t() if norm else torch.ones(1, X.shape[1])
+        g2, x2 = fp16_pieces(G / sg, 2), fp16_pieces(X / sx, 2)
+        rec(f"fp16 x2 {'column-normalised' if norm else 'raw'}, 3 products", ((t(g2[1], x2[0]) + t(g2[0], x2[1])) + t(g2[0], x2[0])) * sg.t() * sx)
+    print(f"== wgrad {name}: G {tuple(G.shape)}, X {tuple(X.shape)}   (max err / max|dW|)")
+    for k, e in res.items():
+        print(f"   {k:58s} {e:10.3e}")
+
+
+Mw = 32768
+xw = torch.nn.functional.normalize(torch.randn(Mw, 768), dim=-1)
+hw = torch.relu(xw @ (torch.randn(512, 768) / 768 ** 0.5).t())
+gw = torch.randn(Mw, 512) * (1.0 / Mw) * (hw > 0)                                   # a masked gradient at the 1 / B scale
+study_wgrad("layer 1 (masked 1/B-scale gradient x unit-norm input)", gw, xw)
+gh = torch.randn(Mw, 256) * (1.0 / Mw) * torch.pow(10.0, torch.randint(-3, 1, (Mw, 1)).float())   # rows spread over three decades
+study_wgrad("layer 2 (gradient rows over three decades x post-ReLU activations)", gh, hw)
