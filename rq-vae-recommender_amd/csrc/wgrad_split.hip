@@ -35,6 +35,10 @@ typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned ws_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWsRows = 16;   // rows per LDS stage = one K step of the matrix instruction
+#ifndef WS_F16   // 1 (developer builds; PROTOTYPE, not run on a GPU yet): two fp16 pieces per operand and the three products
+#define WS_F16 0 // hh + hm + mh, every COLUMN of g_pre and of x scaled by an exact power of two (the reduction runs over the rows, so
+#endif           // the scale must be constant along them) -- csrc/gemm_split.hip GS_F16, DESIGN.md section 9, tools/fp16_split_study.py
+constexpr int kWsNP = WS_F16 ? 2 : 3;   // pieces per operand
 
 struct WgradSplitParams {
     const float *g, *y, *x;
@@ -43,6 +47,9 @@ struct WgradSplitParams {
     int N, K;
     int nslab_n, nslab_k, msplit;
     long long n_chunks;   // ceil(M / 32): the row ranges are cut on wgrad.hip's 32-row granules
+#if WS_F16
+    const unsigned *g_max, *x_max;   // [N], [K] bit patterns of the columns' largest |value| (col_maxima_kernel / an epilogue), or nullptr
+#endif
 };
 
 // (a, b) -> three dwords, each the packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
@@ -57,6 +64,41 @@ __device__ __forceinline__ void ws_split2(float a, float b, unsigned &h, unsigne
     l = __builtin_bit_cast(unsigned, ll);
 }
 
+#if WS_F16
+typedef _Float16 ws_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ws_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ws_split2_f16(float a, float b, unsigned &h, unsigned &m) {
+    const ws_f16x2 hh = __builtin_convertvector(ws_f32x2{a, b}, ws_f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const ws_f32x2 hf = __builtin_convertvector(hh, ws_f32x2);
+    const ws_f16x2 mm = __builtin_convertvector(ws_f32x2{a - hf.x, b - hf.y}, ws_f16x2);
+    m = __builtin_bit_cast(unsigned, mm);
+}
+__device__ __forceinline__ int ws_exp_of_bits(unsigned b) {   // floor(log2) of the positive float with these bits; 0 for 0 / inf / nan
+    b &= 0x7fffffffu;
+    const int e = (int)(b >> 23);
+    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127);
+}
+// mx[c] = max over the rows of |A[m, c]| as bit patterns (unsigned atomic max: the result does not depend on the order); mx zeroed
+// by the caller.  256 threads: 64 columns x 4 row lanes; a block takes 1024 rows of one 64-column strip.
+__global__ __launch_bounds__(256) void col_maxima_kernel(const float *__restrict__ A, long long M, int Cn, unsigned *__restrict__ mx) {
+    const int strips = (Cn + 63) / 64;
+    const int strip = blockIdx.x % strips;
+    const long long r0 = (long long)(blockIdx.x / strips) * 1024;
+    const int c = strip * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float m = 0.0f;
+    if (c < Cn)
+        for (long long r = r0 + rl; r < M && r < r0 + 1024; r += 4) m = fmaxf(m, fabsf(A[(size_t)r * Cn + c]));
+    __shared__ float red[4][64];
+    red[rl][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (rl == 0 && c < Cn) {
+        m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+        atomicMax(mx + c, __builtin_bit_cast(unsigned, m));
+    }
+}
+#endif
+
 // TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given
 template <int TA, int TB, int WA, int WB, bool MASK>
 __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSplitParams p) {
@@ -69,7 +111,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     // ds_write_b64 -- 1.7 us of the 3.2 us a stage took); the 16 lanes an operand read serves per cycle (columns
     // c0 .. c0 + 15) hit positions g * S + q0 .. q0 + 3, g < 4: distinct modulo 16 because S = 4 (mod 16).
     constexpr int SG = Nt / 4 + 4, SX = Kt / 4 + 4;
-    constexpr int PART_G = 3 * 2 * 4 * SG * 4, PART_X = 3 * 2 * 4 * SX * 4;   // dwords
+    constexpr int PART_G = kWsNP * 2 * 4 * SG * 4, PART_X = kWsNP * 2 * 4 * SX * 4;   // dwords
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(ws_smem);      // [2][PART_G + PART_X]
 
@@ -103,6 +145,21 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
     ws_f32x4 rv[UQ][4], ry[MASK ? UQ : 1][4];
+#if WS_F16
+    int ue[UQ][4];   // exponents of the four columns of each of this thread's staging units
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) {
+        const int u = tid + q * NT;
+        const bool isg = u < Nt;
+        const int idx = isg ? u : u - Nt, W = isg ? Nt : Kt;
+        const int cq = idx % (W / 4);
+        const unsigned *mxp = isg ? p.g_max : p.x_max;
+        const int c0 = isg ? n0 : k0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            ue[q][cc] = (mxp && ((UNITS % NT == 0) || u < UNITS)) ? ws_exp_of_bits(mxp[c0 + 4 * cq + cc]) : 0;
+    }
+#endif
     auto fetch = [&](long long stage) {
         const long long row0 = r_begin + stage * kWsRows;
 #pragma unroll
@@ -157,12 +214,18 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 unsigned h01, m01, l01, h23, m23, l23;
+#if WS_F16
+                ws_split2_f16(ldexpf(rv[q][0][cc], -ue[q][cc]), ldexpf(rv[q][1][cc], -ue[q][cc]), h01, m01);
+                ws_split2_f16(ldexpf(rv[q][2][cc], -ue[q][cc]), ldexpf(rv[q][3][cc], -ue[q][cc]), h23, m23);
+                l01 = l23 = 0u;
+#else
                 ws_split2(rv[q][0][cc], rv[q][1][cc], h01, m01, l01);
                 ws_split2(rv[q][2][cc], rv[q][3][cc], h23, m23, l23);
+#endif
                 const int pos = cc * (S4 / 4) + cq;      // column 4 cq + cc
                 *reinterpret_cast<ws_u32x2 *>(part + ((0 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{h01, h23};
                 *reinterpret_cast<ws_u32x2 *>(part + ((1 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{m01, m23};
-                *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{l01, l23};
+                if (kWsNP == 3) *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{l01, l23};
             }
         }
     };
@@ -184,16 +247,16 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     auto multiply = [&](int buf) {
         const ws_bf16x8 *gA = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X));
         const ws_bf16x8 *xB = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X) + PART_G);
-        ws_bf16x8 a[TA][3], b[TB][3];
+        ws_bf16x8 a[TA][kWsNP], b[TB][kWsNP];
 #pragma unroll
         for (int t = 0; t < TA; ++t)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < kWsNP; ++pc)
                 a[t][pc] = gA[(pc * 2 + h) * (4 * SG) + (il & 3) * SG + ((wa * 32 * TA + 32 * t + il) >> 2)];
 #pragma unroll
         for (int u = 0; u < TB; ++u)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < kWsNP; ++pc)
                 b[u][pc] = xB[(pc * 2 + h) * (4 * SX) + (il & 3) * SX + ((wb * 32 * TB + 32 * u + il) >> 2)];
         // smallest products first (their sum is formed before it meets the large ones)
 #pragma unroll
@@ -201,12 +264,18 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 ws_f32x16 c16 = acc[t][u];
+#if WS_F16
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][1]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // m h
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][1]), c16, 0, 0, 0);   // h m
+                c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // h h
+#else
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][1], c16, 0, 0, 0);   // m m
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[u][0], c16, 0, 0, 0);   // l h
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][2], c16, 0, 0, 0);   // h l
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][0], c16, 0, 0, 0);   // m h
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][1], c16, 0, 0, 0);   // h m
                 c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][0], c16, 0, 0, 0);   // h h
+#endif
                 acc[t][u] = c16;
             }
     };
@@ -234,6 +303,14 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+#if WS_F16
+                {   // undo the column scales (exact)
+                    const int k = k0 + wb * 32 * TB + 32 * u + il;
+                    const int e = (p.g_max ? ws_exp_of_bits(p.g_max[n]) : 0) + (p.x_max ? ws_exp_of_bits(p.x_max[k]) : 0);
+                    dst[(size_t)n * p.K + k] = ldexpf(acc[t][u][r], e);
+                    continue;
+                }
+#endif
                 dst[(size_t)n * p.K + k0 + wb * 32 * TB + 32 * u + il] = acc[t][u][r];
             }
 }
@@ -249,7 +326,7 @@ int wgrad_split_cfg(int N, int K) {
 template <int TA, int TB, int WA, int WB>
 static int wgrad_split_go(const WgradSplitParams &p, bool mask, hipStream_t s) {
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB;
-    const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * 3 * 2 * 16;
+    const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * kWsNP * 2 * 16;
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
@@ -260,6 +337,9 @@ static int wgrad_split_go(const WgradSplitParams &p, bool mask, hipStream_t s) {
     return mask ? go(wgrad_split_kernel<TA, TB, WA, WB, true>) : go(wgrad_split_kernel<TA, TB, WA, WB, false>);
 }
 
+#if WS_F16
+static const unsigned *g_ws_g_max = nullptr, *g_ws_x_max = nullptr;   // (prototype plumbing: the column maxima of the next launch)
+#endif
 // called by rqhip_linear_wgrad_ex (wgrad.hip), which owns the plan (row ranges, workspace) and the reduce kernel
 int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
                        int nslab_n, int nslab_k, int msplit, hipStream_t s) {
@@ -267,6 +347,10 @@ int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, 
     p.g = g; p.y = y; p.x = x; p.gm = gm; p.out = out;
     p.M = M; p.N = N; p.K = K; p.nslab_n = nslab_n; p.nslab_k = nslab_k; p.msplit = msplit;
     p.n_chunks = (M + 31) / 32;
+#if WS_F16
+    p.g_max = g_ws_g_max;
+    p.x_max = g_ws_x_max;
+#endif
     const bool mask = y != nullptr;
     switch (cfg) {
         case 0: return wgrad_split_go<4, 2, 2, 4>(p, mask, s);    // 256 x 256, 8 waves of 128 x 64
@@ -276,3 +360,20 @@ int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, 
 }
 
 }  // namespace rqhip
+
+#if WS_F16
+// column maxima (bit patterns, unsigned atomic max into a buffer the caller zeroed) of A [M, Cn]
+extern "C" int rqhip_col_maxima(const float *A, int64_t M, int Cn, unsigned *mx, rqhip_stream_t stream) {
+    if (M <= 0 || Cn <= 0 || !A || !mx) return RQHIP_EARG;
+    const int strips = (Cn + 63) / 64;
+    hipLaunchKernelGGL(rqhip::col_maxima_kernel, dim3((unsigned)(strips * ((M + 1023) / 1024))), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), A, (long long)M, Cn, mx);
+    return RQHIP_OK;
+}
+// the column maxima of g_pre and x for the NEXT rqhip_linear_wgrad(_ex) call on this thread (nullptr: unscaled)
+extern "C" int rqhip_wgrad_split_set_maxima(const unsigned *g_max, const unsigned *x_max) {
+    rqhip::g_ws_g_max = g_max;
+    rqhip::g_ws_x_max = x_max;
+    return RQHIP_OK;
+}
+#endif
