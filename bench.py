@@ -85,9 +85,11 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
-    ap.add_argument("--mlp", choices=("split", "library"), default="split",
-                    help="A/B only: `library` runs the MLP GEMMs as library fp32 GEMMs and the weight gradients on the "
-                         "fp32-MFMA kernel (round 2's step); the product default is `split` (csrc/gemm_split.hip, wgrad_split.hip)")
+    ap.add_argument("--mlp", choices=("split", "split6", "library"), default="split",
+                    help="A/B only.  `split` (the product): the MLP GEMMs and weight gradients as two fp16 pieces per operand "
+                         "under exact power-of-two scales, three piece products (csrc/gemm_split.hip, wgrad_split.hip); `split6`: "
+                         "round 3's three bf16 pieces and six products; `library`: library fp32 GEMMs and the fp32-MFMA weight "
+                         "gradients (round 2's step)")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="if the K timed steps took less, also time a longer region and report it as `long_run`")
     return ap.parse_args()
@@ -274,12 +276,8 @@ def main():
     torch.cuda.set_device(device)
 
     tuned = tuning.enable_tuned_gemms()   # fp32 library-GEMM selections for the MLP layers the split kernels do not tile
-    if args.mlp == "library":             # A/B arm (tools/profile_mlp_ab.sh): round 2's step
-        from modules import encoder as _enc
-        from rqhip import linear as _lin
-        _lin.use_split_gemms(False)
-        _wg = ops.linear_wgrad
-        _enc.ops.linear_wgrad = ops.linear_wgrad = lambda *a, **k: _wg(*a, **dict(k, exact_fp32=True))
+    from rqhip import linear as _lin
+    _lin.use_arith({"split": "f16x2", "split6": "bf16x3", "library": "fp32"}[args.mlp])   # (A/B arms: tools/profile_mlp_ab.sh)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)
     for lo in range(0, B, 250_000):        # generated in host chunks: 1.25 M x 768 fp32 is 3.8 GB
@@ -306,6 +304,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     ops.profile_enable(steps * n_micro + 8)
+    ops.profile_select("rq_forward")      # the timed region records the scan kernel only (one event pair per micro-batch)
     rqdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -342,6 +341,19 @@ def main():
                     "why": f"the {steps} timed steps took {elapsed:.3f} s < --min-seconds {args.min_seconds}"}
 
     # ---- untimed from here ------------------------------------------------------------------------------
+    # Per-kernel records for `roofline_kernels`: the same step, every library launch bracketed by HIP events on its stream
+    # (rqhip_profile_*: tag, duration, algorithmic FLOPs and bytes of the launch).  Its own region because ~50 event pairs
+    # per step are not free; the records of `roofline` above come from the timed region itself.
+    n_prof = min(steps, 20)
+    ops.profile_enable(n_prof * n_micro * 48 + 64)
+    ops.profile_select()
+    torch.cuda.synchronize()
+    for _ in range(n_prof):
+        out = step()
+    torch.cuda.synchronize()
+    prof_records = ops.profile_read_tagged(n_prof * n_micro * 48 + 64)
+    ops.profile_enable(0)
+
     def timed(fn):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -418,7 +430,7 @@ def main():
         traffic, traffic_src = None, None
         from rqhip import _lib as _rqlib
         lib_sha = _sha256_file(_rqlib.SO_PATH)
-        pmc = args.pmc_file or os.path.join(ROOT, "profiles", f"r03_pmc_traffic_{args.config}.json")
+        pmc = args.pmc_file or os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{args.config}.json")
         if not os.path.exists(pmc):
             traffic_src = f"null: no PMC file {os.path.relpath(pmc, ROOT)}"
         elif B != cfg["rows"]:
@@ -435,6 +447,51 @@ def main():
                                f"sha256 {lib_sha[:16]} as this run)")
         f32_mean = float(np.mean(f32_ms)) if f32_ms else float("nan")
         step_tflops = step_flops_per_row * B / (ms_per_step * 1e-3) / 1e12
+        # ---- the kernels that dominate the step ------------------------------------------------------
+        issued_mult = {"split": 3.0, "split6": 6.0, "library": 1.0}[args.mlp]   # matrix-instruction FLOPs per algorithmic FLOP
+        issued_peak = PEAK_FP32_MFMA_TFLOPS if args.mlp == "library" else PEAK_BF16_MFMA_TFLOPS   # (fp16 and bf16 dense peaks are equal)
+        groups = {}
+        for kind, ms, fl, by in prof_records:
+            key = (kind, fl, by)
+            groups.setdefault(key, []).append(ms)
+        pmc_k = {}
+        pmc_all = os.path.join(ROOT, "profiles", f"r04_pmc_kernels_{args.config}.json")
+        if os.path.exists(pmc_all):
+            with open(pmc_all) as fh:
+                pj = json.load(fh)
+            if pj.get("librqhip_sha256") == lib_sha:
+                pmc_k = pj.get("kernels", {})
+        rk = []
+        for (kind, fl, by), mss in groups.items():
+            mean = float(np.mean(mss))
+            matrix = kind in ("gemm_split", "wgrad") and fl >= 2.0 * 4096 * 128 * 256
+            e = {"kernel": kind, "calls_per_step": round(len(mss) / n_prof, 2), "mean_us": round(mean * 1e3, 2),
+                 "step_us": round(float(np.sum(mss)) / n_prof * 1e3, 1),
+                 "algorithmic_gflop": round(fl / 1e9, 3), "algorithmic_mb": round(by / 1e6, 2),
+                 "achieved_tflops": round(fl / (mean * 1e-3) / 1e12, 2),
+                 "achieved_gbps": round(by / (mean * 1e-3) / 1e9, 1),
+                 "frac_vs_fp32_peak": round(fl / (mean * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "frac_vs_hbm_peak": round(by / (mean * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
+            if matrix:
+                e["issued_tflops"] = round(issued_mult * fl / (mean * 1e-3) / 1e12, 1)
+                e["frac_vs_issued_dtype_peak"] = round(issued_mult * fl / (mean * 1e-3) / 1e12 / issued_peak, 4)
+            e["bound"] = "mfma" if (matrix or kind == "rq_forward") else "hbm"
+            tr = pmc_k.get(f"{kind}:{int(fl)}:{int(by)}")
+            e["traffic_ratio"] = round(tr / by, 3) if (tr and by) else None
+            rk.append(e)
+        rk.sort(key=lambda e: -e["step_us"])
+        gemm_us = sum(e["step_us"] for e in rk if "issued_tflops" in e)
+        gemm_issued = sum(e["issued_tflops"] * e["step_us"] for e in rk if "issued_tflops" in e) / max(gemm_us, 1e-9)
+        roofline_kernels = {
+            "how": f"HIP events around every library launch (rqhip_profile_*) over {n_prof} steps run after the timed region; "
+                   "FLOPs / bytes are ALGORITHMIC (2 M N K per GEMM; operands and results once); issued = matrix-instruction "
+                   f"FLOPs ({issued_mult:g} piece products per product); peaks: fp32 157.3 TF/s, fp16/bf16 dense 2500 TF/s, HBM 8 TB/s",
+            "recorded_us_per_step": round(sum(e["step_us"] for e in rk), 1),
+            "matrix_kernels": {"us_per_step": round(gemm_us, 1), "share_of_step": round(gemm_us / (ms_per_step * 1e3), 3),
+                               "issued_tflops_time_weighted": round(gemm_issued, 1),
+                               "frac_of_issued_dtype_peak": round(gemm_issued / issued_peak, 4)},
+            "kernels": rk[:12],
+        }
         workload = {
             "c2": "C2: synthetic 100000x768 unit-norm items per GPU -> RQ-VAE 768-[512,256,128]-32, 3x256 codebooks, "
                   "STE (Gumbel off), one fwd+bwd+allreduce+AdamW step per HBM-resident batch",
@@ -478,9 +535,21 @@ def main():
                          "hbm_view": {"algorithmic_bytes_per_row": bytes_per_row,
                                       "achieved_GBps": round(bytes_per_row * Bm / (mean_ms * 1e-3) / 1e9, 1),
                                       "peak_GBps": PEAK_HBM_GBPS},
-                         "whole_step": {"flops_per_row": step_flops_per_row, "achieved_TFLOPs": round(step_tflops, 2),
-                                        "step_frac_of_fp32_peak": round(step_tflops / PEAK_FP32_MFMA_TFLOPS / world, 4),
-                                        "note": "all GEMM + RQ FLOPs of fwd+bwd per GPU / ms_per_step / 157.3"}},
+                         "whole_step": {"flops_per_row": step_flops_per_row, "achieved_TFLOPs": round(step_tflops / world, 2),
+                                        "issued_dtype_frac": roofline_kernels["matrix_kernels"]["frac_of_issued_dtype_peak"],
+                                        "fp32_equivalent_frac": round(step_tflops / PEAK_FP32_MFMA_TFLOPS / world, 4),
+                                        "note": "issued_dtype_frac: matrix-instruction FLOPs of the GEMM kernels / their time / "
+                                                "the dense peak of the dtype they issue (see roofline_kernels); "
+                                                "fp32_equivalent_frac: all GEMM + RQ FLOPs of fwd+bwd per GPU / ms_per_step / "
+                                                "157.3 -- above 1 is possible, the kernels do not use the fp32 pipe"}},
+            "roofline_kernels": roofline_kernels,
+            "arithmetic": {"split": "f16x2: MLP GEMMs and weight gradients as two fp16 pieces per fp32 operand (11 + 11 significant "
+                                    "bits + sign) under exact power-of-two row / column scales, products hh + hm + mh on "
+                                    "v_mfma_f32_32x32x16_f16, fp32 accumulation -- an emulation of fp32 GEMMs held to `max error "
+                                    "vs fp64 <= the library fp32 GEMM's` on every operand family of tests/test_gpu_gemm_split.py; "
+                                    "the RQ kernels are fp32 (bit-exact vs the oracle)",
+                           "split6": "bf16x3: three exact bf16 pieces per operand, six products (round 3)",
+                           "library": "fp32 library GEMMs + fp32-MFMA weight gradients (round 2)"}[args.mlp],
             "breakdown_ms": {"rows": Bm, "encoder_fwd": round(enc_ms, 3), "rq_forward_call": round(rq_ms, 3),
                              "model_fwd_total": round(fwd_ms, 3), "backward_total": round(bwd_ms, 3),
                              "allreduce_ms": round(allreduce_ms, 4), "adamw": round(opt_ms, 3),
@@ -491,12 +560,8 @@ def main():
                           "tokenize_items_per_s": round(Bm / tok_ms * 1e3, 1), "tokenize_ms": round(tok_ms, 4),
                           "note": "per GPU; S-rq = HIP quantisation stack fwd+bwd on 32-d latents, tokenize = "
                                   "get_semantic_ids (encoder GEMMs + HIP RQ, eval)"},
-            "mlp_gemms": ("csrc/gemm_split.hip + csrc/wgrad_split.hip: every fp32 operand as three exact bf16 pieces, six piece "
-                          "products on v_mfma_f32_32x32x16_bf16, fp32 accumulation (error against fp64 <= the library fp32 "
-                          "GEMM's on the same inputs: tests/test_gpu_gemm_split.py, test_gpu_wgrad.py); layers narrower "
-                          "than 256 columns: " if args.mlp == "split" else "A/B arm --mlp library: ")
-                         + "PyTorch-ROCm fp32 GEMMs (matmul precision highest), TunableOp selections "
-                         + ("loaded" if tuned else "off"),
+            "mlp_gemms": (f"--mlp {args.mlp} (see `arithmetic`); layers narrower than 256 columns: PyTorch-ROCm fp32 GEMMs (matmul "
+                          "precision highest), TunableOp selections " + ("loaded" if tuned else "off")),
             "final_loss": round(final_loss, 6), "p_unique_ids": round(p_unique, 6),
             "librqhip_sha256": lib_sha,
         }

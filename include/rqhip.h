@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 301 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon */
+#define RQHIP_VERSION 400 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+                            400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
 #define RQHIP_EARG (-1)         /* bad pointer / size / mode */
@@ -106,7 +107,8 @@ int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const float *codebo
 /* The filtered scan's too-close-to-call threshold, distance units: a row is re-decided exactly unless the gap between its
  * two smallest approximate distances exceeds  c1 * |x| * max_k|c_k| + c2 * (|x|^2 + max_k|c_k|^2).  Host-side accessor (no
  * GPU needed): tests/test_filter_bound.py checks the constants against the error bound derived in DESIGN.md section 4.1. */
-void rqhip_filter_bound(float *c1, float *c2);
+void rqhip_filter_bound(float *c1, float *c2);             /* D = 32 */
+void rqhip_filter_bound_d(int D, float *c1, float *c2);    /* per embedding width: D = 64 uses c1 = 2^-11 */
 /* Test hook for that bound: scores[b,k] = the approximate score x_b.c_k - |c_k|^2/2 exactly as the filtered scan's
  * matrix-instruction chain produces it (same staging, same split, same instruction order), D = 32 / 64, x [B,D],
  * codebook [K,D], scores [B,K].  tests/test_gpu_filter_bound.py compares it with the real-arithmetic score on adversarial
@@ -306,42 +308,123 @@ int rqhip_linear_wgrad(const float *g, const float *y, const float *x, int64_t M
 int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                           float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
                           unsigned flags, rqhip_stream_t stream);
+/* The weight gradient in RQHIP_SPLIT_F16X2 arithmetic (the product path for the layers csrc/wgrad_split.hip tiles; see the
+ * GEMM section below): the reduction runs over the batch rows, so the exact power-of-two scales are per COLUMN of g and of
+ * x -- g_col_max [N], x_col_max [K]: bit patterns of the columns' largest |value| (rqhip_maxima, or the c_col_max of the
+ * epilogue that wrote the matrix); two fp16 pieces per scaled value, products hh + hm + mh, the result multiplied back by
+ * 2^(e_n + e_k).  With y given the ReLU mask is applied inside as above and g_col_max may hold the maxima of the unmasked
+ * g (an upper bound costs low-order bits of the small elements only).  Same row ranges, reduction tree and workspace as
+ * rqhip_linear_wgrad; layers the split kernel does not tile run the fp32 kernel and ignore the maxima. */
+int rqhip_linear_wgrad_f16(const float *g, const float *y, const float *x, int64_t M, int N, int K,
+                           const unsigned *g_col_max, const unsigned *x_col_max, float *g_masked, float *dW,
+                           void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The activation GEMMs of the MLPs (reference modules/encoder.py:25-38: `relu(x W^T)` forward; autograd's `g W` data
- * gradient) on the bf16 matrix cores with three exact bf16 pieces per fp32 operand and the six piece products that matter
- * (csrc/gemm_split.hip; same arithmetic as the bf16-split weight gradient above).
- *   rqhip_weight_planes : split a weight matrix w [rows, cols] once per step into the kernel's image.  transpose = 0: the
- *       image of w itself (Nc = rows output columns, reduction R = cols: the forward, C = A w^T); transpose = 1: of w^T
- *       (Nc = cols, R = rows: the data gradient, C = A w).  `planes`: rqhip_weight_planes_bytes(Nc, R) bytes, caller-owned.
- *   rqhip_gemm_split    : C [M, Nc] = A [M, R] . image^T, optional ReLU.  Needs Nc % 128 == 0 (256-column tiles when Nc % 256 == 0, else 128), R % 16 == 0
- *       (rqhip_gemm_split_supported), 16-byte aligned pointers; one launch at a time per image (it holds the kernel's
- *       tile dispenser).  Results are bit-reproducible; accuracy against fp64 is that of an fp32 GEMM (tests).
+ * gradient and ReLU backward; modules/rqvae.py:146,152 + modules/loss.py:5-10: the last decoder layer with the
+ * reconstruction loss) on the 16-bit matrix cores, carrying fp32's accuracy (csrc/gemm_split.hip).  Two arithmetics:
+ *   RQHIP_SPLIT_F16X2  (the product path) every row of A and every weight row is scaled by an exact power of two (the
+ *       exponent of its largest |value|), every scaled value is split into two fp16 pieces (11 + 11 significant bits and a
+ *       sign), the product is hh + hm + mh (each piece product exact in fp32, fp32 accumulation), and the epilogue multiplies
+ *       back by 2^(e_row + e_column).  Needs the row maxima of A: `a_row_max`, written by the kernel that produced A (every
+ *       epilogue below can emit the row / column maxima of what it stores) or by rqhip_maxima.
+ *   RQHIP_SPLIT_BF16X3 (round 3, kept for A/B) three exact bf16 pieces per operand, six products, no scaling.
+ * Both are held to: max error against fp64 <= the library fp32 GEMM's on the same inputs (tests/test_gpu_gemm_split.py:
+ * unit-norm rows, post-ReLU activations, 1e-5-scale masked gradients, twelve decades of row scales, five decades inside a
+ * row, the worst-case mantissas of the 11-bit split, cancellation-heavy rows), results bit-reproducible run to run.
+ *
+ *   rqhip_weight_images : split weight matrices w [rows, cols] into the kernel's images, ALL jobs in one launch (an MLP's
+ *       layers, both directions).  transpose = 0: the image of w itself (Nc = rows output columns, reduction R = cols: the
+ *       forward, C = A w^T); transpose = 1: of w^T (Nc = cols, R = rows: the data gradient, C = A w).  `image`:
+ *       rqhip_weight_image_bytes(Nc, R, arith) bytes, caller-owned, 16-byte aligned.  `jobs` is a HOST array.
+ *   rqhip_maxima        : row_max [M] and / or col_max [R] (bit patterns of the largest |value|; col_max is maxed into
+ *       atomically: zero it first) of A [M, R] in one pass; with Y given, of A masked by Y > 0 (the ReLU backward), which is
+ *       also written to masked_out when that is not NULL.  R % 4 == 0, R <= 1024.
+ *   rqhip_gemm_split_ex : C [M, Nc] = epilogue(A [M, R] . image^T).  Needs Nc % 128 == 0 (256-column tiles when
+ *       Nc % 256 == 0, else 128), R % 16 == 0 (rqhip_gemm_split_supported), 16-byte aligned pointers; one launch at a time
+ *       per image (it holds the kernel's tile dispenser).
  */
+#define RQHIP_SPLIT_F16X2 0
+#define RQHIP_SPLIT_BF16X3 1
+#define RQHIP_EPI_STORE 0
+#define RQHIP_EPI_RELU 1  /* C = relu(A.B^T) */
+#define RQHIP_EPI_RECON 2 /* the last decoder layer fused with ReconstructionLoss: x_hat = A.B^T is never stored; loss_rows[m] =
+                             sum_n (x_hat - aux)^2 and C = (2 (x_hat - aux)) * row_scale, the gradient `(reconstruction +
+                             quantize_loss).mean().backward()` sends back when row_scale = loss scale / B.  Nc % 256 == 0;
+                             workspace: rqhip_gemm_split_recon_workspace_bytes(M, Nc) bytes */
+#define RQHIP_EPI_MASK 3  /* C = A.B^T where aux > 0, else 0: a data gradient fused with the ReLU backward of the layer below
+                             (aux = that layer's output); RQHIP_SPLIT_F16X2 only */
+typedef struct {
+    const float *w;      /* [rows, cols] */
+    int rows, cols, transpose, arith;
+    void *image;
+    size_t image_bytes;
+} rqhip_image_job;
+typedef struct {
+    const float *A;      /* [M, R] */
+    int64_t M;
+    int R;
+    const void *image;   /* of B [Nc, R] (rqhip_weight_images) */
+    int Nc;
+    int arith;           /* RQHIP_SPLIT_* the image was built with */
+    int epilogue;        /* RQHIP_EPI_* */
+    int tile_rows;       /* 0 (tools only: 64 / 256 force one tile height) */
+    float *C;            /* [M, Nc] */
+    const float *aux;    /* RQHIP_EPI_RECON: X [M, Nc]; RQHIP_EPI_MASK: Y [M, Nc]; else NULL */
+    float row_scale;     /* RQHIP_EPI_RECON */
+    float *loss_rows;    /* RQHIP_EPI_RECON: [M] */
+    void *workspace;     /* RQHIP_EPI_RECON */
+    size_t workspace_bytes;
+    const unsigned *a_row_max; /* RQHIP_SPLIT_F16X2: [a_row_parts][M]; a row's largest |value| is the maximum over the parts */
+    int a_row_parts;
+    unsigned *c_row_max; /* optional output [column tiles][M] (Nc / 256 tiles when Nc % 256 == 0, else Nc / 128): largest |value| of
+                            each row of C per column tile (plain stores) */
+    unsigned *c_col_max; /* optional output [Nc]: largest |value| of each column of C, maxed into atomically (zero it first) */
+} rqhip_gemm_args;
 int rqhip_gemm_split_supported(int Nc, int R);
+size_t rqhip_weight_image_bytes(int Nc, int R, int arith);
+int rqhip_weight_images(const rqhip_image_job *jobs, int n_jobs, rqhip_stream_t stream);
+int rqhip_maxima(const float *A, const float *Y, float *masked_out, int64_t M, int R, unsigned *row_max, unsigned *col_max,
+                 rqhip_stream_t stream);
+size_t rqhip_gemm_split_recon_workspace_bytes(int64_t M, int Nc);
+int rqhip_gemm_split_ex(const rqhip_gemm_args *args, rqhip_stream_t stream);
+/* the round-3 entry points: RQHIP_SPLIT_BF16X3 with one image per call */
 size_t rqhip_weight_planes_bytes(int Nc, int R);
 int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void *planes, size_t planes_bytes,
                         rqhip_stream_t stream);
 int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
                      rqhip_stream_t stream);
-/* The last decoder layer fused with ReconstructionLoss (reference modules/rqvae.py:146,152 + modules/loss.py:5-10):
- * x_hat = A . image^T is never stored; loss_rows[m] = sum_n (x_hat - X)^2 and G = (2 (x_hat - X)) * row_scale, the gradient
- * `(reconstruction + quantize_loss).mean().backward()` sends back when row_scale = loss scale / B.
- * rqhip_recon_rescale_rows is its backward fix-up: rows of g_out that are not row_scale (bit compare) get G * (g / row_scale).
- * workspace: rqhip_gemm_split_recon_workspace_bytes(M, Nc) bytes (per-column-tile row sums, summed in tile order). */
-size_t rqhip_gemm_split_recon_workspace_bytes(int64_t M, int Nc);
 int rqhip_gemm_split_recon(const float *A, int64_t M, int R, const void *planes, int Nc, const float *X, float row_scale,
                            float *G, float *loss_rows, void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
+/* backward fix-up of RQHIP_EPI_RECON: rows of g_out that are not row_scale (bit compare) get G * (g / row_scale) */
 int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_scale, float *g_spec, rqhip_stream_t stream);
+/* ... which also brings the maxima the epilogue emitted for G up to date for the rows it changes: row_max [row_parts][B]
+ * (the row's new maximum in part 0, the other parts cleared) and col_max [N] (maxed into); either may be NULL */
+int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_scale, float *g_spec, unsigned *row_max,
+                                int row_parts, unsigned *col_max, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Kernel timing for bench.py's roofline line (no reference counterpart).  While enabled, every
- * rqhip_rq_forward call brackets its MAIN kernel (not the codebook-norm prologue) with a hipEvent pair
- * recorded on the call's stream.  rqhip_profile_read synchronises the recorded events and returns the
- * per-launch durations in milliseconds (at most `cap`), then clears the log.
+ * Kernel timing for bench.py's roofline objects (no reference counterpart).  While enabled, the calls below bracket
+ * their MAIN kernel(s) with a hipEvent pair recorded on the call's stream and note what the launch was: a tag, its
+ * algorithmic FLOPs and its algorithmic bytes.  rqhip_profile_read_tagged synchronises the recorded events and returns
+ * the per-launch records (at most `cap`), then clears the log; rqhip_profile_read returns the durations of the
+ * RQHIP_PROF_RQ_FORWARD records only (round 1's interface) and clears the log too.
  */
+#define RQHIP_PROF_RQ_FORWARD 1  /* rqhip_rq_forward(_ex): the scan kernel, not the codebook-norm prologue */
+#define RQHIP_PROF_RQ_BACKWARD 2 /* rqhip_rq_backward: all of its kernels (flat kernel + table reduce) */
+#define RQHIP_PROF_GEMM_SPLIT 3  /* rqhip_gemm_split_ex */
+#define RQHIP_PROF_WGRAD 4       /* rqhip_linear_wgrad*: the kernel and its partial-sum reduction */
+#define RQHIP_PROF_MAXIMA 5      /* rqhip_maxima */
+#define RQHIP_PROF_IMAGES 6      /* rqhip_weight_images */
+typedef struct {
+    int tag;
+    float ms;
+    double flops, bytes;
+} rqhip_profile_record;
 int rqhip_profile_enable(int max_records); /* 0 disables and frees the events */
+int rqhip_profile_select(unsigned tag_mask); /* bit t set: record launches tagged t (default: all) */
 int rqhip_profile_read(float *ms_out, int cap, int *n_out);
+int rqhip_profile_read_tagged(rqhip_profile_record *out, int cap, int *n_out);
 
 #ifdef __cplusplus
 }

@@ -46,12 +46,16 @@ int fill_words(void *dst, uint32_t word, size_t bytes, hipStream_t s) {
 }
 
 static hipEvent_t *g_ev = nullptr;   // 2 * g_cap events
+struct ProfNote { int tag; double flops, bytes; };
+static ProfNote *g_note = nullptr;   // g_cap notes
 static int g_cap = 0, g_n = 0;
+static unsigned g_mask = ~0u;        // bit t set: launches tagged t are recorded
 static bool g_open = false;
 
-void profile_begin(hipStream_t s) {
+void profile_begin(hipStream_t s, int tag, double flops, double bytes) {
     g_open = false;
-    if (g_cap == 0 || g_n >= g_cap) return;
+    if (g_cap == 0 || g_n >= g_cap || !((g_mask >> (tag & 31)) & 1u)) return;
+    g_note[g_n] = ProfNote{tag, flops, bytes};
     if (hipEventRecord(g_ev[2 * g_n], s) == hipSuccess) g_open = true;
 }
 
@@ -83,12 +87,42 @@ extern "C" int rqhip_profile_enable(int max_records) {
     using namespace rqhip;
     for (int i = 0; i < 2 * g_cap; ++i) (void)hipEventDestroy(g_ev[i]);
     delete[] g_ev;
+    delete[] g_note;
     g_ev = nullptr;
+    g_note = nullptr;
     g_cap = g_n = 0;
     if (max_records <= 0) return RQHIP_OK;
     g_ev = new hipEvent_t[2 * (size_t)max_records];
+    g_note = new ProfNote[(size_t)max_records];
     for (int i = 0; i < 2 * max_records; ++i) RQ_RETURN_IF_HIP(hipEventCreate(&g_ev[i]));
     g_cap = max_records;
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_profile_select(unsigned tag_mask) {
+    rqhip::g_mask = tag_mask;
+    return RQHIP_OK;
+}
+
+extern "C" int rqhip_profile_read_tagged(rqhip_profile_record *out, int cap, int *n_out) {
+    using namespace rqhip;
+    if (!n_out || (cap > 0 && !out)) {
+        set_error("rqhip_profile_read_tagged: null output pointer");
+        return RQHIP_EARG;
+    }
+    int n = 0;
+    for (int i = 0; i < g_n && n < cap; ++i) {
+        RQ_RETURN_IF_HIP(hipEventSynchronize(g_ev[2 * i + 1]));
+        float ms = 0.f;
+        RQ_RETURN_IF_HIP(hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]));
+        out[n].tag = g_note[i].tag;
+        out[n].ms = ms;
+        out[n].flops = g_note[i].flops;
+        out[n].bytes = g_note[i].bytes;
+        ++n;
+    }
+    *n_out = n;
+    g_n = 0;
     return RQHIP_OK;
 }
 
@@ -100,6 +134,7 @@ extern "C" int rqhip_profile_read(float *ms_out, int cap, int *n_out) {
     }
     int n = 0;
     for (int i = 0; i < g_n && n < cap; ++i) {
+        if (g_note[i].tag != RQHIP_PROF_RQ_FORWARD) continue;
         RQ_RETURN_IF_HIP(hipEventSynchronize(g_ev[2 * i + 1]));
         float ms = 0.f;
         RQ_RETURN_IF_HIP(hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]));

@@ -1,26 +1,36 @@
-// gemm_split.hip -- the activation GEMMs of the encoder / decoder MLPs on the bf16 matrix cores without narrowing the
-// arithmetic (gfx950).  SURVEY.md section 8 row f2; reference modules/encoder.py:25-38 (`relu(x W^T)` forward) and its
-// autograd (`g W` data gradient).
+// gemm_split.hip -- the activation GEMMs of the encoder / decoder MLPs on the 16-bit matrix cores without narrowing the
+// arithmetic below fp32's (gfx950).  SURVEY.md section 8 row f2; reference modules/encoder.py:25-38 (`relu(x W^T)` forward) and
+// its autograd (`g W` data gradient, ReLU backward), modules/rqvae.py:146,152 + modules/loss.py:5-10 (the last decoder layer with
+// the reconstruction loss).
 //
-//   C[M, Nc] = A[M, R] . B[Nc, R]^T      A: fp32 activations (x, or the masked gradient g_pre), streamed from HBM
+//   C[M, Nc] = A[M, R] . B[Nc, R]^T      A: fp32 activations (x, or a gradient), streamed from HBM
 //                                         B: a weight matrix (W for the forward, W^T for the data gradient), small
-//   optional ReLU epilogue (the forward of every layer but the last).
+//   epilogues: store, ReLU, reconstruction loss (EPI 2), ReLU backward of the layer below (EPI 3: C = (A.B^T) where Y > 0).
 //
-// Same arithmetic as csrc/wgrad_split.hip: every fp32 value is the exact sum of three bf16 pieces h + m + l, the product
-// is formed from the six piece products that matter (dropped terms <= 2^-23 of a product, below fp32's own rounding of
-// it), each piece product is exact in fp32 and accumulates in fp32 inside v_mfma_f32_32x32x16_bf16.  The library's fp32
-// GEMMs run these tall-skinny shapes at the fp32 matrix peak (443-582 us for the 78.6 GFLOP layers); six bf16
-// instructions of 32 cycles do the work of eight fp32 instructions of 64.
+// Two arithmetics behind one kernel template (`NP` = pieces per operand):
+//   NP = 2  RQHIP_SPLIT_F16X2 (the product path, round 4): every row of A and every row of B is scaled by an EXACT power of two
+//           (2^-e, e = exponent of the row's largest |value|: the scaled row has its maximum in [1, 2)), every scaled value is
+//           split into two fp16 pieces h = RN16(v), m = RN16(v - h) (11 + 11 significant bits and a sign: v - h - m is 0 or
+//           +-2^-23 of the row maximum's binade), the product is hh + hm + mh -- three v_mfma_f32_32x32x16_f16 (products of two
+//           fp16 values are exact in fp32, accumulation in fp32; dropped: mm <= 2^-22 of a product) -- and the epilogue
+//           multiplies back by 2^(e_row + e_column), also exact.  The row maxima of A come from the kernel that wrote A
+//           (every epilogue here can emit the row and column maxima of what it stores) or from rqhip_maxima.
+//   NP = 3  RQHIP_SPLIT_BF16X3 (round 3; kept for A/B): three exact bf16 pieces h + m + l, six products, no scaling.
+// Both are held to the same gate (tests/test_gpu_gemm_split.py): max error against fp64 <= the library fp32 GEMM's on the same
+// inputs, on every operand family including the worst-case mantissas of the 11-bit split and cancellation-heavy rows.
 //
 // Mapping
 //   * both operands are consumed along the reduction index as they lie in memory (a lane's operand = 8 consecutive r of
-//     one row of A / one row of B): no transposition.  The weight is split ONCE per step by `weight_planes_kernel` into
-//     the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage is three contiguous 4 KB runs.
+//     one row of A / one row of B): no transposition.  The weight is split once per forward by `weight_images_kernel` (all
+//     layers of an MLP in ONE launch) into the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage
+//     is NP contiguous runs.
 //   * tile = 256 rows x 256 columns (8 waves of 128 x 64) for whole rounds of the chip, 64 x 256 (8 waves of 32 x 64) for
 //     what is left over; layers with 128 (mod 256) output columns take 256 x 128 tiles (8 waves of 64 x 64) and 128 x 128
-//     for the leftover; 16-deep stages through a double-buffered LDS image, loads two stages ahead.  Row tiles are handed out by an atomic counter (persistent workgroups: 100 000 rows are 782 x Nc/256
-//     tiles on 512 slots; a static round-robin would leave the last round a tenth full).
+//     for the leftover; 16-deep stages through a double-buffered LDS image, A rows requested two stages ahead.  Tiles are
+//     handed out by an atomic counter (persistent workgroups, one per CU).
 //   * results do not depend on which workgroup computes a tile: bit-reproducible run to run.
+// The round-3 schedule experiments (wave specialisation, 128 x 128 wave tiles, weight image from L2, phase-skipping probes,
+// s_memtime stamps) live in tools/experiments/gemm_split_r03_variants.hip; what they measured is in DESIGN.md section 4.3d.
 #include "rqhip_common.h"
 
 namespace rqhip {
@@ -30,51 +40,18 @@ typedef float gs_f32x4 __attribute__((ext_vector_type(4)));
 typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 gs_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gs_f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
+typedef int gs_i32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef GS_WAVES   // 4 (developer A/B builds): one wave per SIMD with 128-column wave tiles and a 512-register budget
-#define GS_WAVES 8
-#endif
-#ifndef GS_PC      // 1 (developer A/B builds): four more waves (one per SIMD) do ALL the staging -- global requests, the split, the
-#define GS_PC 0    // LDS writes -- and the eight tile waves only read the LDS and multiply (12 waves: 170 registers each)
-#endif
-#ifndef GS_F16     // 1 (developer A/B builds, TIMING ONLY: no row scaling yet): two fp16 pieces per operand and the three products
-#define GS_F16 0   // hh + hm + mh instead of three bf16 pieces and six products (tools/fp16_split_study.py)
-#endif
-#ifndef GS_BL2     // 1 (with GS_PC): the tile waves take their weight-image operands straight from L2 into registers (refilled for
-#define GS_BL2 0   // the next stage right after their last use); the image never passes through the LDS or the staging waves
-#endif
-constexpr int kGsWaves = GS_WAVES, kGsUB = 16 / GS_WAVES;   // a wave's tile is (32 TA) x (32 UB): UB = 2 (8 waves) or 4 (4 waves)
-constexpr int kGsStageWaves = GS_PC ? 4 : kGsWaves;         // waves that stage (GS_PC: waves kGsWaves .. kGsWaves + 3)
-constexpr int kGsThreads = 64 * (kGsWaves + (GS_PC ? kGsStageWaves : 0)), kGsStageThreads = 64 * kGsStageWaves;
-constexpr int kGsNP = GS_F16 ? 2 : 3;   // pieces per operand
-constexpr int kGsK = 16;   // tile: COLS = 256 or 128 columns, (waves / (COLS / (32 UB))) * 32 * TA rows
-#ifndef GS_XCD_GROUP
-#define GS_XCD_GROUP 0
-#endif
-#ifndef GS_PHASE   // 1 (developer A/B builds): the two waves of a SIMD out of phase -- measured 5-7 % SLOWER
-#define GS_PHASE 0
-#endif
-#ifndef GS_PROBE   // developer builds (tools/ab_build.sh): phase-skipping bit mask, results are WRONG with any bit set --
-#define GS_PROBE 0 // 1: no split arithmetic, 2: no LDS writes at all, 4: operand reads once per tile, 16: no global loads (32: none of A, 64: none of the weight image, 128: A always from the first two stages = cache hits,
-                   // 256: a tile's A stage is one contiguous 16 KB block (wrong data, same bytes), 512: no result stores)
-#endif
+constexpr int kGsWaves = 8, kGsUB = 2;     // a wave's tile is (32 TA) x (32 UB)
+constexpr int kGsThreads = 64 * kGsWaves;
+constexpr int kGsK = 16;                    // reduction depth of a stage = one K step of the matrix instruction
+constexpr int kGsColmaxLds = 1024;          // column maxima are pre-reduced in LDS for Nc up to this (else straight to memory)
 
-#ifdef GS_TIMING
-// developer-only s_memtime stamps of every wave of workgroup 0 during its FIRST tile (tools/gemm_timing.py --build):
-// slot 0 tile start, 1 prologue barrier passed, then per half-iteration i (stage i multiplied): 2 + 4 i staged,
-// 3 + 4 i requests issued, 4 + 4 i multiplied, 5 + 4 i barrier passed
-__device__ unsigned long long gs_dbg[8 * 64];
-__device__ unsigned gs_dbg_armed = 1;
-#define GS_STAMP(i)                                                                                                   \
-    do {                                                                                                              \
-        if (gs_timed && (threadIdx.x & 63) == 0 && threadIdx.x < 512 && (i) < 64) gs_dbg[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define GS_STAMP(i) do { } while (0)
-#endif
-
+// (a, b) -> packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
     const gs_bf16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_bf16x2);
     h = __builtin_bit_cast(unsigned, hh);
@@ -85,10 +62,7 @@ __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigne
     const gs_bf16x2 ll = __builtin_convertvector(gs_f32x2{sa, sb}, gs_bf16x2);
     l = __builtin_bit_cast(unsigned, ll);
 }
-
-#if GS_F16
-typedef _Float16 gs_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 gs_f16x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> packed fp16 pieces: h = RN16(v), m = RN16(v - h)
 __device__ __forceinline__ void gs_split2_f16(float a, float b, unsigned &h, unsigned &m) {
     const gs_f16x2 hh = __builtin_convertvector(gs_f32x2{a, b}, gs_f16x2);
     h = __builtin_bit_cast(unsigned, hh);
@@ -96,73 +70,180 @@ __device__ __forceinline__ void gs_split2_f16(float a, float b, unsigned &h, uns
     const gs_f16x2 mm = __builtin_convertvector(gs_f32x2{a - hf.x, b - hf.y}, gs_f16x2);
     m = __builtin_bit_cast(unsigned, mm);
 }
-#endif
-
-#if GS_F16
-// Exact power-of-two scaling (PROTOTYPE, not validated on the GPU yet): fp16 pieces only carry 11 + 11 bits between 6.1e-5 and
-// 65 504, so every row of A and every weight row is multiplied by 2^-e, e = exponent of its largest |value| (the scaled row then
-// has its maximum in [1, 2)), and the result is multiplied back by 2^(e_row + e_column) in the epilogue -- all three exact.
-__device__ __forceinline__ int gs_exp_of(float m) {   // floor(log2 m) of a positive finite float; 0 for 0 / inf / nan
-    const unsigned b = __builtin_bit_cast(unsigned, m) & 0x7fffffffu;
+// floor(log2) of the positive float with these bits; 0 for 0 / inf / nan (such rows are not scaled)
+__device__ __forceinline__ int gs_exp_of_bits(unsigned b) {
+    b &= 0x7fffffffu;
     const int e = (int)(b >> 23);
     return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127);
 }
-// exps[m] for the rows of A [M, R] (16-byte aligned rows): four rows per 256-thread block, one wave per row
-__global__ __launch_bounds__(256) void row_exps_kernel(const float *__restrict__ A, long long M, int R, int *__restrict__ exps) {
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int lane = threadIdx.x & 63;
-    float m = 0.0f;
-    const gs_f32x4 *src = reinterpret_cast<const gs_f32x4 *>(A + (size_t)row * R);
-    for (int i = lane; i < R / 4; i += 64) {
-        const gs_f32x4 v = src[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));   // (fmaxf drops NaNs: they stay NaN in the product)
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) exps[row] = gs_exp_of(m);
+__device__ __forceinline__ unsigned gs_abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
+// max of the bit patterns of |values| == bit pattern of the largest |value| for everything that is not a NaN; a NaN wins
+// (its pattern is above +inf's), which marks the row / column "do not scale" exactly as an infinity does
+__device__ __forceinline__ unsigned gs_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+// maximum over lanes 0 .. 31 (result in lane 31) and over lanes 32 .. 63 (result in lane 63): four row_shr steps inside the
+// 16-lane DPP rows (zeros shifted in: the identity of an unsigned maximum), then lane 15 of rows 0 / 2 broadcast into rows 1 / 3
+__device__ __forceinline__ unsigned gs_half_wave_umax(unsigned v) {
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));   // row_bcast:15 into rows 1 and 3
+    return v;
 }
-// exps[n] for the rows of B: src[n][r] (transpose == 0) or src[r][n] (transpose == 1); one wave per n
-__global__ __launch_bounds__(64) void weight_exps_kernel(const float *__restrict__ src, int Nc, int R, int transpose, int *__restrict__ exps) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    float m = 0.0f;
-    for (int r = lane; r < R; r += 64) m = fmaxf(m, fabsf(transpose ? src[(size_t)r * Nc + n] : src[(size_t)n * R + r]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (lane == 0) exps[n] = gs_exp_of(m);
-}
-#endif
 
-// planes[s][piece][half][n] (16 bytes: r = 16 s + 8 half + j, j < 8) of src[n][r] (transpose == 0, src is [Nc, R]) or of
-// src[r][n] (transpose == 1, src is [R, Nc]: the data gradient multiplies by W, i.e. B = W^T).  One thread per element.
-__global__ __launch_bounds__(256) void weight_planes_kernel(const float *__restrict__ src, int Nc, int R, int transpose,
-                                                            unsigned *__restrict__ planes) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;     // (n, r pair): r = 2 rp, 2 rp + 1
-    const long long total = (long long)Nc * (R / 2);
-    if (e < 4) planes[(size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + e] = 0u;        // the tile dispenser behind the image
-    if (e >= total) return;
-    const int n = (int)(e % Nc), rp = (int)(e / Nc), r = 2 * rp;
-    const float a = transpose ? src[(size_t)r * Nc + n] : src[(size_t)n * R + r];
-    const float b = transpose ? src[(size_t)(r + 1) * Nc + n] : src[(size_t)n * R + r + 1];
-    unsigned h, m, l = 0u;
-#if GS_F16
-    {   // the exponents lie behind the tile dispenser (16 words): see rqhip_weight_planes
-        const int e_n = reinterpret_cast<const int *>(planes + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16)[n];
-        gs_split2_f16(ldexpf(a, -e_n), ldexpf(b, -e_n), h, m);
+// ---- weight images: every layer of an MLP in one launch -----------------------------------------------------------------------
+// image[s][piece][half][n] (16 bytes: r = 16 s + 8 half + j, j < 8) of src[n][r] (transpose == 0, src is [Nc, R]) or of
+// src[r][n] (transpose == 1, src is [R, Nc]: the data gradient multiplies by W, i.e. B = W^T).  Behind the image: the tile
+// dispenser (16 words), and for NP = 2 the exponents of the Nc rows of B.
+constexpr int kImgCols = 4;         // rows of B per block (one per wave)
+constexpr int kImgMaxJobs = 16;
+struct ImageJob {
+    const float *src;
+    unsigned *image;
+    int Nc, R, transpose, np;
+    int block0;                     // first block of this job in the launch
+};
+struct ImageJobs {
+    ImageJob j[kImgMaxJobs];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void weight_images_kernel(const ImageJobs jobs) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < jobs.n; ++i)
+        if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
+    const ImageJob job = jobs.j[ji];
+    const int blk = (int)blockIdx.x - job.block0;
+    const int Nc = job.Nc, R = job.R, np = job.np, n0 = blk * kImgCols;
+    unsigned *tail = job.image + (size_t)(R / kGsK) * 2 * np * Nc * 4;
+    if (blk == 0 && threadIdx.x < 16) tail[threadIdx.x] = 0u;        // the tile dispenser
+    __shared__ unsigned s_max[kImgCols];
+    if (threadIdx.x < kImgCols) s_max[threadIdx.x] = 0u;
+    __syncthreads();
+    const int pairs = R / 2, total = kImgCols * pairs;
+    // thread -> (row of B, r pair): the pair index runs fastest along the contiguous direction of src
+    auto locate = [&](int idx, int &nl, int &rp) {
+        if (job.transpose) { nl = idx % kImgCols; rp = idx / kImgCols; }
+        else { rp = idx % pairs; nl = idx / pairs; }
+    };
+    auto fetch = [&](int nl, int rp, float &a, float &b) {
+        const int n = n0 + nl, r = 2 * rp;
+        a = job.transpose ? job.src[(size_t)r * Nc + n] : job.src[(size_t)n * R + r];
+        b = job.transpose ? job.src[(size_t)(r + 1) * Nc + n] : job.src[(size_t)n * R + r + 1];
+    };
+    if (np == 2) {   // the exponent of every row of B first
+        if (job.transpose) {   // src[r][n]: thread = (row of B, 1 of 64 r phases), partial maxima met in LDS
+            __shared__ unsigned s_part[256];
+            const int nl = threadIdx.x % kImgCols;
+            unsigned m = 0u;
+            for (int r = threadIdx.x / kImgCols; r < R; r += 256 / kImgCols) m = gs_umax(m, gs_abs_bits(job.src[(size_t)r * Nc + n0 + nl]));
+            s_part[threadIdx.x] = m;
+            __syncthreads();
+            if (threadIdx.x < kImgCols) {
+                for (int i = threadIdx.x + kImgCols; i < 256; i += kImgCols) m = gs_umax(m, s_part[i]);
+                s_max[threadIdx.x] = m;
+            }
+        } else {               // src[n][r]: a wave per row of B
+            const int lane = threadIdx.x & 63, nl = threadIdx.x >> 6;
+            unsigned m = 0u;
+            for (int rp = lane; rp < pairs; rp += 64) {
+                const gs_f32x2 v = *reinterpret_cast<const gs_f32x2 *>(job.src + (size_t)(n0 + nl) * R + 2 * rp);
+                m = gs_umax(m, gs_umax(gs_abs_bits(v.x), gs_abs_bits(v.y)));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = gs_umax(m, (unsigned)__shfl_xor((int)m, o, 64));
+            if (lane == 0) s_max[nl] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < kImgCols) reinterpret_cast<int *>(tail + 16)[n0 + threadIdx.x] = gs_exp_of_bits(s_max[threadIdx.x]);
     }
-#else
-    gs_split2(a, b, h, m, l);
-#endif
-    const int s = r >> 4, half = (r >> 3) & 1, j2 = (r & 7) >> 1;      // dword j2 of the 16-byte element
-    const size_t base = ((size_t)(s * kGsNP) * 2 + half) * Nc + n;
-    planes[(base + 0 * 2 * (size_t)Nc) * 4 + j2] = h;
-    planes[(base + 1 * 2 * (size_t)Nc) * 4 + j2] = m;
-    if (kGsNP == 3) planes[(base + 2 * 2 * (size_t)Nc) * 4 + j2] = l;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        int nl, rp;
+        float a, b;
+        locate(idx, nl, rp);
+        fetch(nl, rp, a, b);
+        const int n = n0 + nl, r = 2 * rp;
+        unsigned h, m, l = 0u;
+        if (np == 2) {
+            const int e = gs_exp_of_bits(s_max[nl]);
+            gs_split2_f16(ldexpf(a, -e), ldexpf(b, -e), h, m);
+        } else {
+            gs_split2(a, b, h, m, l);
+        }
+        const int s = r >> 4, half = (r >> 3) & 1, j2 = (r & 7) >> 1;      // dword j2 of the 16-byte element
+        const size_t base = ((size_t)(s * np) * 2 + half) * Nc + n;
+        job.image[(base + 0 * 2 * (size_t)Nc) * 4 + j2] = h;
+        job.image[(base + 1 * 2 * (size_t)Nc) * 4 + j2] = m;
+        if (np == 3) job.image[(base + 2 * 2 * (size_t)Nc) * 4 + j2] = l;
+    }
+}
+
+// ---- maxima of a matrix in one pass ---------------------------------------------------------------------------------------------
+// row_max[m] / col_max[c]: bit patterns of the largest |value| of row m / column c of A [M, R] (optionally of A masked by Y > 0,
+// which is then also written to `out`: the ReLU backward as its own pass, for callers that do not get it from an epilogue).
+// 256 threads = 4 waves, a wave takes rows; col_max is maxed into atomically (zeroed by the caller).
+__global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ A, const float *__restrict__ Y, float *__restrict__ out,
+                                                     long long M, int R, unsigned *__restrict__ row_max, unsigned *__restrict__ col_max) {
+    extern __shared__ unsigned mx_smem[];            // [R] column maxima of this block (when col_max)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (col_max) {
+        for (int c = threadIdx.x; c < R; c += 256) mx_smem[c] = 0u;
+        __syncthreads();
+    }
+    const int R4 = R / 4;
+    constexpr int kQ = 4;                             // float4s per lane held for the column maxima (R <= 1024)
+    unsigned cm[kQ][4];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cm[q][j] = 0u;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < M; row += (long long)gridDim.x * 4) {
+        const gs_f32x4 *src = reinterpret_cast<const gs_f32x4 *>(A + (size_t)row * R);
+        const gs_f32x4 *ys = Y ? reinterpret_cast<const gs_f32x4 *>(Y + (size_t)row * R) : nullptr;
+        gs_f32x4 *dst = out ? reinterpret_cast<gs_f32x4 *>(out + (size_t)row * R) : nullptr;
+        unsigned rm = 0u;
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const int i = lane + 64 * q;
+            if (i >= R4) break;
+            gs_f32x4 v = src[i];
+            if (ys) {   // threshold_backward(g, y, 0): 0 where y <= 0
+                const gs_f32x4 y4 = ys[i];
+                v.x = y4.x <= 0.0f ? 0.0f : v.x; v.y = y4.y <= 0.0f ? 0.0f : v.y;
+                v.z = y4.z <= 0.0f ? 0.0f : v.z; v.w = y4.w <= 0.0f ? 0.0f : v.w;
+                if (dst) dst[i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned b = gs_abs_bits(v[j]);
+                rm = gs_umax(rm, b);
+                cm[q][j] = gs_umax(cm[q][j], b);
+            }
+        }
+        if (row_max) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rm = gs_umax(rm, (unsigned)__shfl_xor((int)rm, o, 64));
+            if (lane == 0) row_max[row] = rm;
+        }
+    }
+    if (col_max) {
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const int i = lane + 64 * q;
+            if (i >= R4) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicMax(&mx_smem[4 * i + j], cm[q][j]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < R; c += 256)
+            if (mx_smem[c]) atomicMax(col_max + c, mx_smem[c]);
+    }
 }
 
 struct GemmSplitParams {
     const float *A;          // [M, R]
-    const unsigned *planes;  // weight image, see weight_planes_kernel
+    const unsigned *planes;  // weight image, see weight_images_kernel
     float *C;                // [M, Nc]
     long long M;
     int R, Nc;
@@ -172,69 +253,70 @@ struct GemmSplitParams {
     int rt_big;
     unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
     // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
-    // rowsum[ct][m] the squared error of row m over column tile ct
+    // rowsum[ct][m] the squared error of row m over column tile ct.  EPI == 3: X is Y, the activation whose ReLU is undone
     const float *X;
     float *rowsum;
     float row_scale;
-#if GS_F16
-    const int *a_exp;        // [M] exponents of the rows of A (row_exps_kernel), or nullptr: A is used as it is
-    const int *b_exp;        // [Nc] exponents of the weight rows (inside the image, written by rqhip_weight_planes)
-    int a_is_max;            // a_exp holds the bit patterns of the rows' largest |value| (another GEMM's rowmax_out) instead
-    unsigned *rowmax_out;    // [M] or nullptr: unsigned max of the bit patterns of |C[row, :]| (zeroed by the caller; the maximum
-                             // does not depend on the order of the atomics) -- the row exponents of the GEMM that reads C next
-#endif
+    // NP == 2: a_max [a_parts][M] bit patterns whose maximum over the parts is row m's largest |value| (an epilogue's c_rowmax, or
+    // rqhip_maxima's row_max with one part); b_exp [Nc] lives behind the image
+    const unsigned *a_max;
+    int a_parts;
+    const int *b_exp;
+    // optional outputs of every epilogue: c_rowmax [column tiles][M] (part = column tile; plain stores), c_colmax [Nc]
+    // (atomic maxima: zeroed by the caller) -- the scales of the kernels that read C next
+    unsigned *c_rowmax, *c_colmax;
 };
 
 // one output tile of ROWS x COLS: 8 waves of (32 TA) x 64, WN = COLS / 64 of them side by side
-// EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss (see GemmSplitParams)
-template <int EPI, int TA, int COLS>
-__device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, long long m0, int n0) {
-    constexpr int kGsCols = COLS, UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
-    constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsStageThreads - 1) / kGsStageThreads;   // float4s of A per staging thread and stage
-    constexpr int PA = kGsNP * 2 * ROWS * 4, PB = GS_BL2 ? 0 : kGsNP * 2 * kGsCols * 4;    // dwords per stage image
-    constexpr int BQ = (2 * kGsNP * kGsCols + kGsStageThreads - 1) / kGsStageThreads;      // 16-byte elements of B per staging thread and stage
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // GS_PC: waves 0 .. 7 multiply (`tiler`), waves 8 .. 11 stage (`stager`); otherwise every wave does both
-    const bool stager = GS_PC ? __builtin_amdgcn_readfirstlane(wave) >= kGsWaves : true;
-    const bool tiler = GS_PC ? !stager : true;
-    const int tid = GS_PC ? (int)threadIdx.x - 64 * kGsWaves : (int)threadIdx.x;   // staging thread number (negative: a tile wave)
+// EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss, 3 = masked by Y > 0 (see GemmSplitParams)
+template <int EPI, int TA, int COLS, int NP>
+__device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, int *s_aexp, unsigned *s_colmax, long long m0, int n0) {
+    constexpr int UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
+    constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
+    constexpr int PA = NP * 2 * ROWS * 4, PB = NP * 2 * COLS * 4;                       // dwords per stage image
+    constexpr int BQ = (2 * NP * COLS + kGsThreads - 1) / kGsThreads;                   // 16-byte elements of B per thread and stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-#ifdef GS_TIMING
-    const bool gs_timed = blockIdx.x == 0 && TA >= 3 && m0 < 256 * (long long)gridDim.x && gs_dbg_armed;   // the workgroup's first big tile
-#endif
     const int n_stage = p.R / kGsK;
-    constexpr int APASS = kGsStageThreads / 4;             // rows one staging pass of the workgroup covers
-    // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- three
+    constexpr int APASS = kGsThreads / 4;                  // rows one staging pass of the workgroup covers
+    // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- BQ
     // 16-byte elements of the stage's weight image per thread
-    const int arow = (tid < 0 ? 0 : tid) >> 2, akq = tid & 3;
+    const int arow = tid >> 2, akq = tid & 3;
     bool a_live[AQ], arow_ok[AQ];
     const float *asrc[AQ];
+    int a_e[AQ];                                           // NP == 2: exponents of this thread's rows of A
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
         a_live[q] = arow + APASS * q < ROWS;
         const long long arow_g = m0 + arow + APASS * q;
         arow_ok[q] = a_live[q] && arow_g < p.M;
-        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * ((GS_PROBE & 256) ? 16 : p.R) + 4 * akq;
-    }
-#if GS_F16
-    int a_e[AQ];             // exponents of this thread's rows of A
+        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
+        a_e[q] = 0;
+        if (NP == 2) {
+            // (four parts per round, their loads independent of one another: a dependent load per part put a_parts memory
+            // latencies in front of every tile -- 12 parts x 2 rows x ~0.7 us on a 768-column producer)
+            unsigned mx = 0u;
+            const unsigned *am = p.a_max + (arow_ok[q] ? arow_g : 0);
+            for (int part = 0; part < p.a_parts; part += 4) {
+                unsigned v[4];
 #pragma unroll
-    for (int q = 0; q < AQ; ++q) {
-        a_e[q] = (p.a_exp && arow_ok[q]) ? p.a_exp[m0 + arow + APASS * q] : 0;
-        if (p.a_is_max) a_e[q] = gs_exp_of(__builtin_bit_cast(float, a_e[q]));
+                for (int j = 0; j < 4; ++j) v[j] = am[(size_t)(part + j < p.a_parts ? part + j : part) * p.M];
+                mx = gs_umax(gs_umax(mx, gs_umax(v[0], v[1])), gs_umax(v[2], v[3]));
+            }
+            if (!arow_ok[q]) mx = 0u;
+            a_e[q] = gs_exp_of_bits(mx);
+            if (a_live[q] && akq == 0) s_aexp[arow + APASS * q] = a_e[q];   // (read by the epilogue, many barriers later)
+        }
     }
-#endif
 
     gs_f32x16 acc[TA][UB];
-#if !GS_PC   // (GS_PC zeroes them in the tile waves' own branch, so that the accumulators are not live beside the staging registers)
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
-#endif
 
     gs_f32x4 ra0[AQ], ra1[AQ];   // rows of A: two stages in flight (requested two iterations before they are split)
     gs_u32x4 rb[BQ];
@@ -242,316 +324,240 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // compiler's s_waitcnt insertion assume it may not have been issued, and the wait for the weight image then drains it)
     auto fetchA = [&](int stage, gs_f32x4 *dst) {
         stage = stage < n_stage ? stage : n_stage - 1;
-        if ((GS_PROBE & 16) && stage > 1) return;
 #pragma unroll
         for (int q = 0; q < AQ; ++q)
-            if (!((GS_PROBE & 32) && stage > 1))
-                dst[q] = !arow_ok[q] ? gs_f32x4{0.f, 0.f, 0.f, 0.f}   // (non-temporal loads of A: +3 ... +4 %)
-                         : *reinterpret_cast<const gs_f32x4 *>(asrc[q] + ((GS_PROBE & 128) ? (stage & 1) : stage) * ((GS_PROBE & 256) ? 256 * 1024 : kGsK));
+            dst[q] = !arow_ok[q] ? gs_f32x4{0.f, 0.f, 0.f, 0.f}   // (non-temporal loads of A: +3 ... +4 %)
+                                 : *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK);
     };
     auto fetchB = [&](int stage) {
-        if (GS_BL2) return;
         stage = stage < n_stage ? stage : n_stage - 1;
-        if ((GS_PROBE & 16) && stage > 1) return;
-        // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + 255 of each of the six
-        // (piece, half) rows: element e = tid + 512 q  ->  (ph = e / COLS, col = e % COLS)
-        const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 2 * kGsNP * p.Nc + n0;
+        // stage image: [piece][half][Nc] 16-byte elements; this tile's part is columns n0 .. n0 + COLS - 1 of each of the
+        // 2 NP (piece, half) rows: element e = tid + 512 q  ->  (ph = e / COLS, col = e % COLS)
+        const gs_u32x4 *img = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)stage * 2 * NP * p.Nc + n0;
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
-            const int e = tid + kGsStageThreads * q;
-            if ((2 * kGsNP * kGsCols) % kGsStageThreads != 0 && e >= 2 * kGsNP * kGsCols) continue;
-            if (!((GS_PROBE & 64) && stage > 1)) rb[q] = img[(size_t)(e / kGsCols) * p.Nc + (e % kGsCols)];
+            const int e = tid + kGsThreads * q;
+            if ((2 * NP * COLS) % kGsThreads != 0 && e >= 2 * NP * COLS) continue;
+            rb[q] = img[(size_t)(e / COLS) * p.Nc + (e % COLS)];
         }
     };
     auto stash = [&](int buf, const gs_f32x4 *ra) {
-        if ((GS_PROBE & 2) && buf) return;
         unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
             if (!a_live[q]) continue;
-            unsigned h01, m01, l01, h23, m23, l23;
-            if (GS_PROBE & 1) {
-                h01 = __builtin_bit_cast(unsigned, ra[q].x); m01 = __builtin_bit_cast(unsigned, ra[q].y); l01 = h01 ^ m01;
-                h23 = __builtin_bit_cast(unsigned, ra[q].z); m23 = __builtin_bit_cast(unsigned, ra[q].w); l23 = h23 ^ m23;
+            unsigned h01, m01, l01 = 0u, h23, m23, l23 = 0u;
+            if (NP == 2) {
+                gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
+                gs_split2_f16(ldexpf(ra[q].z, -a_e[q]), ldexpf(ra[q].w, -a_e[q]), h23, m23);
             } else {
-#if GS_F16
-            gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
-            gs_split2_f16(ldexpf(ra[q].z, -a_e[q]), ldexpf(ra[q].w, -a_e[q]), h23, m23);
-            l01 = l23 = 0u;
-#else
-            gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
-            gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
-#endif
+                gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
+                gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
             }
             // element [piece][half = akq >> 1][row] is 16 bytes = r 8 half .. 8 half + 7; this thread fills its half (akq & 1)
             unsigned *d = dA + (((akq >> 1) * ROWS) + arow + APASS * q) * 4 + 2 * (akq & 1);
             *reinterpret_cast<gs_u32x2 *>(d + 0 * 2 * ROWS * 4) = gs_u32x2{h01, h23};
             *reinterpret_cast<gs_u32x2 *>(d + 1 * 2 * ROWS * 4) = gs_u32x2{m01, m23};
-            if (kGsNP == 3) *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
+            if (NP == 3) *reinterpret_cast<gs_u32x2 *>(d + 2 * 2 * ROWS * 4) = gs_u32x2{l01, l23};
         }
 #pragma unroll
         for (int q = 0; q < BQ; ++q) {
-            const int e = tid + kGsStageThreads * q;
-            if (GS_BL2 || ((2 * kGsNP * kGsCols) % kGsStageThreads != 0 && e >= 2 * kGsNP * kGsCols)) continue;
+            const int e = tid + kGsThreads * q;
+            if ((2 * NP * COLS) % kGsThreads != 0 && e >= 2 * NP * COLS) continue;
             *reinterpret_cast<gs_u32x4 *>(dB + (size_t)e * 4) = rb[q];   // [ph][col] order == the image's
         }
     };
-#if GS_BL2
-    // this lane's image operands of the current stage, [column half][piece]; element (piece, half h, column) of stage s is
-    // planes[((s 6 + piece 2 + h) Nc + column) x 16 bytes]
-    gs_bf16x8 breg[UB][kGsNP];
-    auto load_b = [&](int stage, int u) {
-        stage = stage < n_stage ? stage : n_stage - 1;
-        const gs_bf16x8 *img = reinterpret_cast<const gs_bf16x8 *>(p.planes) + ((size_t)stage * 2 * kGsNP + h) * p.Nc + n0 + wn * 32 * UB + 32 * u + il;
-#pragma unroll
-        for (int pc = 0; pc < kGsNP; ++pc) breg[u][pc] = img[(size_t)pc * 2 * p.Nc];
-    };
-    auto multiply = [&](int buf, int next_stage) {
-#else
     auto multiply = [&](int buf) {
-#endif
         const gs_bf16x8 *aA = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB));
         const gs_bf16x8 *bB = reinterpret_cast<const gs_bf16x8 *>(sbuf + buf * (PA + PB) + PA);
-        // column half outer, row block inner: 12 + 12 operand registers live (the row blocks are read once per column half:
-        // 30 instead of 18 LDS reads per stage, which the LDS has room for -- tools/gemm_probe.py, GS_PROBE 4)
+        // the weight columns take the instruction's ROW role: the accumulator is the tile transposed, a lane holds four
+        // consecutive columns of one output row per register quad -> 16-byte result stores
+        if constexpr (NP == 2) {
+            // both column halves' operands first (16 registers), then every row block once: 2 TA + 4 LDS reads per 6 TA matrix
+            // instructions.  (With three matrix instructions per block the u-outer order of the bf16 path -- 2 (2 + 2 TA) reads
+            // -- puts the LDS read time of eight waves next to the matrix time of a stage.)
+            gs_f16x8 fb[UB][2];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            gs_bf16x8 b[kGsNP];
+            for (int u = 0; u < UB; ++u)
 #pragma unroll
-            for (int pc = 0; pc < kGsNP; ++pc)
-#if GS_BL2
-                b[pc] = breg[u][pc];
-#else
-                b[pc] = bB[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * kGsCols + wn * 32 * UB + ((GS_PROBE & 4) ? 0 : 32 * u) + il];
-#endif
+                for (int pc = 0; pc < 2; ++pc)
+                    fb[u][pc] = __builtin_bit_cast(gs_f16x8, bB[(pc * 2 + h) * COLS + wn * 32 * UB + 32 * u + il]);
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
-                gs_bf16x8 a[kGsNP];
+                gs_f16x8 fa[2];
 #pragma unroll
-                for (int pc = 0; pc < kGsNP; ++pc)
-                    a[pc] = aA[(((GS_PROBE & 4) ? 0 : pc) * 2 + h) * ROWS + wm * 32 * TA + ((GS_PROBE & 4) ? 0 : 32 * t) + il];
-                gs_f32x16 c16 = acc[t][u];
-                // the weight columns take the instruction's ROW role: the accumulator is the tile transposed, a lane holds
-                // four consecutive columns of one output row per register quad -> 16-byte result stores
-#if GS_F16
-                {
-                    gs_f16x8 fa[2], fb[2];
+                for (int pc = 0; pc < 2; ++pc)
+                    fa[pc] = __builtin_bit_cast(gs_f16x8, aA[(pc * 2 + h) * ROWS + wm * 32 * TA + 32 * t + il]);
 #pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) { fa[pc] = __builtin_bit_cast(gs_f16x8, a[pc]); fb[pc] = __builtin_bit_cast(gs_f16x8, b[pc]); }
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0], fa[1], c16, 0, 0, 0);   // m h (smallest first)
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[1], fa[0], c16, 0, 0, 0);   // h m
-                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[0], fa[0], c16, 0, 0, 0);   // h h
+                for (int u = 0; u < UB; ++u) {
+                    gs_f32x16 c16 = acc[t][u];
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[u][0], fa[1], c16, 0, 0, 0);   // m h (smallest first)
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[u][1], fa[0], c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[u][0], fa[0], c16, 0, 0, 0);   // h h
+                    acc[t][u] = c16;
                 }
-#else
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[1], c16, 0, 0, 0);   // m m (smallest first)
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[2], c16, 0, 0, 0);   // l h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], a[0], c16, 0, 0, 0);   // h l
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], c16, 0, 0, 0);   // m h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], c16, 0, 0, 0);   // h m
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], c16, 0, 0, 0);   // h h
-#endif
-                acc[t][u] = c16;
-                // GS_PC, 128 accumulators: 170 registers hold them and ONE block's operands; keep the scheduler from hoisting
-                // the next block's LDS reads above this block's matrix instructions (it spills the accumulators otherwise)
-                if (GS_PC && TA * UB * 16 > 96) __builtin_amdgcn_sched_barrier(0);
             }
-            // GS_PC, 96 accumulators: one column half's operands (12 + 36 registers) at a time
-            if (GS_PC && TA * UB * 16 <= 96) __builtin_amdgcn_sched_barrier(0);
-#if GS_BL2
-            load_b(next_stage, u);                 // this column half's operands of the next stage, into the registers just used
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+        } else {
+            // column half outer, row block inner: 12 + 12 operand registers live (the row blocks are read once per column half:
+            // 30 instead of 18 LDS reads per stage, which the LDS has room for at six matrix instructions per block)
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                gs_bf16x8 b[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b[pc] = bB[(pc * 2 + h) * COLS + wn * 32 * UB + 32 * u + il];
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    gs_bf16x8 a[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) a[pc] = aA[(pc * 2 + h) * ROWS + wm * 32 * TA + 32 * t + il];
+                    gs_f32x16 c16 = acc[t][u];
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[1], c16, 0, 0, 0);   // m m (smallest first)
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[2], c16, 0, 0, 0);   // l h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2], a[0], c16, 0, 0, 0);   // h l
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], c16, 0, 0, 0);   // m h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], c16, 0, 0, 0);   // h h
+                    acc[t][u] = c16;
+                }
+            }
         }
     };
 
     // Order of the requests inside an iteration: the weight image FIRST, then the A rows.  Loads complete in order
     // (vmcnt): the next iteration waits for the image it stages, and with the A rows requested before it that wait also
-    // drained the A rows of the stage after -- their latency had ONE iteration to hide in, not two (phase-skipping probes:
-    // the kernel ran 86 us faster without its global loads although every one of them is issued 1-2 iterations early).
-    // (A third register set and LDS buffer -- A rows three iterations ahead -- do not fit: 8 more registers spill inside
-    // the stage loop, 535 vs 476 us.)
+    // drained the A rows of the stage after -- their latency had ONE iteration to hide in, not two.
     // A rows are requested TWO iterations before they are split (scattered 64-byte pieces of 256 rows: their latency is
-    // longer than one iteration's matrix work -- tools/gemm_probe.py: the kernel ran 17 % faster without them, 10 % with
-    // cache hits), the weight image (L2-resident) one iteration before.
-    GS_STAMP(0);
-    if (stager) {
-        fetchA(0, ra0);
-        fetchB(0);
-        fetchA(1, ra1);
-        stash(0, ra0);
-        fetchB(1);
-        fetchA(2, ra0);
-    }
-#if GS_BL2
-    if (tiler) {
-#pragma unroll
-        for (int u = 0; u < UB; ++u) load_b(0, u);
-    }
-#endif
+    // longer than one iteration's matrix work), the weight image (L2-resident) one iteration before.
+    fetchA(0, ra0);
+    fetchB(0);
+    fetchA(1, ra1);
+    stash(0, ra0);
+    fetchB(1);
+    fetchA(2, ra0);
     __syncthreads();
-    GS_STAMP(1);
-#if GS_PC
-#if GS_BL2
-#define GS_MUL(buf, next) multiply(buf, next)
-#else
-#define GS_MUL(buf, next) multiply(buf)
-#endif
-    // each role runs its own loop (registers of the two roles are then never live together); both pass the same barriers
-    if (stager) {
-        for (int c = 0; c < (n_stage & ~1); c += 2) {
-            stash(1, ra1);                             // stage c + 1
-            fetchB(c + 2);
-            fetchA(c + 3, ra1);
-            __syncthreads();
-            stash(0, ra0);                             // stage c + 2
-            fetchB(c + 3);
-            fetchA(c + 4, ra0);
-            __syncthreads();
-        }
-        if (n_stage & 1) __syncthreads();
-    } else {
-#pragma unroll
-        for (int t = 0; t < TA; ++t)
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
-        for (int c = 0; c < (n_stage & ~1); c += 2) {
-            GS_MUL(0, c + 1);
-            GS_STAMP(4 + 4 * c);
-            __syncthreads();
-            GS_STAMP(5 + 4 * c);
-            GS_MUL(1, c + 2);
-            GS_STAMP(8 + 4 * c);
-            __syncthreads();
-            GS_STAMP(9 + 4 * c);
-        }
-        if (n_stage & 1) {
-            GS_MUL(0, n_stage);
-            __syncthreads();
-        }
-    }
-#else
-    // Every wave stages the next stage first, then multiplies the current one.  GS_PHASE = 1 (developer builds) puts the two
-    // waves of a SIMD OUT OF PHASE inside the barrier interval (one half of the waves stages first, the other multiplies
-    // first -- what helped csrc/wgrad_split.hip): measured 5-7 % slower here at every shape.
-    const bool stage_first = GS_PHASE ? __builtin_amdgcn_readfirstlane(wave) < 4 : true;   // (scalar: a real branch)
+    // Every wave stages the next stage first, then multiplies the current one.
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
-        if (stage_first) {
-            stash(1, ra1);                             // stage c + 1
-            GS_STAMP(2 + 4 * c);
-            fetchB(c + 2);
-            fetchA(c + 3, ra1);
-            GS_STAMP(3 + 4 * c);
-        }
+        stash(1, ra1);                             // stage c + 1
+        fetchB(c + 2);
+        fetchA(c + 3, ra1);
         multiply(0);
-        GS_STAMP(4 + 4 * c);
-        if (!stage_first) {
-            stash(1, ra1);
-            fetchB(c + 2);
-            fetchA(c + 3, ra1);
-        }
-        if (!(GS_PROBE & 1024)) __syncthreads();
-        GS_STAMP(5 + 4 * c);
-        if (stage_first) {
-            stash(0, ra0);                             // stage c + 2 (past the end: the last stage again, never multiplied)
-            GS_STAMP(6 + 4 * c);
-            fetchB(c + 3);
-            fetchA(c + 4, ra0);
-            GS_STAMP(7 + 4 * c);
-        }
+        __syncthreads();
+        stash(0, ra0);                             // stage c + 2 (past the end: the last stage again, never multiplied)
+        fetchB(c + 3);
+        fetchA(c + 4, ra0);
         multiply(1);
-        GS_STAMP(8 + 4 * c);
-        if (!stage_first) {
-            stash(0, ra0);
-            fetchB(c + 3);
-            fetchA(c + 4, ra0);
-        }
-        if (!(GS_PROBE & 1024)) __syncthreads();
-        GS_STAMP(9 + 4 * c);
+        __syncthreads();
     }
     if (n_stage & 1) {                             // the last stage of an odd count lies in buffer 0
         multiply(0);
-        if (!(GS_PROBE & 1024)) __syncthreads();
+        __syncthreads();
     }
-#endif
 
     // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
-    // 32 16-byte stores per lane and tile (the untransposed accumulator needed 128 dword stores; same time: what the result
-    // costs is its write traffic, 7-11 % of the kernel while every CU reaches its epilogue in the same phase of a round --
-    // tools/gemm_probe.py, GS_PROBE 512)
+    // Column group (u, g) outer, row block t inner: the four columns of a group are finished for all of the lane's rows
+    // before the next group starts, so their column maxima need four registers, not sixty-four; a row's statistics (squared
+    // error, maximum) still accumulate over (u, g, j) ascending -- the order of round 3's row-major epilogue, same bits.
+    // EPI 2 / 3 read X / Y beside every result they store.  The compiler may not move a load above a store that could alias
+    // it, so the aux values of a whole column group are requested before its stores, and the next group's before that.
+    const bool want_rowmax = p.c_rowmax != nullptr, want_colmax = p.c_colmax != nullptr;
     float rowsq[TA];
-#if GS_F16
-    float rowmx[TA];
-#pragma unroll
-    for (int t = 0; t < TA; ++t) rowmx[t] = 0.0f;
-#endif
-    // EPI == 2 reads x beside every result it stores.  The compiler may not move a load above a store that could alias
-    // it, so with load / compute / store per 16 bytes every one of the 32 loads of a lane waited for its own latency AND
-    // for the store before it (the recon GEMM ran 547 us against 440 for the plain one).  The x values of a whole row
-    // block are therefore requested first, and those of the next block before this block's stores.
-    gs_f32x4 xv[2][UB * 4];
-    auto load_x = [&](int t, gs_f32x4 *dst) {
-        const long long row = m0 + 32 * TA * wm + 32 * t + il;
-        const float *xs = p.X + (size_t)(row < p.M ? row : p.M - 1) * p.Nc + n0 + 32 * UB * wn + 4 * h;
-#pragma unroll
-        for (int u = 0; u < UB; ++u)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dst[u * 4 + g] = *reinterpret_cast<const gs_f32x4 *>(xs + 32 * u + 8 * g);
-    };
-    if (EPI == 2 && tiler && !(GS_PROBE & 512)) load_x(0, xv[0]);
+    unsigned rowmx[TA];
+    long long rows[TA];
+    int er[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
-        const long long row = m0 + 32 * TA * wm + 32 * t + il;
         rowsq[t] = 0.0f;
-        if (EPI == 2 && tiler && t + 1 < TA && !(GS_PROBE & 512)) load_x(t + 1, xv[(t + 1) & 1]);
-        if (tiler && row < p.M && !(GS_PROBE & 512)) {
-            float *dst = p.C + (size_t)row * p.Nc + n0 + 32 * UB * wn + 4 * h;
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
-#if GS_F16
-                    {   // undo the row and column scales (exact)
-                        int er = p.a_exp ? p.a_exp[row] : 0;
-                        if (p.a_is_max) er = gs_exp_of(__builtin_bit_cast(float, er));
-                        const int *ec = p.b_exp + n0 + 32 * UB * wn + 4 * h + 32 * u + 8 * g;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er + ec[j]);
-                    }
-#endif
-                    if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
-                        v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
-                        v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
-                    }
-                    if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
-                        const gs_f32x4 x4 = xv[t & 1][u * 4 + g];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float d = v[j] - x4[j];
-                            rowsq[t] = rowsq[t] + d * d;
-                            v[j] = (2.0f * d) * p.row_scale;
-                        }
-                    }
-#if GS_F16
-                    if (EPI != 2) rowmx[t] = fmaxf(fmaxf(rowmx[t], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-#endif
-                    *reinterpret_cast<gs_f32x4 *>(dst + 32 * u + 8 * g) = v;   // (non-temporal stores: +2 ... +36 %)
-                }
-        }
+        rowmx[t] = 0u;
+        rows[t] = m0 + 32 * TA * wm + 32 * t + il;
+        er[t] = NP == 2 ? s_aexp[32 * TA * wm + 32 * t + il] : 0;
     }
-#if GS_F16
-    if (EPI != 2 && p.rowmax_out && tiler) {   // this wave's 32 UB columns of a row: both lane halves, then one atomic per row
+    const int col0 = n0 + 32 * UB * wn + 4 * h;        // + 32 u + 8 g (+ j)
+    constexpr int kAuxDepth = 2;           // column groups whose aux values are in flight ahead of the one being stored
+    gs_f32x4 xv[kAuxDepth + 1][TA];
+    auto load_aux = [&](int ug, gs_f32x4 *dst) {
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+            dst[t] = *reinterpret_cast<const gs_f32x4 *>(p.X + (size_t)(rows[t] < p.M ? rows[t] : p.M - 1) * p.Nc + col0 + 32 * (ug >> 2) + 8 * (ug & 3));
+    };
+    if (EPI >= 2) {
+#pragma unroll
+        for (int a = 0; a < kAuxDepth; ++a) load_aux(a, xv[a]);
+    }
+#pragma unroll
+    for (int ug = 0; ug < UB * 4; ++ug) {
+        const int u = ug >> 2, g = ug & 3, col = col0 + 32 * u + 8 * g;
+        if (EPI >= 2 && ug + kAuxDepth < UB * 4) load_aux(ug + kAuxDepth, xv[(ug + kAuxDepth) % (kAuxDepth + 1)]);
+        gs_i32x4 ec = {0, 0, 0, 0};
+        if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + col);
+        unsigned cmx[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
-            const long long row = m0 + 32 * TA * wm + 32 * t + il;
-            const float mx = fmaxf(rowmx[t], __shfl_xor(rowmx[t], 32, 64));
-            if (h == 0 && row < p.M) atomicMax(p.rowmax_out + row, __builtin_bit_cast(unsigned, mx));
+            gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+            if (NP == 2) {   // undo the row and column scales (exact)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er[t] + ec[j]);
+            }
+            if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
+                v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
+                v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+            }
+            if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
+                const gs_f32x4 x4 = xv[ug % (kAuxDepth + 1)][t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[j] - x4[j];
+                    rowsq[t] = rowsq[t] + d * d;
+                    v[j] = (2.0f * d) * p.row_scale;
+                }
+            }
+            if (EPI == 3) {   // threshold_backward(g, y, 0): 0 where y <= 0
+                const gs_f32x4 y4 = xv[ug % (kAuxDepth + 1)][t];
+                v.x = y4.x <= 0.0f ? 0.0f : v.x; v.y = y4.y <= 0.0f ? 0.0f : v.y;
+                v.z = y4.z <= 0.0f ? 0.0f : v.z; v.w = y4.w <= 0.0f ? 0.0f : v.w;
+            }
+            if (rows[t] < p.M) {
+                if (want_rowmax | want_colmax) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned b = gs_abs_bits(v[j]);
+                        rowmx[t] = gs_umax(rowmx[t], b);
+                        cmx[j] = gs_umax(cmx[j], b);
+                    }
+                }
+                *reinterpret_cast<gs_f32x4 *>(p.C + (size_t)rows[t] * p.Nc + col) = v;   // (non-temporal stores: +2 ... +36 %)
+            }
+        }
+        if (want_colmax) {   // the 32 rows of the half-wave (DPP: no LDS traffic), then one LDS (or memory) atomic per column
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned m = gs_half_wave_umax(cmx[j]);      // valid in lanes 31 and 63
+                if (il == 31 && m != 0u) {
+                    if (p.Nc <= kGsColmaxLds) atomicMax(&s_colmax[col + j], m);
+                    else atomicMax(p.c_colmax + col + j, m);
+                }
+            }
         }
     }
-#endif
+    if (want_rowmax) {
+        // a row's maximum over this column tile: both lane halves, then the WN column waves through LDS (free: the loop's
+        // last barrier has been passed; EPI 2's `red` lies behind it) -- one part per column tile, one plain store per row
+        unsigned *mred = sbuf + WN * ROWS;                       // [WN][ROWS]
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const unsigned mx = gs_umax(rowmx[t], (unsigned)__shfl_xor((int)rowmx[t], 32, 64));
+            if (h == 0) mred[wn * ROWS + 32 * TA * wm + 32 * t + il] = mx;
+        }
+        __syncthreads();
+        unsigned *dst = p.c_rowmax + (size_t)(n0 / COLS) * p.M;
+        for (int r = tid; r < ROWS; r += kGsThreads) {
+            if (m0 + r >= p.M) continue;
+            unsigned mx = mred[r];
+#pragma unroll
+            for (int w = 1; w < WN; ++w) mx = gs_umax(mx, mred[w * ROWS + r]);
+            dst[m0 + r] = mx;
+        }
+    }
     if (EPI == 2) {
         // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
         // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
@@ -559,28 +565,33 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
             const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
-            if (h == 0 && tiler) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
+            if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
         }
         __syncthreads();
-        for (int r = (int)threadIdx.x; r < ROWS; r += kGsThreads) {
+        for (int r = tid; r < ROWS; r += kGsThreads) {
             if (m0 + r >= p.M) continue;
             float sum = red[r];
 #pragma unroll
             for (int w = 1; w < WN; ++w) sum = sum + red[w * ROWS + r];
-            p.rowsum[(size_t)(n0 / kGsCols) * p.M + m0 + r] = sum;
+            p.rowsum[(size_t)(n0 / COLS) * p.M + m0 + r] = sum;
         }
         // (the persistent loop's barrier at its top keeps the next tile's staging off `red`)
     }
 }
 
-template <int EPI, int COLS>
+template <int EPI, int COLS, int NP>
 __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
     constexpr int kSmallRows = (8 / (COLS / 64)) * 32;   // 64 (COLS = 256) or 128 (COLS = 128)
-    constexpr int kBigRows = (GS_PC && COLS == 256) ? 192 : 256;   // (GS_PC: 96 accumulators per lane leave room for a stage's operands in 170 registers)
+    constexpr int kBigRows = 256;
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
     __shared__ unsigned s_tile;
+    __shared__ int s_aexp[kBigRows];
+    __shared__ unsigned s_colmax[kGsColmaxLds];
     const int tid = threadIdx.x;
+    const bool lds_colmax = p.c_colmax != nullptr && p.Nc <= kGsColmaxLds;
+    if (lds_colmax)
+        for (int c = tid; c < p.Nc; c += kGsThreads) s_colmax[c] = 0u;
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
         if (tid == 0) s_tile = atomicAdd(p.counter, 1u);
@@ -599,18 +610,17 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
         // round is cut into 64-row tiles so that it spreads over all CUs instead of giving a few of them a fourth big
         // tile (100 000 x 512: 782 big tiles on 256 CUs were 4 tile times for 3.05 rounds of work).
         if (tile < p.n_big) {
-            int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
-#if GS_XCD_GROUP
-            // tickets t, t + 8, .. (the same XCD while tickets are taken in workgroup order) share one row tile's A strip
-            const unsigned grp = 8u * (unsigned)p.n_col_tiles, g = tile / grp, in = tile % grp;
-            if ((g + 1) * grp <= p.n_big) { rt = (int)(g * 8u + (in & 7u)); ct = (int)(in >> 3); }
-#endif
-            gs_tile<EPI, kBigRows / kSmallRows, COLS>(p, sbuf, (long long)rt * kBigRows, ct * COLS);
+            const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+            gs_tile<EPI, kBigRows / kSmallRows, COLS, NP>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
         } else {
             const unsigned st = tile - p.n_big;
             const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
-            gs_tile<EPI, 1, COLS>(p, sbuf, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
+            gs_tile<EPI, 1, COLS, NP>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
         }
+    }
+    if (lds_colmax) {   // (every wave of the workgroup passed the loop's barriers after its last LDS maximum)
+        for (int c = tid; c < p.Nc; c += kGsThreads)
+            if (s_colmax[c]) atomicMax(p.c_colmax + c, s_colmax[c]);
     }
 }
 
@@ -629,170 +639,196 @@ __global__ __launch_bounds__(256) void recon_rows_finish_kernel(const float *__r
 using namespace rqhip;
 
 static int gs_cols(int Nc) { return Nc % 256 == 0 ? 256 : 128; }   // tile width
+static int gs_np(int arith) { return arith == RQHIP_SPLIT_F16X2 ? 2 : arith == RQHIP_SPLIT_BF16X3 ? 3 : 0; }
 extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R > 0 && Nc % 128 == 0 && R % kGsK == 0) ? 1 : 0; }
 
-extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) {
-    if (!rqhip_gemm_split_supported(Nc, R)) return 0;
-    return (size_t)(R / kGsK) * 2 * kGsNP * Nc * 16 + 64 + (GS_F16 ? (size_t)Nc * sizeof(int) : 0);    // + the tile counter (+ GS_F16: the weight rows' exponents) behind the image
+extern "C" size_t rqhip_weight_image_bytes(int Nc, int R, int arith) {
+    const int np = gs_np(arith);
+    if (!np || !rqhip_gemm_split_supported(Nc, R)) return 0;
+    return (size_t)(R / kGsK) * 2 * np * Nc * 16 + 64 + (np == 2 ? (size_t)Nc * sizeof(int) : 0);   // + the tile counter (+ exponents)
+}
+extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) { return rqhip_weight_image_bytes(Nc, R, RQHIP_SPLIT_BF16X3); }
+
+extern "C" int rqhip_weight_images(const rqhip_image_job *jobs, int n_jobs, rqhip_stream_t stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) {
+        set_error("weight_images: bad job list");
+        return RQHIP_EARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int first = 0; first < n_jobs; first += kImgMaxJobs) {
+        ImageJobs batch;
+        batch.n = n_jobs - first < kImgMaxJobs ? n_jobs - first : kImgMaxJobs;
+        int blocks = 0;
+        for (int i = 0; i < batch.n; ++i) {
+            const rqhip_image_job &j = jobs[first + i];
+            // w is [rows, cols] row-major.  transpose == 0: B = w (Nc = rows, R = cols); transpose == 1: B = w^T (Nc = cols, R = rows)
+            const int Nc = j.transpose ? j.cols : j.rows, R = j.transpose ? j.rows : j.cols;
+            const size_t need = rqhip_weight_image_bytes(Nc, R, j.arith);
+            if (!j.w || !j.image || need == 0 || j.image_bytes < need || (reinterpret_cast<uintptr_t>(j.image) & 15u) != 0) {
+                set_error("weight_images: job %d: bad arguments or unsupported shape (Nc = %d must be a multiple of 128, R = %d of 16, "
+                          "image of rqhip_weight_image_bytes, 16-byte aligned)", first + i, Nc, R);
+                return RQHIP_EARG;
+            }
+            ImageJob &d = batch.j[i];
+            d.src = j.w; d.image = reinterpret_cast<unsigned *>(j.image); d.Nc = Nc; d.R = R; d.transpose = j.transpose ? 1 : 0;
+            d.np = gs_np(j.arith); d.block0 = blocks;
+            blocks += Nc / kImgCols;
+        }
+        hipLaunchKernelGGL(weight_images_kernel, dim3((unsigned)blocks), dim3(256), 0, s, batch);
+        RQ_CHECK_LAUNCH("weight_images_kernel");
+    }
+    return RQHIP_OK;
 }
 
 extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int transpose, void *planes, size_t planes_bytes,
                                    rqhip_stream_t stream) {
-    // w is [rows, cols] row-major.  transpose == 0: B = w (Nc = rows, R = cols); transpose == 1: B = w^T (Nc = cols, R = rows)
-    const int Nc = transpose ? cols : rows, R = transpose ? rows : cols;
-    if (!w || !planes || !rqhip_gemm_split_supported(Nc, R) || planes_bytes < rqhip_weight_planes_bytes(Nc, R)) {
-        set_error("weight_planes: bad arguments or unsupported shape (Nc = %d must be a multiple of 128, R = %d of 16)", Nc, R);
+    rqhip_image_job j;
+    j.w = w; j.rows = rows; j.cols = cols; j.transpose = transpose; j.arith = RQHIP_SPLIT_BF16X3; j.image = planes; j.image_bytes = planes_bytes;
+    return rqhip_weight_images(&j, 1, stream);
+}
+
+extern "C" int rqhip_maxima(const float *A, const float *Y, float *masked_out, int64_t M, int R, unsigned *row_max, unsigned *col_max,
+                            rqhip_stream_t stream) {
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (M < 0 || R <= 0 || (R % 4) != 0 || R > 1024 || (M > 0 && !A) || (masked_out && !Y) || !al16(A) || !al16(Y) || !al16(masked_out)) {
+        set_error("maxima: bad arguments (R = %d must be a multiple of 4, at most 1024; 16-byte aligned rows; masked_out needs Y)", R);
         return RQHIP_EARG;
     }
+    if (M == 0 || (!row_max && !col_max && !masked_out)) return RQHIP_OK;
+    long long blocks = (M + 3) / 4;
+    const long long cap = (long long)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long long total = (long long)Nc * (R / 2);
-#if GS_F16
-    hipLaunchKernelGGL(weight_exps_kernel, dim3(Nc), dim3(64), 0, s, w, Nc, R, transpose,
-                       reinterpret_cast<int *>(reinterpret_cast<unsigned *>(planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16));
-    RQ_CHECK_LAUNCH("weight_exps_kernel");
-#endif
-    hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, Nc, R, transpose,
-                       reinterpret_cast<unsigned *>(planes));
-    RQ_CHECK_LAUNCH("weight_planes_kernel");
+    profile_begin(s, RQHIP_PROF_MAXIMA, 0.0, (double)M * R * 4 * ((Y ? 2 : 1) + (masked_out ? 1 : 0)));
+    hipLaunchKernelGGL(maxima_kernel, dim3((unsigned)blocks), dim3(256), col_max ? (size_t)R * 4 : 0, s, A, Y, masked_out, (long long)M, R,
+                       row_max, col_max);
+    profile_end(s);
+    RQ_CHECK_LAUNCH("maxima_kernel");
     return RQHIP_OK;
-}
-
-static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int epi, float *C, int flags_tile,
-                             const float *X, float row_scale, float *rowsum, rqhip_stream_t stream);
-
-#if GS_F16
-static const int *g_gs_a_exp = nullptr;   // (prototype plumbing: the row exponents of the next gemm_split_launch)
-static int g_gs_a_is_max = 0;
-static unsigned *g_gs_rowmax_out = nullptr;
-// exponents of the rows of A for rqhip_gemm_split_f16; A rows must be 16-byte aligned (R % 4 == 0)
-extern "C" int rqhip_row_exponents(const float *A, int64_t M, int R, int *exps, rqhip_stream_t stream) {
-    if (M < 0 || R <= 0 || (R % 4) != 0 || (M > 0 && (!A || !exps))) {
-        set_error("row_exponents: bad arguments");
-        return RQHIP_EARG;
-    }
-    if (M == 0) return RQHIP_OK;
-    hipLaunchKernelGGL(row_exps_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A,
-                       (long long)M, R, exps);
-    RQ_CHECK_LAUNCH("row_exps_kernel");
-    return RQHIP_OK;
-}
-// rqhip_gemm_split with the rows of A scaled by 2^-a_exp[row] before the fp16 split (a_exp from rqhip_row_exponents)
-extern "C" int rqhip_gemm_split_f16(const float *A, const int *a_exp, int64_t M, int R, const void *planes, int Nc, int relu,
-                                    float *C, rqhip_stream_t stream) {
-    g_gs_a_exp = a_exp;
-    const int rc = gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, 0, nullptr, 0.0f, nullptr, stream);
-    g_gs_a_exp = nullptr;
-    return rc;
-}
-// the chained form: a_max = the row maxima another GEMM left in its rowmax_out (bit patterns; used in place of exponents), and
-// rowmax_out (zeroed by the caller, or nullptr) receives this GEMM's for the next one.  NOT validated on the GPU yet.
-extern "C" int rqhip_gemm_split_f16_chain(const float *A, const unsigned *a_max, int64_t M, int R, const void *planes, int Nc,
-                                          int relu, float *C, unsigned *rowmax_out, rqhip_stream_t stream) {
-    g_gs_a_exp = reinterpret_cast<const int *>(a_max);
-    g_gs_a_is_max = a_max ? 1 : 0;
-    g_gs_rowmax_out = rowmax_out;
-    const int rc = gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, 0, nullptr, 0.0f, nullptr, stream);
-    g_gs_a_exp = nullptr;
-    g_gs_a_is_max = 0;
-    g_gs_rowmax_out = nullptr;
-    return rc;
-}
-#endif
-
-extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
-                                rqhip_stream_t stream) {
-    return gemm_split_launch(A, M, R, planes, Nc, relu & 1, C, (relu >> 8) & 0xfff, nullptr, 0.0f, nullptr,
-                             stream);   // (bits 8.. of `relu`: tile rows, A/B)
 }
 
 extern "C" size_t rqhip_gemm_split_recon_workspace_bytes(int64_t M, int Nc) {
     return (M > 0 && Nc > 0 && Nc % 256 == 0) ? (size_t)(Nc / 256) * (size_t)M * sizeof(float) : 0;
 }
 
-extern "C" int rqhip_gemm_split_recon(const float *A, int64_t M, int R, const void *planes, int Nc, const float *X,
-                                      float row_scale, float *G, float *loss_rows, void *workspace, size_t workspace_bytes,
-                                      rqhip_stream_t stream) {
-    if (M > 0 && (!X || !G || !loss_rows || !workspace || Nc % 256 != 0 ||
-                  workspace_bytes < rqhip_gemm_split_recon_workspace_bytes(M, Nc) || (reinterpret_cast<uintptr_t>(X) & 15u) != 0)) {
-        set_error("gemm_split_recon: bad arguments (X, G, loss_rows, workspace of rqhip_gemm_split_recon_workspace_bytes)");
+extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stream) {
+    if (!a) {
+        set_error("gemm_split: null argument block");
         return RQHIP_EARG;
     }
-    const int rc = gemm_split_launch(A, M, R, planes, Nc, 2, G, 0, X, row_scale, reinterpret_cast<float *>(workspace), stream);
-    if (rc != RQHIP_OK || M == 0) return rc;
-    hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(workspace), Nc / 256,
-                       (long long)M, loss_rows);
-    RQ_CHECK_LAUNCH("recon_rows_finish_kernel");
-    return RQHIP_OK;
-}
-
-static int gemm_split_launch(const float *A, int64_t M, int R, const void *planes, int Nc, int epi, float *C, int flags_tile,
-                             const float *X, float row_scale, float *rowsum, rqhip_stream_t stream) {
-    if (M < 0 || !planes || (M > 0 && (!A || !C)) || !rqhip_gemm_split_supported(Nc, R)) {
-        set_error("gemm_split: bad arguments or unsupported shape (Nc = %d, R = %d)", Nc, R);
+    const int np = gs_np(a->arith), epi = a->epilogue;
+    const int64_t M = a->M;
+    const int R = a->R, Nc = a->Nc;
+    if (!np || M < 0 || !a->image || (M > 0 && (!a->A || !a->C)) || !rqhip_gemm_split_supported(Nc, R) || epi < 0 || epi > 3) {
+        set_error("gemm_split: bad arguments or unsupported shape (Nc = %d, R = %d, arithmetic %d, epilogue %d)", Nc, R, a->arith, epi);
         return RQHIP_EARG;
     }
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (!al16(A) || !al16(C) || !al16(planes) || (R % 4) != 0) {
+    if (!al16(a->A) || !al16(a->C) || !al16(a->image) || !al16(a->aux) || (R % 4) != 0) {
         set_error("gemm_split: pointers must be 16-byte aligned");
+        return RQHIP_EARG;
+    }
+    if (M > 0 && np == 2 && (!a->a_row_max || a->a_row_parts < 1)) {
+        set_error("gemm_split: RQHIP_SPLIT_F16X2 needs the row maxima of A (a_row_max from rqhip_maxima or from the epilogue that wrote A)");
+        return RQHIP_EARG;
+    }
+    if (M > 0 && epi >= RQHIP_EPI_RECON && !a->aux) {
+        set_error("gemm_split: epilogue %d needs aux (X / Y, [M, Nc])", epi);
+        return RQHIP_EARG;
+    }
+    const int cols = gs_cols(Nc);
+    if (epi == RQHIP_EPI_RECON && M > 0 && (cols != 256 || !a->loss_rows || !a->workspace ||
+                                           a->workspace_bytes < rqhip_gemm_split_recon_workspace_bytes(M, Nc))) {
+        set_error("gemm_split: the reconstruction-loss epilogue needs Nc %% 256 == 0 (Nc = %d), loss_rows and a workspace of "
+                  "rqhip_gemm_split_recon_workspace_bytes", Nc);
         return RQHIP_EARG;
     }
     if (M == 0) return RQHIP_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     GemmSplitParams p;
-    p.A = A; p.planes = reinterpret_cast<const unsigned *>(planes); p.C = C; p.M = M; p.R = R; p.Nc = Nc;
-    p.X = X; p.rowsum = rowsum; p.row_scale = row_scale;
-#if GS_F16
-    p.a_exp = g_gs_a_exp;    // (set by rqhip_gemm_split_f16 around this call; nullptr otherwise)
-    p.a_is_max = g_gs_a_is_max;
-    p.rowmax_out = g_gs_rowmax_out;
-    p.b_exp = reinterpret_cast<const int *>(reinterpret_cast<const unsigned *>(planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4 + 16);
-#endif
+    p.A = a->A; p.planes = reinterpret_cast<const unsigned *>(a->image); p.C = a->C; p.M = M; p.R = R; p.Nc = Nc;
+    p.X = a->aux; p.rowsum = reinterpret_cast<float *>(a->workspace); p.row_scale = a->row_scale;
+    p.a_max = a->a_row_max; p.a_parts = a->a_row_parts;
+    p.c_rowmax = a->c_row_max; p.c_colmax = a->c_col_max;
+    // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
+    // GEMM at a time per image, i.e. launches on one stream
+    p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
+    p.b_exp = reinterpret_cast<const int *>(p.counter + 16);
     const int cus = cu_count();
-    const int cols = gs_cols(Nc), small_rows = cols == 256 ? 64 : 128;
+    const int small_rows = cols == 256 ? 64 : 128;
     p.n_col_tiles = Nc / cols;
     // whole rounds of 256-row tiles, the remainder as 64-row (128-row for the 128-column tile) tiles (see the kernel);
-    // flags_tile (tools only): 256 = big tiles for every row, 64 = small tiles for every row
-    const int big_rows = (GS_PC && cols == 256) ? 192 : 256;
+    // tile_rows (tools only): 256 = big tiles for every row, 64 = small tiles for every row
+    const int big_rows = 256;
     const long long rt256 = (M + big_rows - 1) / big_rows;
     long long rt_big = ((rt256 * p.n_col_tiles) / cus) * cus / p.n_col_tiles;   // row tiles of the whole rounds
     if (rt_big * big_rows > M) rt_big = M / big_rows;
     // (measured at 100 000 rows: worth it when the leftover is a small part of a round -- Nc = 512: 14 of 256 slots, 517 ->
     // 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
     if ((rt256 * p.n_col_tiles) % cus > (3 * cus) / 10 && rt256 * p.n_col_tiles >= cus) rt_big = rt256;
-    if (flags_tile == 256) rt_big = rt256;
-    if (flags_tile == 64) rt_big = 0;
+    if (a->tile_rows == 256) rt_big = rt256;
+    if (a->tile_rows == 64) rt_big = 0;
     const long long rem_rows = M - rt_big * big_rows > 0 ? M - rt_big * big_rows : 0;
     const long long rt_small = (rem_rows + small_rows - 1) / small_rows;
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
-    // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_planes, re-armed by every launch): one
-    // GEMM at a time per image, i.e. launches on one stream
-    p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * kGsNP * Nc * 4;
-    const size_t lds = (size_t)2 * (kGsNP * 2 * (256 + cols) * 16);
+    const size_t lds = (size_t)2 * (np * 2 * (256 + cols) * 16);
     const long long tiles = (long long)p.n_tiles;
-    const long long slots = (long long)cus;                // one workgroup per CU (240 VGPRs x 512 threads)
+    const long long slots = (long long)cus;                // one workgroup per CU
     const int grid = (int)(tiles < slots ? tiles : slots);
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
-        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)lds));   // (+ 4 bytes of static LDS)
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)lds));   // (+ the static LDS)
+        // algorithmic work of the launch: 2 M Nc R FLOP; bytes: A once, C once (+ the aux matrix)
+        profile_begin(s, RQHIP_PROF_GEMM_SPLIT, 2.0 * (double)M * Nc * R, 4.0 * (double)M * (R + Nc * (epi >= 2 ? 2 : 1)));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kGsThreads), lds, s, p);
+        profile_end(s);
         RQ_CHECK_LAUNCH("gemm_split_kernel");
         return 0;
     };
-    if (cols == 128) {
-        if (epi == 2) {
-            set_error("gemm_split: the reconstruction-loss epilogue needs Nc %% 256 == 0 (Nc = %d)", Nc);
-            return RQHIP_EARG;
+    int rc;
+    if (np == 2) {
+        if (cols == 128)
+            rc = epi == 3 ? go(gemm_split_kernel<3, 128, 2>) : epi == 1 ? go(gemm_split_kernel<1, 128, 2>) : go(gemm_split_kernel<0, 128, 2>);
+        else
+            rc = epi == 3 ? go(gemm_split_kernel<3, 256, 2>) : epi == 2 ? go(gemm_split_kernel<2, 256, 2>)
+                 : epi == 1 ? go(gemm_split_kernel<1, 256, 2>) : go(gemm_split_kernel<0, 256, 2>);
+    } else {
+        if (epi == 3) {
+            set_error("gemm_split: the masked epilogue exists for RQHIP_SPLIT_F16X2 only");
+            return RQHIP_EUNSUPPORTED;
         }
-        return epi == 1 ? go(gemm_split_kernel<1, 128>) : go(gemm_split_kernel<0, 128>);
+        if (cols == 128) rc = epi == 1 ? go(gemm_split_kernel<1, 128, 3>) : go(gemm_split_kernel<0, 128, 3>);
+        else rc = epi == 2 ? go(gemm_split_kernel<2, 256, 3>) : epi == 1 ? go(gemm_split_kernel<1, 256, 3>) : go(gemm_split_kernel<0, 256, 3>);
     }
-    return epi == 2 ? go(gemm_split_kernel<2, 256>) : epi == 1 ? go(gemm_split_kernel<1, 256>) : go(gemm_split_kernel<0, 256>);
+    if (rc) return rc;
+    if (epi == RQHIP_EPI_RECON) {
+        hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float *>(a->workspace), Nc / 256, (long long)M, a->loss_rows);
+        RQ_CHECK_LAUNCH("recon_rows_finish_kernel");
+    }
+    return RQHIP_OK;
 }
 
-#ifdef GS_TIMING
-extern "C" int rqhip_gs_debug_read(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rqhip::gs_dbg), sizeof(unsigned long long) * 8 * 64);
+// ---- the round-3 entry points: RQHIP_SPLIT_BF16X3 --------------------------------------------------------------------------------
+extern "C" int rqhip_gemm_split(const float *A, int64_t M, int R, const void *planes, int Nc, int relu, float *C,
+                                rqhip_stream_t stream) {
+    rqhip_gemm_args a = {};
+    a.A = A; a.M = M; a.R = R; a.image = planes; a.Nc = Nc; a.arith = RQHIP_SPLIT_BF16X3; a.epilogue = relu & 1; a.C = C;
+    a.tile_rows = (relu >> 8) & 0xfff;   // (bits 8.. of `relu`: tile rows, A/B)
+    return rqhip_gemm_split_ex(&a, stream);
 }
-#endif
+
+extern "C" int rqhip_gemm_split_recon(const float *A, int64_t M, int R, const void *planes, int Nc, const float *X,
+                                      float row_scale, float *G, float *loss_rows, void *workspace, size_t workspace_bytes,
+                                      rqhip_stream_t stream) {
+    rqhip_gemm_args a = {};
+    a.A = A; a.M = M; a.R = R; a.image = planes; a.Nc = Nc; a.arith = RQHIP_SPLIT_BF16X3; a.epilogue = RQHIP_EPI_RECON; a.C = G;
+    a.aux = X; a.row_scale = row_scale; a.loss_rows = loss_rows; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    if (M > 0 && (!X || !G || !loss_rows || !workspace)) {
+        set_error("gemm_split_recon: bad arguments (X, G, loss_rows, workspace of rqhip_gemm_split_recon_workspace_bytes)");
+        return RQHIP_EARG;
+    }
+    return rqhip_gemm_split_ex(&a, stream);
+}

@@ -137,19 +137,38 @@ __global__ __launch_bounds__(256) void recon_bwd_spec_kernel(const float *__rest
 // Backward of the reconstruction loss FUSED into the last decoder GEMM (csrc/gemm_split.hip, EPI 2): x_hat was never
 // stored, so a row whose upstream gradient is not row_scale is rescaled, g_spec * (g / row_scale), instead of recomputed
 // (one more rounding than (2 d) g; rows that match -- every row of a training step -- are not touched).
+// row_max [parts][B] / col_max [N] (optional): the maxima the fused epilogue emitted for g_spec (the scales of the fp16 split
+// kernels that read it next) are brought up to date for the rows that change: the row's new maximum goes to part 0 (the other
+// parts are cleared), the columns are maxed into atomically (a stale, larger column maximum is a valid scale).
 __global__ __launch_bounds__(256) void recon_rescale_rows_kernel(const float *__restrict__ g, long long B, int N,
-                                                                 float row_scale, float *__restrict__ gs) {
+                                                                 float row_scale, float *__restrict__ gs,
+                                                                 unsigned *__restrict__ row_max, int parts,
+                                                                 unsigned *__restrict__ col_max) {
     const int lane = threadIdx.x & 63;
     const long long waves = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (long long row = gw; row < B; row += waves) {
         const float gr = g[row];
         if (__float_as_uint(gr) == __float_as_uint(row_scale)) continue;
         const float f = gr / row_scale;
+        unsigned rm = 0u;
         for (int i = lane; i < N / 4; i += 64) {
             f32x4 o = *reinterpret_cast<const f32x4 *>(gs + row * (long long)N + 4 * i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = o[j] * f;
+            for (int j = 0; j < 4; ++j) {
+                o[j] = o[j] * f;
+                const unsigned b = __float_as_uint(o[j]) & 0x7fffffffu;
+                rm = rm > b ? rm : b;
+                if (col_max && b) atomicMax(col_max + 4 * i + j, b);
+            }
             *reinterpret_cast<f32x4 *>(gs + row * (long long)N + 4 * i) = o;
+        }
+        if (row_max) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)rm, o, 64);
+                rm = rm > other ? rm : other;
+            }
+            if (lane < parts) row_max[(size_t)lane * B + row] = lane == 0 ? rm : 0u;
         }
     }
 }
@@ -290,18 +309,23 @@ extern "C" int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat
     return RQHIP_OK;
 }
 
-extern "C" int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
-                                        rqhip_stream_t stream) {
+extern "C" int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
+                                           unsigned *row_max, int row_parts, unsigned *col_max, rqhip_stream_t stream) {
     if (B < 0 || N < 4 || (N % 4) != 0 || (B > 0 && (!g_out || !g_spec)) || (reinterpret_cast<uintptr_t>(g_spec) & 15u) != 0 ||
-        !(row_scale != 0.0f)) {
-        set_error("recon_rescale_rows: bad arguments (N a multiple of 4, 16-byte aligned g_spec, non-zero row_scale)");
+        !(row_scale != 0.0f) || (row_max && (row_parts < 1 || row_parts > 64))) {
+        set_error("recon_rescale_rows: bad arguments (N a multiple of 4, 16-byte aligned g_spec, non-zero row_scale, 1 .. 64 row-maxima parts)");
         return RQHIP_EARG;
     }
     if (B == 0) return RQHIP_OK;
     hipLaunchKernelGGL(recon_rescale_rows_kernel, dim3(row_grid(B)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       g_out, (long long)B, N, row_scale, g_spec);
+                       g_out, (long long)B, N, row_scale, g_spec, row_max, row_parts, col_max);
     RQ_CHECK_LAUNCH("recon_rescale_rows_kernel");
     return RQHIP_OK;
+}
+
+extern "C" int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_scale, float *g_spec,
+                                        rqhip_stream_t stream) {
+    return rqhip_recon_rescale_rows_ex(g_out, B, N, row_scale, g_spec, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int rqhip_loss_means_backward(const float *g_loss, const float *g_recon_mean, const float *g_quant_mean,

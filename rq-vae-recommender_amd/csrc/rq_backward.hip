@@ -746,11 +746,31 @@ extern "C" size_t rqhip_rq_backward_workspace_bytes(int64_t B, int D, int L, int
     return rows + g * (size_t)L * K * D * sizeof(float);
 }
 
+static int rq_backward_impl(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                            int mode, float beta, const int64_t *ids, const float *g_embs,
+                            const float *g_embsum, const float *g_resid, const float *g_loss,
+                            float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
+                            rqhip_stream_t stream);
+
 extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                                  int mode, float beta, const int64_t *ids, const float *g_embs,
                                  const float *g_embsum, const float *g_resid, const float *g_loss,
                                  float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
                                  rqhip_stream_t stream) {
+    // (bench only: one profile record for all kernels of the call; algorithmic bytes 12 D + 8 L per row)
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    profile_begin(s, RQHIP_PROF_RQ_BACKWARD, (double)B * L * 3.0 * D, (double)B * (12.0 * D + 8.0 * L));
+    const int rc = rq_backward_impl(res0, B, D, codebooks, L, K, mode, beta, ids, g_embs, g_embsum, g_resid, g_loss, g_res0,
+                                    g_codebooks, workspace, workspace_bytes, stream);
+    profile_end(s);
+    return rc;
+}
+
+static int rq_backward_impl(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                            int mode, float beta, const int64_t *ids, const float *g_embs,
+                            const float *g_embsum, const float *g_resid, const float *g_loss,
+                            float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
+                            rqhip_stream_t stream) {
     if (B < 0 || !codebooks || (B > 0 && (!res0 || !ids))) {
         set_error("rq_backward: null pointer or negative B");
         return RQHIP_EARG;

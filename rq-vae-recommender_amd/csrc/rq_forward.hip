@@ -271,10 +271,17 @@ __device__ __forceinline__ void bf16_split2(float a, float b, rq_bf16x2 &hi, rq_
 //   |d_k - (xsq + csq_k - 2 x.c_k)| <= 2^-18 |x||c_k| + 3 * 2^-24 (xsq + csq_k)          (the oracle's own roundings)
 //   two codes, distance units:  gap needed  <= 1.773e-4 |x| max|c| + 1.08e-6 (xsq + max csq)
 //   threshold used (distance units)          2^-12    |x| max|c| + 2^-19   (xsq + max csq)     headroom 1.38 / 1.77
-constexpr float kFiltC1 = 2.44140625e-4f;       // 2^-12, distance units
+// The numbers above are D = 32's (3 D + 3 = 99 accumulation steps).  At D = 64 (195 steps) the derived bound is 2.313e-4
+// |x| max|c|, which 2^-12 would cover with 6 % to spare -- and that margin rests on the hardware assumption (H) of DESIGN.md
+// 4.1 (at most 2^-23 relative error per accumulation step, measured on a few operand sets by tests/test_gpu_filter_bound.py).
+// D = 64 therefore uses 2^-11 (headroom 2.1: a few more rows re-decided exactly, never a wrong id).
+constexpr float kFiltC1 = 2.44140625e-4f;       // 2^-12, distance units (D = 32)
+constexpr float kFiltC1D64 = 4.8828125e-4f;     // 2^-11 (D = 64)
 constexpr float kFiltC2 = 1.9073486328125e-6f;  // 2^-19
+template <int KSTEPS>
 __device__ __forceinline__ float filt_threshold(float xsq, float csqmax) {
-    return (0.5f * kFiltC1) * __builtin_sqrtf(xsq * csqmax) + (0.5f * kFiltC2) * (xsq + csqmax);
+    constexpr float c1 = KSTEPS > 16 ? kFiltC1D64 : kFiltC1;
+    return (0.5f * c1) * __builtin_sqrtf(xsq * csqmax) + (0.5f * kFiltC2) * (xsq + csqmax);
 }
 
 template <int KSTEPS, int NT>
@@ -917,7 +924,7 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                 // Too close to call?  best / second are scores; Th is half the distance-gap bound (filt_threshold).  Rows of
                 // vanishing magnitude (the bound's sqrt underflows; bf16 pieces may be flushed) and any NaN go exact too.
                 const float scale2 = xsq * csqmax_l;
-                const float Th = filt_threshold(xsq, csqmax_l);
+                const float Th = filt_threshold<KSTEPS>(xsq, csqmax_l);
                 full_scan = bad || !(scale2 > 1.0e-30f) || COOP;
 #ifndef RQ_FILT_NOSLOW   // (developer timing build, tools/ab_build.sh: how fast is the scan without its exact re-checks?)
                 const bool close = !((best - second) > Th);
@@ -1226,7 +1233,8 @@ static int launch_mode(const RqFwdParams &p, int mode, int grid, size_t lds, uns
         // path and out of hipGraph captures); the limit only ever grows
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kLdsBudget));
-        profile_begin(s);
+        // (bench only; the launch covers every level: SURVEY 8d's per-row figures x B)
+        profile_begin(s, RQHIP_PROF_RQ_FORWARD, (double)p.B * p.L * (2.0 * p.D * p.K + 5.0 * p.D), (double)p.B * (8.0 * p.D + 12.0 * p.L + 4.0));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
         profile_end(s);
         RQ_CHECK_LAUNCH("rq_forward_kernel");
@@ -1307,6 +1315,11 @@ extern "C" int rqhip_filter_scores(const float *x, int64_t B, int D, const float
     else hipLaunchKernelGGL(filter_scores_kernel<32>, dim3(grid), dim3(64), 0, s, x, (long long)B, codebook, csq, K, scores);
     RQ_CHECK_LAUNCH("filter_scores_kernel");
     return RQHIP_OK;
+}
+
+extern "C" void rqhip_filter_bound_d(int D, float *c1, float *c2) {
+    if (c1) *c1 = D > 32 ? kFiltC1D64 : kFiltC1;
+    if (c2) *c2 = kFiltC2;
 }
 
 extern "C" void rqhip_filter_bound(float *c1, float *c2) {

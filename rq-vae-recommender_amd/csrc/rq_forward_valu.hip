@@ -233,7 +233,7 @@ int launch_rq_forward_valu(const float *res0, int64_t B, int D, const float *cod
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
-        profile_begin(s);
+        profile_begin(s, RQHIP_PROF_RQ_FORWARD, (double)p.B * p.L * (2.0 * kValuD * p.K + 5.0 * kValuD), (double)p.B * (8.0 * kValuD + 12.0 * p.L + 4.0));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, s, p);
         profile_end(s);
         RQ_CHECK_LAUNCH("rq_forward_valu_kernel");

@@ -58,7 +58,8 @@ struct LdsGrant {
 };
 
 // bench-only kernel timing (capi.hip); no-ops unless rqhip_profile_enable(n > 0) was called
-void profile_begin(hipStream_t s);
+// (tag: RQHIP_PROF_*; flops / bytes: the ALGORITHMIC work of what is bracketed -- bench.py prices them against the rooflines)
+void profile_begin(hipStream_t s, int tag, double flops, double bytes);
 void profile_end(hipStream_t s);
 
 // Fill `bytes` (a multiple of 4) at `dst` (4-byte aligned) with the 32-bit pattern `word`, as a KERNEL on stream s.

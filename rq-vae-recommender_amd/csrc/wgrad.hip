@@ -277,7 +277,7 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
 
 int wgrad_split_cfg(int N, int K);   // wgrad_split.hip
 int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
-                       int nslab_n, int nslab_k, int msplit, hipStream_t s);
+                       int nslab_n, int nslab_k, int msplit, const unsigned *g_max, const unsigned *x_max, hipStream_t s);
 
 }  // namespace rqhip
 
@@ -316,9 +316,29 @@ extern "C" int rqhip_linear_wgrad(const float *g, const float *y, const float *x
     return rqhip_linear_wgrad_ex(g, y, x, M, N, K, g_masked, dW, workspace, workspace_bytes, 0u, stream);
 }
 
+static int linear_wgrad_impl(const float *g, const float *y, const float *x, int64_t M, int N, int K, float *g_masked, float *dW,
+                             void *workspace, size_t workspace_bytes, unsigned flags, const unsigned *g_col_max,
+                             const unsigned *x_col_max, rqhip_stream_t stream);
+
 extern "C" int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                                      float *g_masked, float *dW, void *workspace, size_t workspace_bytes,
                                      unsigned flags, rqhip_stream_t stream) {
+    return linear_wgrad_impl(g, y, x, M, N, K, g_masked, dW, workspace, workspace_bytes, flags, nullptr, nullptr, stream);
+}
+
+extern "C" int rqhip_linear_wgrad_f16(const float *g, const float *y, const float *x, int64_t M, int N, int K,
+                                      const unsigned *g_col_max, const unsigned *x_col_max, float *g_masked, float *dW,
+                                      void *workspace, size_t workspace_bytes, rqhip_stream_t stream) {
+    if (M > 0 && (!g_col_max || !x_col_max)) {
+        set_error("linear_wgrad_f16: the column maxima of g and x are required (rqhip_maxima or an epilogue's c_col_max)");
+        return RQHIP_EARG;
+    }
+    return linear_wgrad_impl(g, y, x, M, N, K, g_masked, dW, workspace, workspace_bytes, 0u, g_col_max, x_col_max, stream);
+}
+
+static int linear_wgrad_impl(const float *g, const float *y, const float *x, int64_t M, int N, int K, float *g_masked, float *dW,
+                             void *workspace, size_t workspace_bytes, unsigned flags, const unsigned *g_col_max,
+                             const unsigned *x_col_max, rqhip_stream_t stream) {
     if (flags & ~RQHIP_WGRAD_FP32) {
         set_error("linear_wgrad: unknown flags 0x%x", flags);
         return RQHIP_EARG;
@@ -357,8 +377,11 @@ extern "C" int rqhip_linear_wgrad_ex(const float *g, const float *y, const float
     int rc = 0;
     // large layers: the six-term bf16-split kernel (wgrad_split.hip) unless the oracle-exact fp32 kernel is asked for
     const int scfg = (flags & RQHIP_WGRAD_FP32) ? -1 : wgrad_split_cfg(N, K);
+    // (bench only: one profile record for the kernel and its partial-sum reduction; algorithmic work 2 M N K FLOP, bytes: g, x
+    // (and y) once, g_pre once when it is written back)
+    profile_begin(s, RQHIP_PROF_WGRAD, 2.0 * (double)M * N * K, 4.0 * (double)M * (N * (1 + (y ? 1 : 0) + (g_masked && y ? 1 : 0)) + K));
     if (scfg >= 0 && scfg == pl.cfg) {
-        rc = launch_wgrad_split(scfg, g, y, x, M, N, K, g_masked, p.out, pl.nslab_n, pl.nslab_k, pl.msplit, s);
+        rc = launch_wgrad_split(scfg, g, y, x, M, N, K, g_masked, p.out, pl.nslab_n, pl.nslab_k, pl.msplit, g_col_max, x_col_max, s);
     } else
     switch (pl.cfg) {
         case 0: rc = wgrad_launch<4, 2, 2, 4, 32>(p, pl, mask, s); break;
@@ -367,7 +390,7 @@ extern "C" int rqhip_linear_wgrad_ex(const float *g, const float *y, const float
         case 3: rc = wgrad_launch<1, 1, 1, 4, 64>(p, pl, mask, s); break;
         default: rc = wgrad_launch<1, 1, 4, 1, 64>(p, pl, mask, s); break;
     }
-    if (rc) return rc;
+    if (rc) { profile_end(s); return rc; }
     if (pl.msplit > 1) {
         const size_t nk4 = (size_t)N * K / 4;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + kRedElems - 1) / kRedElems)), dim3(256),
@@ -375,5 +398,6 @@ extern "C" int rqhip_linear_wgrad_ex(const float *g, const float *y, const float
                            pl.msplit, pl.pow2, nk4, dW);
         RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
     }
+    profile_end(s);
     return RQHIP_OK;
 }

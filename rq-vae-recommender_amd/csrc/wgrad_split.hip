@@ -13,6 +13,12 @@
 // tolerance (tests/test_gpu_wgrad.py: no less exact than the library's fp32 GEMM), not bit for bit.
 // RQHIP_WGRAD_FP32 (rqhip_linear_wgrad_ex) keeps wgrad.hip's oracle-exact kernel.
 //
+// Round 4, the product path (NP = 2, rqhip_linear_wgrad_f16): TWO fp16 pieces per operand and the three products hh + hm + mh
+// (csrc/gemm_split.hip, RQHIP_SPLIT_F16X2).  The reduction runs over the batch rows, so the exact power-of-two scale has to be
+// constant along them: every COLUMN of g_pre and of x is multiplied by 2^-e, e = exponent of the column's largest |value| (from
+// the epilogue that wrote the matrix, or rqhip_maxima), and dW[n, k] is multiplied back by 2^(e_n + e_k).  Half the matrix
+// instructions, two thirds of the LDS bytes; error against fp64 below the three-piece kernel's (tests/test_gpu_wgrad.py).
+//
 // Mapping
 //   * A = g_pre^T (32 n x 16 m), B = x (16 m x 32 k): a lane's operand is EIGHT CONSECUTIVE ROWS of one column, so the
 //     rows are transposed on the way into LDS: a staging thread takes 4 rows x 4 columns (four 16-byte loads per tensor,
@@ -35,10 +41,6 @@ typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned ws_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWsRows = 16;   // rows per LDS stage = one K step of the matrix instruction
-#ifndef WS_F16   // 1 (developer builds; PROTOTYPE, not run on a GPU yet): two fp16 pieces per operand and the three products
-#define WS_F16 0 // hh + hm + mh, every COLUMN of g_pre and of x scaled by an exact power of two (the reduction runs over the rows, so
-#endif           // the scale must be constant along them) -- csrc/gemm_split.hip GS_F16, DESIGN.md section 9, tools/fp16_split_study.py
-constexpr int kWsNP = WS_F16 ? 2 : 3;   // pieces per operand
 
 struct WgradSplitParams {
     const float *g, *y, *x;
@@ -47,9 +49,7 @@ struct WgradSplitParams {
     int N, K;
     int nslab_n, nslab_k, msplit;
     long long n_chunks;   // ceil(M / 32): the row ranges are cut on wgrad.hip's 32-row granules
-#if WS_F16
-    const unsigned *g_max, *x_max;   // [N], [K] bit patterns of the columns' largest |value| (col_maxima_kernel / an epilogue), or nullptr
-#endif
+    const unsigned *g_max, *x_max;   // NP == 2: [N], [K] bit patterns of the columns' largest |value| (rqhip_maxima / an epilogue)
 };
 
 // (a, b) -> three dwords, each the packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
@@ -64,7 +64,6 @@ __device__ __forceinline__ void ws_split2(float a, float b, unsigned &h, unsigne
     l = __builtin_bit_cast(unsigned, ll);
 }
 
-#if WS_F16
 typedef _Float16 ws_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ws_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ws_split2_f16(float a, float b, unsigned &h, unsigned &m) {
@@ -79,28 +78,9 @@ __device__ __forceinline__ int ws_exp_of_bits(unsigned b) {   // floor(log2) of 
     const int e = (int)(b >> 23);
     return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127);
 }
-// mx[c] = max over the rows of |A[m, c]| as bit patterns (unsigned atomic max: the result does not depend on the order); mx zeroed
-// by the caller.  256 threads: 64 columns x 4 row lanes; a block takes 1024 rows of one 64-column strip.
-__global__ __launch_bounds__(256) void col_maxima_kernel(const float *__restrict__ A, long long M, int Cn, unsigned *__restrict__ mx) {
-    const int strips = (Cn + 63) / 64;
-    const int strip = blockIdx.x % strips;
-    const long long r0 = (long long)(blockIdx.x / strips) * 1024;
-    const int c = strip * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    float m = 0.0f;
-    if (c < Cn)
-        for (long long r = r0 + rl; r < M && r < r0 + 1024; r += 4) m = fmaxf(m, fabsf(A[(size_t)r * Cn + c]));
-    __shared__ float red[4][64];
-    red[rl][threadIdx.x & 63] = m;
-    __syncthreads();
-    if (rl == 0 && c < Cn) {
-        m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
-        atomicMax(mx + c, __builtin_bit_cast(unsigned, m));
-    }
-}
-#endif
 
-// TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given
-template <int TA, int TB, int WA, int WB, bool MASK>
+// TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given; NP: pieces per operand (3 bf16 / 2 fp16 under column scales)
+template <int TA, int TB, int WA, int WB, bool MASK, int NP>
 __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSplitParams p) {
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB, NT = 64 * WA * WB;
     constexpr int UNITS = Nt + Kt;                 // staging units of 4 rows x 4 columns per stage: Nt for g, Kt for x
@@ -111,7 +91,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     // ds_write_b64 -- 1.7 us of the 3.2 us a stage took); the 16 lanes an operand read serves per cycle (columns
     // c0 .. c0 + 15) hit positions g * S + q0 .. q0 + 3, g < 4: distinct modulo 16 because S = 4 (mod 16).
     constexpr int SG = Nt / 4 + 4, SX = Kt / 4 + 4;
-    constexpr int PART_G = kWsNP * 2 * 4 * SG * 4, PART_X = kWsNP * 2 * 4 * SX * 4;   // dwords
+    constexpr int PART_G = NP * 2 * 4 * SG * 4, PART_X = NP * 2 * 4 * SX * 4;   // dwords
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(ws_smem);      // [2][PART_G + PART_X]
 
@@ -145,10 +125,9 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
     ws_f32x4 rv[UQ][4], ry[MASK ? UQ : 1][4];
-#if WS_F16
-    int ue[UQ][4];   // exponents of the four columns of each of this thread's staging units
+    int ue[NP == 2 ? UQ : 1][4];   // NP == 2: exponents of the four columns of each of this thread's staging units
 #pragma unroll
-    for (int q = 0; q < UQ; ++q) {
+    for (int q = 0; q < (NP == 2 ? UQ : 0); ++q) {
         const int u = tid + q * NT;
         const bool isg = u < Nt;
         const int idx = isg ? u : u - Nt, W = isg ? Nt : Kt;
@@ -159,7 +138,6 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         for (int cc = 0; cc < 4; ++cc)
             ue[q][cc] = (mxp && ((UNITS % NT == 0) || u < UNITS)) ? ws_exp_of_bits(mxp[c0 + 4 * cq + cc]) : 0;
     }
-#endif
     auto fetch = [&](long long stage) {
         const long long row0 = r_begin + stage * kWsRows;
 #pragma unroll
@@ -213,19 +191,18 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             const int oct = rq >> 1, half = rq & 1, S4 = 4 * (isg ? SG : SX);
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                unsigned h01, m01, l01, h23, m23, l23;
-#if WS_F16
-                ws_split2_f16(ldexpf(rv[q][0][cc], -ue[q][cc]), ldexpf(rv[q][1][cc], -ue[q][cc]), h01, m01);
-                ws_split2_f16(ldexpf(rv[q][2][cc], -ue[q][cc]), ldexpf(rv[q][3][cc], -ue[q][cc]), h23, m23);
-                l01 = l23 = 0u;
-#else
-                ws_split2(rv[q][0][cc], rv[q][1][cc], h01, m01, l01);
-                ws_split2(rv[q][2][cc], rv[q][3][cc], h23, m23, l23);
-#endif
+                unsigned h01, m01, l01 = 0u, h23, m23, l23 = 0u;
+                if constexpr (NP == 2) {
+                    ws_split2_f16(ldexpf(rv[q][0][cc], -ue[q][cc]), ldexpf(rv[q][1][cc], -ue[q][cc]), h01, m01);
+                    ws_split2_f16(ldexpf(rv[q][2][cc], -ue[q][cc]), ldexpf(rv[q][3][cc], -ue[q][cc]), h23, m23);
+                } else {
+                    ws_split2(rv[q][0][cc], rv[q][1][cc], h01, m01, l01);
+                    ws_split2(rv[q][2][cc], rv[q][3][cc], h23, m23, l23);
+                }
                 const int pos = cc * (S4 / 4) + cq;      // column 4 cq + cc
                 *reinterpret_cast<ws_u32x2 *>(part + ((0 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{h01, h23};
                 *reinterpret_cast<ws_u32x2 *>(part + ((1 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{m01, m23};
-                if (kWsNP == 3) *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{l01, l23};
+                if (NP == 3) *reinterpret_cast<ws_u32x2 *>(part + ((2 * 2 + oct) * S4 + pos) * 4 + 2 * half) = ws_u32x2{l01, l23};
             }
         }
     };
@@ -247,16 +224,16 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     auto multiply = [&](int buf) {
         const ws_bf16x8 *gA = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X));
         const ws_bf16x8 *xB = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X) + PART_G);
-        ws_bf16x8 a[TA][kWsNP], b[TB][kWsNP];
+        ws_bf16x8 a[TA][NP], b[TB][NP];
 #pragma unroll
         for (int t = 0; t < TA; ++t)
 #pragma unroll
-            for (int pc = 0; pc < kWsNP; ++pc)
+            for (int pc = 0; pc < NP; ++pc)
                 a[t][pc] = gA[(pc * 2 + h) * (4 * SG) + (il & 3) * SG + ((wa * 32 * TA + 32 * t + il) >> 2)];
 #pragma unroll
         for (int u = 0; u < TB; ++u)
 #pragma unroll
-            for (int pc = 0; pc < kWsNP; ++pc)
+            for (int pc = 0; pc < NP; ++pc)
                 b[u][pc] = xB[(pc * 2 + h) * (4 * SX) + (il & 3) * SX + ((wb * 32 * TB + 32 * u + il) >> 2)];
         // smallest products first (their sum is formed before it meets the large ones)
 #pragma unroll
@@ -264,18 +241,18 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 ws_f32x16 c16 = acc[t][u];
-#if WS_F16
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][1]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // m h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][1]), c16, 0, 0, 0);   // h m
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // h h
-#else
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][1], c16, 0, 0, 0);   // m m
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[u][0], c16, 0, 0, 0);   // l h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][2], c16, 0, 0, 0);   // h l
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][0], c16, 0, 0, 0);   // m h
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][1], c16, 0, 0, 0);   // h m
-                c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][0], c16, 0, 0, 0);   // h h
-#endif
+                if constexpr (NP == 2) {
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][1]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // m h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][1]), c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // h h
+                } else {
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][1], c16, 0, 0, 0);   // m m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][NP - 1], b[u][0], c16, 0, 0, 0);   // l h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][NP - 1], c16, 0, 0, 0);   // h l
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[u][0], c16, 0, 0, 0);   // m h
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][1], c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[u][0], c16, 0, 0, 0);   // h h
+                }
                 acc[t][u] = c16;
             }
     };
@@ -303,14 +280,12 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-#if WS_F16
-                {   // undo the column scales (exact)
+                if constexpr (NP == 2) {   // undo the column scales (exact)
                     const int k = k0 + wb * 32 * TB + 32 * u + il;
                     const int e = (p.g_max ? ws_exp_of_bits(p.g_max[n]) : 0) + (p.x_max ? ws_exp_of_bits(p.x_max[k]) : 0);
                     dst[(size_t)n * p.K + k] = ldexpf(acc[t][u][r], e);
                     continue;
                 }
-#endif
                 dst[(size_t)n * p.K + k0 + wb * 32 * TB + 32 * u + il] = acc[t][u][r];
             }
 }
@@ -323,10 +298,10 @@ int wgrad_split_cfg(int N, int K) {
     return -1;
 }
 
-template <int TA, int TB, int WA, int WB>
+template <int TA, int TB, int WA, int WB, int NP>
 static int wgrad_split_go(const WgradSplitParams &p, bool mask, hipStream_t s) {
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB;
-    const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * kWsNP * 2 * 16;
+    const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * NP * 2 * 16;
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
@@ -334,46 +309,32 @@ static int wgrad_split_go(const WgradSplitParams &p, bool mask, hipStream_t s) {
         RQ_CHECK_LAUNCH("wgrad_split_kernel");
         return 0;
     };
-    return mask ? go(wgrad_split_kernel<TA, TB, WA, WB, true>) : go(wgrad_split_kernel<TA, TB, WA, WB, false>);
+    return mask ? go(wgrad_split_kernel<TA, TB, WA, WB, true, NP>) : go(wgrad_split_kernel<TA, TB, WA, WB, false, NP>);
 }
 
-#if WS_F16
-static const unsigned *g_ws_g_max = nullptr, *g_ws_x_max = nullptr;   // (prototype plumbing: the column maxima of the next launch)
-#endif
-// called by rqhip_linear_wgrad_ex (wgrad.hip), which owns the plan (row ranges, workspace) and the reduce kernel
+// called by rqhip_linear_wgrad_ex / rqhip_linear_wgrad_f16 (wgrad.hip), which own the plan (row ranges, workspace) and the
+// reduce kernel.  g_max / x_max: the column maxima of the fp16 path (both non-null), or nullptr for the three-piece bf16 path.
 int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
-                       int nslab_n, int nslab_k, int msplit, hipStream_t s) {
+                       int nslab_n, int nslab_k, int msplit, const unsigned *g_max, const unsigned *x_max, hipStream_t s) {
     WgradSplitParams p;
     p.g = g; p.y = y; p.x = x; p.gm = gm; p.out = out;
     p.M = M; p.N = N; p.K = K; p.nslab_n = nslab_n; p.nslab_k = nslab_k; p.msplit = msplit;
     p.n_chunks = (M + 31) / 32;
-#if WS_F16
-    p.g_max = g_ws_g_max;
-    p.x_max = g_ws_x_max;
-#endif
+    p.g_max = g_max;
+    p.x_max = x_max;
     const bool mask = y != nullptr;
+    if (g_max && x_max) {
+        switch (cfg) {
+            case 0: return wgrad_split_go<4, 2, 2, 4, 2>(p, mask, s);    // 256 x 256, 8 waves of 128 x 64
+            case 1: return wgrad_split_go<2, 2, 2, 4, 2>(p, mask, s);    // 128 x 256, 8 waves of 64 x 64
+            default: return wgrad_split_go<2, 2, 4, 2, 2>(p, mask, s);   // 256 x 128
+        }
+    }
     switch (cfg) {
-        case 0: return wgrad_split_go<4, 2, 2, 4>(p, mask, s);    // 256 x 256, 8 waves of 128 x 64
-        case 1: return wgrad_split_go<2, 2, 2, 4>(p, mask, s);    // 128 x 256, 8 waves of 64 x 64
-        default: return wgrad_split_go<2, 2, 4, 2>(p, mask, s);   // 256 x 128
+        case 0: return wgrad_split_go<4, 2, 2, 4, 3>(p, mask, s);
+        case 1: return wgrad_split_go<2, 2, 2, 4, 3>(p, mask, s);
+        default: return wgrad_split_go<2, 2, 4, 2, 3>(p, mask, s);
     }
 }
 
 }  // namespace rqhip
-
-#if WS_F16
-// column maxima (bit patterns, unsigned atomic max into a buffer the caller zeroed) of A [M, Cn]
-extern "C" int rqhip_col_maxima(const float *A, int64_t M, int Cn, unsigned *mx, rqhip_stream_t stream) {
-    if (M <= 0 || Cn <= 0 || !A || !mx) return RQHIP_EARG;
-    const int strips = (Cn + 63) / 64;
-    hipLaunchKernelGGL(rqhip::col_maxima_kernel, dim3((unsigned)(strips * ((M + 1023) / 1024))), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), A, (long long)M, Cn, mx);
-    return RQHIP_OK;
-}
-// the column maxima of g_pre and x for the NEXT rqhip_linear_wgrad(_ex) call on this thread (nullptr: unscaled)
-extern "C" int rqhip_wgrad_split_set_maxima(const unsigned *g_max, const unsigned *x_max) {
-    rqhip::g_ws_g_max = g_max;
-    rqhip::g_ws_x_max = x_max;
-    return RQHIP_OK;
-}
-#endif

@@ -1,13 +1,13 @@
 """Bias-free Linear+ReLU stack (API and state_dict keys of reference modules/encoder.py:7-38).
 
-The large encoder/decoder GEMMs (output or reduction width >= 256) run as six-term bf16-split products on the bf16 matrix
-cores (csrc/gemm_split.hip: fp32 operands as three exact bf16 pieces, fp32 accumulation; no less exact than the library's
-fp32 GEMM, tests/test_gpu_gemm_split.py); the rest stay library GEMMs on PyTorch-ROCm (fp32, `rqhip/tuning.py` picks the
-kernels), where every Linear that is followed by a ReLU runs as ONE hipBLASLt call with the ReLU in the GEMM epilogue
-(`torch._addmm_activation` with a zero bias) instead of a GEMM plus an elementwise pass over the activations:
--0.29 ms of a 6.1 ms step at 100 000 rows (`tools/relu_epilogue_probe.py`).  The op has no autograd formula, so
-`_LinearReLU` supplies the backward itself: the weight gradient WITH the ReLU mask fused is one hand-written kernel
-(`csrc/wgrad.hip`), the input gradient a library GEMM on the masked gradient it hands over.  Parameter names are `mlp.{0,2,4,...}.weight`, as in the reference, so checkpoints load in both
+On ROCm tensors the whole run of Linear (+ ReLU) layers is ONE autograd node (`_MLPStack`).  Its large GEMMs (output width a
+multiple of 256, batches of 4096 rows and more) run on the 16-bit matrix cores with fp32's accuracy (csrc/gemm_split.hip,
+csrc/wgrad_split.hip: two fp16 pieces per operand under exact power-of-two row / column scales, three piece products, fp32
+accumulation; no less exact than the library's fp32 GEMM, tests/test_gpu_gemm_split.py, tests/test_gpu_wgrad.py) with the
+ReLU, the ReLU backward and the reconstruction loss in their epilogues; the narrow layers stay library GEMMs on PyTorch-ROCm
+(fp32, `rqhip/tuning.py` picks the kernels), where a Linear followed by a ReLU is ONE hipBLASLt call with the ReLU in the
+GEMM epilogue (`torch._addmm_activation` with a zero bias).  Weight gradients: csrc/wgrad_split.hip / csrc/wgrad.hip
+(SURVEY section 8 row f2).  Parameter names are `mlp.{0,2,4,...}.weight`, as in the reference, so checkpoints load in both
 directions."""
 from typing import List
 
@@ -33,16 +33,10 @@ def _adopt(gw: Tensor, sink) -> Tensor:
     return gw.view_as(gw) if sink is not None else gw
 
 
-def _hip_wgrad_ok(g: Tensor, w: Tensor) -> bool:
-    return (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[0] > 0
-            and ops.linear_wgrad_supported(w.shape[0], w.shape[1]))
-
-
 class _LinearReLU(torch.autograd.Function):
-    """relu(x @ w.T) for 2-D fp32 ROCm tensors, ReLU fused into the GEMM epilogue.  Backward: the weight gradient and
-    the ReLU mask are ONE hand-written kernel (csrc/wgrad.hip), which also hands the masked gradient to the library
-    GEMM that forms the input gradient; shapes the kernel does not tile keep the three library kernels autograd
-    would run (mask, two GEMMs)."""
+    """relu(x @ w.T) for 2-D fp32 tensors, one layer (the registered operators, stacks with dropout, CPU): ReLU fused into the
+    GEMM epilogue; backward by rqhip/linear.py:backward -- weight gradient with the ReLU mask, data gradient on the masked
+    gradient it hands over; shapes no kernel tiles keep the three library kernels autograd would run (mask, two GEMMs)."""
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor, zero_bias: Tensor) -> Tensor:
@@ -55,17 +49,12 @@ class _LinearReLU(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         sink = _grad_sink(w) if need_w else None
-        if need_w and _hip_wgrad_ok(gy, w):
-            gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x, out=sink)
-        else:
-            g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
-            gw = (torch.mm(g.t(), x, out=sink) if sink is not None else g.t().mm(x)) if need_w else None
-        gx = _lin.input_grad(g, w) if need_x else None
+        gx, gw = _lin.backward(gy, y, x, w, need_x, need_w, sink)
         return gx, (_adopt(gw, sink) if need_w else None), None
 
 
 class _LinearPlain(torch.autograd.Function):
-    """x @ w.T (the last layer of each MLP: no ReLU), weight gradient by csrc/wgrad.hip."""
+    """x @ w.T (the last layer of each MLP: no ReLU), one layer."""
 
     @staticmethod
     def forward(ctx, x: Tensor, w: Tensor) -> Tensor:
@@ -76,57 +65,136 @@ class _LinearPlain(torch.autograd.Function):
     def backward(ctx, gy: Tensor):
         x, w = ctx.saved_tensors
         need_x, need_w = ctx.needs_input_grad
-        gw = None
-        if need_w:
-            # (round 2 kept the 768 x 512 layer with the library: 626 vs 600 us for the fp32-MFMA kernel without a mask to
-            # fuse; the bf16-split kernel of round 3 takes it: csrc/wgrad_split.hip)
-            sink = _grad_sink(w)
-            if _hip_wgrad_ok(gy, w):
-                gw = ops.linear_wgrad(gy, None, x, out=sink)[0]
-            else:
-                gw = torch.mm(gy.t(), x, out=sink) if sink is not None else gy.t().mm(x)
-            gw = _adopt(gw, sink)
-        gx = _lin.input_grad(gy, w) if need_x else None
-        return gx, gw
+        sink = _grad_sink(w) if need_w else None
+        gx, gw = _lin.backward(gy, None, x, w, need_x, need_w, sink)
+        return gx, (_adopt(gw, sink) if need_w else None)
 
 
-class _LinearRecon(torch.autograd.Function):
-    """reconstruction_loss(h @ w.T, x) per row (reference modules/rqvae.py:146,152 + modules/loss.py:5-10) with the LAST
-    decoder layer and the loss in ONE kernel (csrc/gemm_split.hip, epilogue 2): x_hat never reaches memory; the epilogue
-    reads x, sums the squared error of its row and writes the gradient the step is going to ask for, (2 (x_hat - x)) * s / B
-    (s: rqhip.autograd.loss_scale).  Backward compares the upstream rows with s / B on the device and rescales the rows
-    that differ (csrc/recon_loss.hip: recon_rescale_rows_kernel), then forms the two GEMM gradients from that matrix as
-    _LinearPlain does.  A second backward through a retained graph recomputes x_hat with the library."""
+class _MLPStack(torch.autograd.Function):
+    """A whole bias-free Linear(+ReLU) stack as ONE autograd node, optionally ending in the reconstruction loss
+    (reference modules/encoder.py:25-38; with `target`: modules/rqvae.py:146,152 + modules/loss.py:5-10, the last layer and
+    the loss in one kernel -- x_hat never reaches memory).  What the single node buys over one node per layer:
+      * the weight images of every forward and data-gradient GEMM of the stack are built by one launch when the forward
+        starts;
+      * the power-of-two scales of the fp16 split kernels travel with the data: every GEMM epilogue emits the row maxima
+        (for the GEMM that reads its output next) and the column maxima (for the weight-gradient kernel that does) of what
+        it stores, so the only maxima PASS of a training step is the one over the input batch;
+      * a data gradient applies the ReLU backward of the layer below in its epilogue (RQHIP_EPI_MASK), so the masked
+        gradient is written once, with its maxima, and the weight-gradient kernels read it unmasked.
+    Same kernels, maxima and therefore result bits as the per-layer Functions above (tests/test_gpu_modules.py).
+    forward(x, target, relus, zero_bias, *weights): relus[i] = layer i is followed by a ReLU; zero_bias(n, like) -> zeros
+    [n] for the library GEMM's fused-ReLU call.  Returns the last layer's output, or the loss rows [M] when target is given
+    (then the last layer has no ReLU and takes the split kernel: the caller checks)."""
 
     @staticmethod
-    def forward(ctx, h: Tensor, w: Tensor, x: Tensor) -> Tensor:
+    def forward(ctx, x: Tensor, target, relus, zero_bias, *weights):
+        from rqhip import _lib
         from rqhip import autograd as _ag
-        one = torch.tensor(1.0, dtype=torch.float32)   # fp32 (loss scale) * fp32 (1 / B), as ReconLossFunction
-        ctx.row_scale = float(torch.tensor(_ag._LOSS_SCALE, dtype=torch.float32) * (one / x.shape[0]))
-        g, rows = ops.gemm_split_recon(h, _lin.planes(w, False), w.shape[0], x, ctx.row_scale)
-        ctx.save_for_backward(h, w, x, g)
-        return rows
+        n, M = len(weights), x.shape[0]
+        need_w = [bool(f) for f in ctx.needs_input_grad[4:]]
+        need_in = [bool(ctx.needs_input_grad[0]) or any(need_w[:i]) for i in range(n)]   # gradient wrt layer i's input wanted
+        fwd_split = [_lin.split_shape_ok(M, w.shape[0], w.shape[1]) for w in weights]
+        dg_split = [need_in[i] and _lin.split_shape_ok(M, w.shape[1], w.shape[0]) for i, w in enumerate(weights)]
+        wg_f16 = [need_w[i] and _lin.wgrad_f16_ok(w.shape[0], w.shape[1]) for i, w in enumerate(weights)]
+        jobs = [(w, False) for i, w in enumerate(weights) if fwd_split[i]] + [(w, True) for i, w in enumerate(weights) if dg_split[i]]
+        imgs = iter(_lin.images(jobs))
+        img_f = [next(imgs) if fwd_split[i] else None for i in range(n)]
+        img_t = [next(imgs) if dg_split[i] else None for i in range(n)]
+        f16 = _lin.f16()
+        # column maxima the epilogues emit in this forward: of layer i's output when layer i + 1's weight gradient wants them
+        # (and of the reconstruction gradient for the last layer's own weight gradient) -- one zeroed arena
+        emit = [f16 and fwd_split[i] and ((i + 1 < n and wg_f16[i + 1]) or (i + 1 == n and target is not None and wg_f16[i]))
+                for i in range(n)]
+        arena = torch.zeros((sum(w.shape[0] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=x.device) if any(emit) else None
+        off = 0
+        acts, scs = [x], [_lin.Scales()]
+        if f16 and (fwd_split[0] or wg_f16[0]):   # the input batch: the one maxima pass of the step
+            _lin.ensure_scales(x, scs[0], fwd_split[0], wg_f16[0])
+        out = g_recon = g_scales = None
+        for i, w in enumerate(weights):
+            a, sc, last = acts[-1], scs[-1], i + 1 == n
+            col_out = None
+            if emit[i]:
+                col_out = arena[off:off + w.shape[0]]
+                off += w.shape[0]
+            if last and target is not None:
+                one = torch.tensor(1.0, dtype=torch.float32)   # fp32 (loss scale) * fp32 (1 / B), as ReconLossFunction
+                ctx.row_scale = float(torch.tensor(_ag._LOSS_SCALE, dtype=torch.float32) * (one / M))
+                g_recon, out, g_scales = _lin.gemm(a, img_f[i], w.shape[0], epilogue=_lib.EPI_RECON, aux=target,
+                                                   row_scale=ctx.row_scale, a_scales=sc, want_rows=dg_split[i], col_out=col_out)
+                break
+            if fwd_split[i]:
+                y, _, ysc = _lin.gemm(a, img_f[i], w.shape[0], epilogue=_lib.EPI_RELU if relus[i] else _lib.EPI_STORE,
+                                      a_scales=sc, want_rows=not last and fwd_split[i + 1], col_out=col_out)
+            else:
+                y, ysc = _lin.library_forward(a, w, relus[i], zero_bias(w.shape[0], a) if relus[i] else None), _lin.Scales()
+            acts.append(y)
+            scs.append(ysc)
+            out = y
+        # (the OUTPUT goes through save_for_backward: as a plain attribute it would close a reference cycle output -> node ->
+        # ctx -> output and keep the activations alive until the garbage collector runs; intermediates carry no grad_fn)
+        ctx.has_target = target is not None
+        ctx.save_for_backward(x, *weights, target if ctx.has_target else out)
+        ctx.acts_mid, ctx.scs, ctx.relus = (acts[1:] if ctx.has_target else acts[1:-1]), scs, tuple(relus)
+        ctx.img_t, ctx.dg_split, ctx.wg_f16, ctx.need_in, ctx.need_w = img_t, dg_split, wg_f16, need_in, need_w
+        ctx.g_recon, ctx.g_scales, ctx.consumed = g_recon, g_scales, False
+        return out
 
     @staticmethod
     def backward(ctx, g_out: Tensor):
-        h, w, x, g = ctx.saved_tensors
-        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        from rqhip import _lib
+        x, weights, tail = ctx.saved_tensors[0], ctx.saved_tensors[1:-1], ctx.saved_tensors[-1]
+        n = len(weights)
+        target = tail if ctx.has_target else None
+        acts = [x] + list(ctx.acts_mid) + ([] if ctx.has_target else [tail])
+        scs, relus, need_in, need_w = ctx.scs, ctx.relus, ctx.need_in, ctx.need_w
+        dg_split, wg_f16, f16 = ctx.dg_split, ctx.wg_f16, _lin.f16()
         g_out = g_out.contiguous()
-        if not getattr(ctx, "consumed", False):
+        if target is None:
+            g, gsc = g_out, _lin.Scales()
+        elif not ctx.consumed:
             ctx.consumed = True
-            g = ops.recon_rescale_rows(g, g_out, ctx.row_scale)        # in place; a no-op in a training step
-        else:
-            g = ops.recon_loss_backward(h.mm(w.t()), x, g_out, True, False)[0]
-        gw = None
-        if need_w:
-            sink = _grad_sink(w)
-            if _hip_wgrad_ok(g, w):
-                gw = ops.linear_wgrad(g, None, h, out=sink)[0]
+            gsc = ctx.g_scales       # rows whose upstream gradient is not the announced one are rescaled in place, maxima too
+            g = ops.recon_rescale_rows(ctx.g_recon, g_out, ctx.row_scale, gsc.rows, gsc.cols)
+        else:                        # a second backward through a retained graph: x_hat is recomputed with the library
+            g = ops.recon_loss_backward(acts[-1].mm(weights[-1].t()), target, g_out, True, False)[0]
+            gsc = _lin.Scales()
+        # column maxima the data-gradient epilogues emit: of the gradient wrt layer i - 1's output (masked) when that
+        # layer's weight gradient wants them
+        emit = [f16 and dg_split[i] and i > 0 and wg_f16[i - 1] for i in range(n)]
+        arena = torch.zeros((sum(w.shape[1] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=g.device) if any(emit) else None
+        off = 0
+        premasked = not relus[n - 1]      # is g already masked by this layer's ReLU (or is there none)?
+        gws = [None] * n
+        for i in range(n - 1, -1, -1):
+            w, a = weights[i], acts[i]
+            y = acts[i + 1] if (relus[i] and not premasked) else None
+            if need_w[i]:
+                sink = _grad_sink(w)
+                gw, g, gsc = _lin.weight_grad(g, y, a, w, out=sink, want_masked=need_in[i], g_scales=gsc, x_scales=scs[i],
+                                              premasked=premasked)
+                gws[i] = _adopt(gw, sink)
+            elif y is not None and need_in[i]:
+                g, gsc = torch.ops.aten.threshold_backward(g, y, 0.0), _lin.Scales()
+            if not need_in[i]:
+                g = None
+                break
+            lower_relu = i > 0 and relus[i - 1]
+            if dg_split[i]:
+                col_out = None
+                if emit[i]:
+                    col_out = arena[off:off + w.shape[1]]
+                    off += w.shape[1]
+                fuse = f16 and lower_relu              # the ReLU backward of the layer below in this GEMM's epilogue
+                g, _, gsc = _lin.gemm(g, ctx.img_t[i], w.shape[1], epilogue=_lib.EPI_MASK if fuse else _lib.EPI_STORE,
+                                      aux=a if fuse else None, a_scales=gsc,
+                                      want_rows=i > 0 and dg_split[i - 1] and (fuse or not lower_relu),
+                                      col_out=col_out if (fuse or not lower_relu) else None)
+                premasked = fuse or not lower_relu
             else:
-                gw = torch.mm(g.t(), h, out=sink) if sink is not None else g.t().mm(h)
-            gw = _adopt(gw, sink)
-        gh = _lin.input_grad(g, w) if need_h else None
-        return gh, gw, None
+                g, gsc = g.mm(w), _lin.Scales()
+                premasked = not lower_relu
+        return (g if ctx.needs_input_grad[0] else None), None, None, None, *gws
 
 
 class MLP(nn.Module):
@@ -159,9 +227,24 @@ class MLP(nn.Module):
         assert x.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {x.shape[-1]}"
         if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
             return self.mlp(x)
-        return self._run(x, list(self.mlp))
+        return self._run(x if x.is_contiguous() else x.contiguous(), list(self.mlp))
 
-    def _run(self, x: Tensor, layers) -> Tensor:
+    def _run(self, x: Tensor, layers, target: Tensor = None) -> Tensor:
+        if torch_ops.enabled():
+            return self._run_layerwise(x, layers)
+        # the leading run of bias-free Linear (+ ReLU) layers is one autograd node; what follows (Identity, L2 norm) is applied
+        # after it; a Dropout inside the run ends it (the rest goes layer by layer)
+        weights, relus, i = [], [], 0
+        while i < len(layers) and isinstance(layers[i], nn.Linear) and layers[i].bias is None:
+            relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+            weights.append(layers[i].weight)
+            relus.append(relu)
+            i += 2 if relu else 1
+        if weights:
+            x = _MLPStack.apply(x, target, tuple(relus), self._zero_bias, *weights)
+        return self._run_layerwise(x, layers[i:]) if i < len(layers) else x
+
+    def _run_layerwise(self, x: Tensor, layers) -> Tensor:
         as_ops = torch_ops.enabled()   # registered torch.library operators instead of the autograd Functions
         i = 0
         while i < len(layers):
@@ -180,12 +263,18 @@ class MLP(nn.Module):
         return x
 
     def reconstruction_rows(self, z: Tensor, target: Tensor):
-        """ReconstructionLoss(self(z), target) per row with the last layer and the loss fused (`_LinearRecon`), or None
-        when that kernel does not apply here (the caller then composes the two, as the reference does)."""
+        """ReconstructionLoss(self(z), target) per row with the last layer and the loss fused (`_MLPStack` with a target), or
+        None when that kernel does not apply here (the caller then composes the two, as the reference does).  The fused
+        epilogue writes the gradient matrix the backward is going to ask for, so it only runs when a backward can follow."""
         layers = list(self.mlp)
+        lin = [l for l in layers[:-1]]
         last = layers[-2] if len(layers) >= 2 else None
-        if not (isinstance(last, nn.Linear) and last.bias is None and isinstance(layers[-1], nn.Identity)
+        chain_ok = all((isinstance(l, nn.Linear) and l.bias is None) or isinstance(l, nn.ReLU) for l in lin) \
+            and not any(isinstance(a, nn.ReLU) and isinstance(b, nn.ReLU) for a, b in zip(lin, lin[1:]))
+        if not (isinstance(last, nn.Linear) and last.bias is None and isinstance(layers[-1], nn.Identity) and chain_ok
+                and isinstance(layers[0], nn.Linear)
                 and not torch_ops.enabled() and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32
+                and torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters()))
                 and target.is_cuda and target.dtype == torch.float32 and not target.requires_grad
                 and tuple(target.shape) == (z.shape[0], last.out_features) and target.is_contiguous()
                 and target.data_ptr() % 16 == 0
@@ -193,5 +282,4 @@ class MLP(nn.Module):
                 and _lin.split_shape_ok(z.shape[0], last.out_features, last.in_features)):
             return None
         assert z.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {z.shape[-1]}"
-        hdn = self._run(z, layers[:-2])
-        return _LinearRecon.apply(hdn if hdn.is_contiguous() else hdn.contiguous(), last.weight, target)
+        return self._run(z if z.is_contiguous() else z.contiguous(), layers[:-1], target)

@@ -20,6 +20,27 @@ MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
 # rqhip_rq_forward_ex flags (include/rqhip.h)
 FWD_SCAN_FP32, FWD_SCAN_VALU, FWD_NO_COOP_TAIL = 0x1, 0x2, 0x10
 WGRAD_FP32 = 0x1   # rqhip_linear_wgrad_ex
+SPLIT_F16X2, SPLIT_BF16X3 = 0, 1                       # arithmetic of the split GEMM kernels (include/rqhip.h)
+EPI_STORE, EPI_RELU, EPI_RECON, EPI_MASK = 0, 1, 2, 3  # rqhip_gemm_split_ex epilogues
+PROF_TAGS = {1: "rq_forward", 2: "rq_backward", 3: "gemm_split", 4: "wgrad", 5: "maxima", 6: "weight_images"}
+
+
+class ImageJob(C.Structure):          # rqhip_image_job
+    _fields_ = [("w", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("transpose", C.c_int), ("arith", C.c_int),
+                ("image", C.c_void_p), ("image_bytes", C.c_size_t)]
+
+
+class GemmArgs(C.Structure):          # rqhip_gemm_args
+    _fields_ = [("A", C.c_void_p), ("M", C.c_int64), ("R", C.c_int), ("image", C.c_void_p), ("Nc", C.c_int),
+                ("arith", C.c_int), ("epilogue", C.c_int), ("tile_rows", C.c_int), ("C", C.c_void_p), ("aux", C.c_void_p),
+                ("row_scale", C.c_float), ("loss_rows", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("a_row_max", C.c_void_p), ("a_row_parts", C.c_int),
+                ("c_row_max", C.c_void_p), ("c_col_max", C.c_void_p)]
+
+
+class ProfileRecord(C.Structure):     # rqhip_profile_record
+    _fields_ = [("tag", C.c_int), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
+
 
 # every symbol include/rqhip.h declares: (restype, argtypes)
 _i64, _int, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
@@ -33,6 +54,7 @@ SIGNATURES = {
     "rqhip_rq_forward_ex": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _sz, C.c_uint, _vp]),
     "rqhip_filter_bound": (None, [C.POINTER(_f32), C.POINTER(_f32)]),
+    "rqhip_filter_bound_d": (None, [_int, C.POINTER(_f32), C.POINTER(_f32)]),
     "rqhip_filter_scores": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _sz, _vp]),
     "rqhip_rq_backward_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "rqhip_rq_backward_plan": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
@@ -65,15 +87,23 @@ SIGNATURES = {
     "rqhip_linear_wgrad_workspace_bytes": (_sz, [_i64, _int, _int]),
     "rqhip_linear_wgrad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_linear_wgrad_ex": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, C.c_uint, _vp]),
+    "rqhip_linear_wgrad_f16": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_gemm_split_supported": (_int, [_int, _int]),
+    "rqhip_weight_image_bytes": (_sz, [_int, _int, _int]),
+    "rqhip_weight_images": (_int, [C.POINTER(ImageJob), _int, _vp]),
+    "rqhip_maxima": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp]),
+    "rqhip_gemm_split_ex": (_int, [C.POINTER(GemmArgs), _vp]),
     "rqhip_weight_planes_bytes": (_sz, [_int, _int]),
     "rqhip_weight_planes": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp]),
     "rqhip_gemm_split": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp]),
     "rqhip_gemm_split_recon_workspace_bytes": (_sz, [_i64, _int]),
     "rqhip_gemm_split_recon": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_recon_rescale_rows": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
+    "rqhip_recon_rescale_rows_ex": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _int, _vp, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
+    "rqhip_profile_select": (_int, [C.c_uint]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),
+    "rqhip_profile_read_tagged": (_int, [C.POINTER(ProfileRecord), _int, C.POINTER(_int)]),
 }
 
 

@@ -4,7 +4,8 @@ The reference drives `train_rqvae.train` with gin (train_rqvae.py:24, modules/ut
 config files use a small subset of gin's grammar, which is all this module understands:
 
     import a.b.c                      -> importlib.import_module (registers enum constants as a side effect)
-    include 'other.gin'               -> gin's include: parse that file first (path relative to the including file)
+    include 'other.gin'               -> gin's include: parse that file first (path relative to the working directory, as
+                                         gin does, else to the including file's directory or its parent)
     # comment
     scope.name = <python literal>     -> int / float / str / bool / None / list literals
     scope.name = %mod.path.Enum.MEMBER -> constants registered by @constants_from_enum
@@ -88,8 +89,15 @@ def parse_config(text: str, base_dir: str | None = None) -> None:
         if line.startswith("include "):
             import os
             inc = ast.literal_eval(line[len("include "):].strip())
-            parse_config_file(inc if os.path.isabs(inc) or base_dir is None or os.path.exists(inc)
-                              else os.path.join(base_dir, inc))
+            # gin resolves an include relative to the working directory; this parser also tries the including file's own
+            # directory and its parent (so `include 'configs/x.gin'` written for a launch from the package root resolves from
+            # anywhere) before it gives up with the list of what it tried
+            tried = [inc] if (os.path.isabs(inc) or base_dir is None) else \
+                [inc, os.path.join(base_dir, inc), os.path.join(os.path.dirname(base_dir), inc)]
+            found = next((t for t in tried if os.path.exists(t)), None)
+            if found is None:
+                raise FileNotFoundError(f"ginlite: line {lineno}: include {inc!r} not found (tried {tried})")
+            parse_config_file(found)
             continue
         if "=" not in line:
             raise ValueError(f"ginlite: line {lineno}: expected 'scope.name = value', got {raw!r}")

@@ -1,19 +1,29 @@
 """Kernel selection for the bias-free Linear(+ReLU) layers of the MLPs, shared by the autograd Functions of
 modules/encoder.py and the registered operators of rqhip/torch_ops.py (both must run the same kernels: the tests compare
-them bit for bit)."""
+them bit for bit).
+
+The large layers run on the 16-bit matrix cores with fp32's accuracy (csrc/gemm_split.hip, csrc/wgrad_split.hip).  Round 4's
+product arithmetic is `f16x2`: every row (column, for the weight gradients) is scaled by an exact power of two and split into
+two fp16 pieces, three piece products per product.  The scales are the maxima of the rows / columns of the operand, which the
+kernel that WROTE the operand emits from its epilogue (`Scales`, handed from layer to layer by modules/encoder.py:_MLPStack);
+a caller that has none gets them from one `ops.maxima` pass -- same maxima, same exponents, same result bits either way.
+`use_arith("bf16x3")` keeps round 3's three-piece bf16 kernels for A/B (bench.py --mlp split6)."""
+from typing import List, Optional, Tuple
+
 import torch
 from torch import Tensor
 
-from . import ops
+from . import _lib, ops
 
-# ---- the large activation GEMMs on the bf16 matrix cores (csrc/gemm_split.hip) ------------------------------------------
+# ---- the large activation GEMMs on the matrix cores (csrc/gemm_split.hip) -------------------------------------------------------
 # Measured at 100 000 rows against the tuned library fp32 GEMM of the same layer (tools/bench_gemm_split.py, and in the
-# step: profiles/r03_bench_kernel_stats_summary.txt): every supported forward and data gradient is faster -- the first
-# encoder layer's forward (768 -> 512 with the ReLU in the hipBLASLt epilogue) was a tie in isolation (456 vs 445-489 us)
-# but takes 626 us inside the step, where the chip runs at the clocks the other matrix kernels leave it.  Small batches
-# are launch-bound and stay with the library.
+# step: profiles/r04_*): every supported forward and data gradient is faster.  Small batches are launch-bound and stay with
+# the library.
 _SPLIT_MIN_ROWS = 4096
 _SPLIT_GEMMS = True
+_ARITH = ops.F16X2
+_FP32 = -1   # no split kernels at all: library fp32 GEMMs, fp32-MFMA weight gradients (round 2's step, bench.py --mlp library)
+_ARITH_NAMES = {"f16x2": ops.F16X2, "bf16x3": ops.BF16X3, "fp32": _FP32}
 
 
 def use_split_gemms(on: bool = True) -> bool:
@@ -24,10 +34,50 @@ def use_split_gemms(on: bool = True) -> bool:
     return before
 
 
+def use_arith(name: str) -> str:
+    """"f16x2" (two fp16 pieces under exact power-of-two scales, three products: the product path), "bf16x3" (round 3: three
+    bf16 pieces, six products) or "fp32" (round 2: library fp32 GEMMs and the oracle-ordered fp32-MFMA weight gradients).
+    Returns the previous setting's name."""
+    global _ARITH
+    before = arith_name()
+    _ARITH = _ARITH_NAMES[name]
+    return before
+
+
+def arith_name() -> str:
+    return next(k for k, v in _ARITH_NAMES.items() if v == _ARITH)
+
+
+def f16() -> bool:
+    return _ARITH == ops.F16X2
+
+
+class Scales:
+    """What the fp16 kernels need to know about an operand [M, N]: `rows` int32 [parts, M] (a row's largest |value| is the
+    maximum over the parts, bit patterns), `cols` int32 [N]; either may be missing (None) until someone needs it."""
+    __slots__ = ("rows", "cols")
+
+    def __init__(self, rows: Optional[Tensor] = None, cols: Optional[Tensor] = None):
+        self.rows, self.cols = rows, cols
+
+
+def ensure_scales(a: Tensor, sc: Optional[Scales], rows: bool, cols: bool) -> Scales:
+    """`sc` with the requested maxima present: what is missing is computed by ONE pass over `a` (rqhip_maxima)."""
+    sc = sc if sc is not None else Scales()
+    need_r, need_c = rows and sc.rows is None, cols and sc.cols is None
+    if need_r or need_c:
+        r, c, _ = ops.maxima(a, rows=need_r, cols=need_c)
+        if need_r:
+            sc.rows = r
+        if need_c:
+            sc.cols = c
+    return sc
+
+
 def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool = False) -> bool:
-    """Does this GEMM (x [M, n_red] against a weight image of n_cols columns) take the bf16-split kernel?"""
-    del forward_relu   # (round 3 excluded the first encoder layer's forward here; see the note above)
-    return bool(_SPLIT_GEMMS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    """Does this GEMM (x [M, n_red] against a weight image of n_cols columns) take the split kernel?"""
+    del forward_relu   # (round 3 excluded the first encoder layer's forward here)
+    return bool(_SPLIT_GEMMS and _ARITH != _FP32 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
                 and x.shape[0] >= _SPLIT_MIN_ROWS and x.is_contiguous() and _wide(n_cols)
                 and ops.gemm_split_supported(n_cols, n_red))
 
@@ -35,38 +85,112 @@ def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool = False) -> 
 def _wide(n_cols: int) -> bool:
     """Layers of 256 (mod 256) output columns only.  The kernel also has a 256 x 128 tile for 128 (mod 256) columns
     (csrc/gemm_split.hip, tested), but the layers that would take it are HBM-bound at these widths and the library is as
-    fast: 100 000 x 256 -> 128 forward 58 us vs 67, its data gradient 59 vs 56, 100 000 x 32 -> 128 24 vs 25 -- and every use
-    adds the 6 us image rebuild (round 3, tools/bench_gemm_split.py)."""
+    fast: 100 000 x 256 -> 128 forward 58 us vs 67, its data gradient 59 vs 56, 100 000 x 32 -> 128 24 vs 25 (round 3,
+    tools/bench_gemm_split.py)."""
     return n_cols % 256 == 0
 
 
 def split_shape_ok(rows: int, n_cols: int, n_red: int) -> bool:
     """`split_ok` for a contiguous fp32 ROCm operand of `rows` rows that does not exist yet."""
-    return bool(_SPLIT_GEMMS and rows >= _SPLIT_MIN_ROWS and _wide(n_cols) and ops.gemm_split_supported(n_cols, n_red))
+    return bool(_SPLIT_GEMMS and _ARITH != _FP32 and rows >= _SPLIT_MIN_ROWS and _wide(n_cols)
+                and ops.gemm_split_supported(n_cols, n_red))
+
+
+def wgrad_f16_ok(n_out: int, n_in: int) -> bool:
+    """Does the weight gradient of an [n_out, n_in] layer run on the fp16 split kernel (and therefore want column maxima)?
+    The shapes csrc/wgrad_split.hip tiles: both multiples of 128, one of them of 256."""
+    return bool(f16() and n_out % 128 == 0 and n_in % 128 == 0 and (n_out % 256 == 0 or n_in % 256 == 0))
+
+
+def images(jobs: List[Tuple[Tensor, bool]]) -> List[Tensor]:
+    """The weight images of `jobs` = [(w, transpose), ...] in the current arithmetic, one launch.  Rebuilt at EVERY forward:
+    a first version cached an image per `w._version` -- and trained on stale weights: the fused AdamW update (and any
+    `w.data` write) does not bump the version counter.  The images of an MLP's forward and data-gradient GEMMs are built
+    together when its forward starts (weights cannot change between a forward and its backward); inside a hipGraph capture
+    the build is part of the graph, as it has to be."""
+    return ops.weight_images([(w.detach(), tr) for w, tr in jobs], _ARITH)
 
 
 def planes(w: Tensor, transpose: bool) -> Tensor:
-    """The bf16-piece image of `w` (or of its transpose) for csrc/gemm_split.hip, rebuilt at EVERY use (one 6 us kernel).
-    A first version cached it per `w._version` -- and trained on stale weights: the fused AdamW update (and any
-    `w.data` write) does not bump the version counter.  Nothing cheaper than the rebuild is safe, and it is 0.1 % of the
-    GEMM it feeds; inside a hipGraph capture the rebuild is part of the graph, as it has to be."""
-    return ops.weight_planes(w.detach(), transpose=transpose)
+    return images([(w, transpose)])[0]
 
 
-def input_grad(g: Tensor, w: Tensor) -> Tensor:
-    """g [M, N] . w [N, K]: the bf16-split kernel with the image of w^T where it applies, else the library GEMM."""
+def gemm(a: Tensor, image: Tensor, n_cols: int, *, epilogue: int = _lib.EPI_STORE, aux: Optional[Tensor] = None,
+         row_scale: float = 0.0, a_scales: Optional[Scales] = None, want_rows: bool = False,
+         col_out: Optional[Tensor] = None):
+    """One split GEMM in the current arithmetic.  Returns (C, loss_rows, Scales of C): the row maxima of `a` come from
+    `a_scales` or from a pass; the Scales of C hold the row maxima when `want_rows` and `col_out` (a zeroed int32 [n_cols]
+    slice that receives the column maxima) when given -- both only in the f16x2 arithmetic (the bf16 path needs none)."""
+    rows_in = ensure_scales(a, a_scales, True, False).rows if f16() else None
+    c, loss_rows, crm = ops.gemm_split_ex(a, image, n_cols, arith=_ARITH, epilogue=epilogue, aux=aux, row_scale=row_scale,
+                                          a_row_max=rows_in, want_row_max=want_rows and f16(),
+                                          col_max_out=col_out if f16() else None)
+    return c, loss_rows, Scales(crm, col_out if f16() else None)
+
+
+def input_grad(g: Tensor, w: Tensor, *, g_scales: Optional[Scales] = None, image: Optional[Tensor] = None) -> Tensor:
+    """g [M, N] . w [N, K]: the split kernel with the image of w^T where it applies, else the library GEMM."""
     g = g if g.is_contiguous() else g.contiguous()
     if split_ok(g, w.shape[1], w.shape[0], False):
-        return ops.gemm_split(g, planes(w, True), w.shape[1])
+        return gemm(g, image if image is not None else planes(w, True), w.shape[1], a_scales=g_scales)[0]
     return g.mm(w)
 
 
 def forward(x: Tensor, w: Tensor, relu: bool, zero_bias: Tensor = None) -> Tensor:
-    """relu(x w^T) or x w^T for 2-D fp32 ROCm tensors: the bf16-split kernel where it applies, else the library GEMM (with
+    """relu(x w^T) or x w^T for 2-D fp32 ROCm tensors: the split kernel where it applies, else the library GEMM (with
     the ReLU in the hipBLASLt epilogue)."""
     if split_ok(x, w.shape[0], w.shape[1], relu):
-        return ops.gemm_split(x, planes(w, False), w.shape[0], relu=relu)
+        return gemm(x, planes(w, False), w.shape[0], epilogue=_lib.EPI_RELU if relu else _lib.EPI_STORE)[0]
+    return library_forward(x, w, relu, zero_bias)
+
+
+def library_forward(x: Tensor, w: Tensor, relu: bool, zero_bias: Tensor = None) -> Tensor:
     if relu:
         zb = zero_bias if zero_bias is not None else x.new_zeros((w.shape[0],))
         return torch._addmm_activation(zb, x, w.t())
     return x.mm(w.t())
+
+
+def hip_wgrad_ok(g: Tensor, w: Tensor) -> bool:
+    return bool(g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[0] > 0
+                and ops.linear_wgrad_supported(w.shape[0], w.shape[1]))
+
+
+def weight_grad(g: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, *, out: Optional[Tensor] = None,
+                want_masked: bool = True, g_scales: Optional[Scales] = None, x_scales: Optional[Scales] = None,
+                premasked: bool = False):
+    """(dW, g_pre, Scales of g_pre) of y = relu(x w^T) (y given) or y = x w^T (y None).  dW = g_pre^T x with
+    g_pre = g where y > 0 else 0; `premasked`: g already is g_pre (a data gradient whose epilogue applied this layer's ReLU
+    backward).  f16x2 arithmetic on the shapes csrc/wgrad_split.hip tiles: column scales of g_pre and x from `g_scales` /
+    `x_scales` or from passes (for an unmasked g with y, ONE pass masks, writes g_pre and takes its maxima); otherwise the
+    round-3 kernels (mask fused into the weight-gradient kernel).  Falls back to library GEMMs for shapes no kernel tiles."""
+    if not hip_wgrad_ok(g, w):
+        gp = g if (y is None or premasked) else torch.ops.aten.threshold_backward(g, y, 0.0)
+        gw = torch.mm(gp.t(), x, out=out) if out is not None else gp.t().mm(x)
+        return gw, gp, None
+    if premasked:
+        y = None
+    if wgrad_f16_ok(w.shape[0], w.shape[1]):
+        if y is not None:   # mask + maxima in one pass; the weight-gradient kernel then runs without a mask
+            r, c, g = ops.maxima(g, y, rows=want_masked, cols=True, write_masked=True)
+            g_scales = Scales(r, c)
+        else:
+            g_scales = ensure_scales(g, g_scales, False, True)
+        x_scales = ensure_scales(x, x_scales, False, True)
+        gw, _ = ops.linear_wgrad(g, None, x, out=out, g_col_max=g_scales.cols, x_col_max=x_scales.cols)
+        return gw, g, g_scales
+    gw, gp = ops.linear_wgrad(g, y, x, want_masked=want_masked, out=out, exact_fp32=_ARITH == _FP32)
+    return gw, gp, (g_scales if y is None else None)
+
+
+def backward(gy: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, need_x: bool, need_w: bool, sink: Optional[Tensor] = None):
+    """(gx, gw) of one layer, y = relu(x w^T) (y given) or x w^T (y None): the per-layer backward both the autograd Functions
+    and the registered operators run."""
+    gy = gy if gy.is_contiguous() else gy.contiguous()
+    g, gw, gs = gy, None, None
+    if need_w:
+        gw, g, gs = weight_grad(gy, y, x, w, out=sink, want_masked=need_x)
+    elif y is not None and need_x:
+        g = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0 (what autograd does for relu)
+    gx = input_grad(g, w, g_scales=gs) if need_x else None
+    return gx, gw

@@ -63,11 +63,12 @@ TIE_TAU = 1e-6  # rows with tie_margin below this are near-ties: another correct
 _SCAN_FLAGS = {"auto": 0, "fp32": _lib.FWD_SCAN_FP32, "valu": _lib.FWD_SCAN_VALU}
 
 
-def filter_bound():
-    """(c1, c2) of the filtered scan's too-close-to-call threshold (rqhip_filter_bound; host-side, no GPU needed)."""
+def filter_bound(D: int = 32):
+    """(c1, c2) of the filtered scan's too-close-to-call threshold at embedding width D (rqhip_filter_bound_d; host-side, no
+    GPU needed): c1 = 2^-12 at D = 32, 2^-11 at D = 64."""
     import ctypes as C
     c1, c2 = C.c_float(0), C.c_float(0)
-    _lib.lib().rqhip_filter_bound(C.byref(c1), C.byref(c2))
+    _lib.lib().rqhip_filter_bound_d(int(D), C.byref(c1), C.byref(c2))
     return c1.value, c2.value
 
 
@@ -379,6 +380,23 @@ def profile_read(cap: int = 4096):
     return [buf[i] for i in range(n.value)]
 
 
+def profile_select(*kinds: str) -> None:
+    """Record only launches of these kinds (names of _lib.PROF_TAGS); no argument = every kind."""
+    mask = 0
+    for k in kinds:
+        mask |= 1 << next(t for t, n in _lib.PROF_TAGS.items() if n == k)
+    check(_lib.lib().rqhip_profile_select(mask if kinds else 0xFFFFFFFF), "rqhip_profile_select")
+
+
+def profile_read_tagged(cap: int = 65536):
+    """Every record since the last read as (kind, ms, algorithmic flops, algorithmic bytes); kinds: _lib.PROF_TAGS."""
+    import ctypes as C
+    buf = (_lib.ProfileRecord * cap)()
+    n = C.c_int(0)
+    check(_lib.lib().rqhip_profile_read_tagged(buf, cap, C.byref(n)), "rqhip_profile_read_tagged")
+    return [(_lib.PROF_TAGS.get(buf[i].tag, str(buf[i].tag)), buf[i].ms, buf[i].flops, buf[i].bytes) for i in range(n.value)]
+
+
 def _rows(t: Tensor, name: str) -> Tensor:
     """[B,N] fp32 with unit column stride (row stride may exceed N: slices of a wider matrix are fine)."""
     if t.dtype != torch.float32 or t.dim() != 2:
@@ -482,20 +500,25 @@ def linear_wgrad_supported(n_out: int, n_in: int) -> bool:
 
 
 def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool = True, out: Optional[Tensor] = None,
-                 exact_fp32: bool = False):
-    """dW [N,K] = (g * (y > 0))^T x with the ReLU backward fused (rqhip_linear_wgrad); y None = layer without ReLU.
+                 exact_fp32: bool = False, g_col_max: Optional[Tensor] = None, x_col_max: Optional[Tensor] = None):
+    """dW [N,K] = (g * (y > 0))^T x with the ReLU backward fused (rqhip_linear_wgrad*); y None = layer without ReLU.
     Returns (dW, g_pre): g_pre = the masked gradient in a fresh tensor when `want_masked` and y is given (the input
     of the data-gradient GEMM that follows), g itself when there is no mask, None when not wanted.  `out`: a
     contiguous fp32 [N,K] tensor to receive dW (e.g. the parameter's slice of a flat gradient buffer).
-    exact_fp32: force the fp32-MFMA kernel with the oracle-restated summation order (RQHIP_WGRAD_FP32) where the default is
-    the bf16-split kernel (large layers)."""
-    _need_gpu(g, y, x)
+    g_col_max / x_col_max (int32 [N] / [K], `maxima`): the two-piece fp16 arithmetic under exact column scales
+    (rqhip_linear_wgrad_f16, the product path); without them the three-piece bf16 kernel of round 3.
+    exact_fp32: force the fp32-MFMA kernel with the oracle-restated summation order (RQHIP_WGRAD_FP32)."""
+    _need_gpu(g, y, x, g_col_max, x_col_max)
     g, x = _f32c(g, "g"), _f32c(x, "x")
     y = _f32c(y, "y")
     if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0] or (y is not None and y.shape != g.shape):
         raise RqHipError(f"linear_wgrad: shapes g {tuple(g.shape)}, x {tuple(x.shape)}")
     M, N = g.shape
     K = x.shape[1]
+    f16 = g_col_max is not None or x_col_max is not None
+    if f16 and (exact_fp32 or g_col_max is None or x_col_max is None or g_col_max.numel() != N or x_col_max.numel() != K
+                or g_col_max.dtype != torch.int32 or x_col_max.dtype != torch.int32):
+        raise RqHipError("linear_wgrad: the fp16 path needs BOTH column-maxima vectors (int32 [N] and [K]) and no exact_fp32")
     dev = g.device
     with torch.cuda.device(dev):
         l = _lib.lib()
@@ -505,9 +528,14 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
         wsb = l.rqhip_linear_wgrad_workspace_bytes(M, N, K)
         ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
         gm = torch.empty_like(g) if (want_masked and y is not None) else None
-        rc = l.rqhip_linear_wgrad_ex(_ptr(g), _ptr(y), _ptr(x), M, N, K, _ptr(gm), _ptr(dw), _ptr(ws), wsb,
-                                     _lib.WGRAD_FP32 if exact_fp32 else 0, _stream())
-        check(rc, "rqhip_linear_wgrad_ex")
+        if f16:
+            rc = l.rqhip_linear_wgrad_f16(_ptr(g), _ptr(y), _ptr(x), M, N, K, _ptr(g_col_max), _ptr(x_col_max), _ptr(gm),
+                                          _ptr(dw), _ptr(ws), wsb, _stream())
+            check(rc, "rqhip_linear_wgrad_f16")
+        else:
+            rc = l.rqhip_linear_wgrad_ex(_ptr(g), _ptr(y), _ptr(x), M, N, K, _ptr(gm), _ptr(dw), _ptr(ws), wsb,
+                                         _lib.WGRAD_FP32 if exact_fp32 else 0, _stream())
+            check(rc, "rqhip_linear_wgrad_ex")
     return dw, (g if y is None else gm)
 
 
@@ -515,62 +543,131 @@ def gemm_split_supported(n_cols: int, n_red: int) -> bool:
     return bool(_lib.lib().rqhip_gemm_split_supported(int(n_cols), int(n_red)))
 
 
-def weight_planes(w: Tensor, transpose: bool = False) -> Tensor:
-    """The bf16-piece image of a weight matrix for `gemm_split` (rqhip_weight_planes): of w [rows, cols] itself
-    (forward: C = A w^T) or of w^T (`transpose`: data gradient, C = A w).  Returns an opaque uint8 tensor."""
-    _need_gpu(w)
-    w = _f32c(w, "w")
-    rows, cols = w.shape
-    Nc, R = (cols, rows) if transpose else (rows, cols)
-    with torch.cuda.device(w.device):
-        l = _lib.lib()
-        nbytes = l.rqhip_weight_planes_bytes(Nc, R)
-        if nbytes == 0:
-            raise RqHipError(f"weight_planes: unsupported shape {tuple(w.shape)} (transpose={transpose})")
-        planes = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
-        check(l.rqhip_weight_planes(_ptr(w), rows, cols, int(transpose), _ptr(planes), nbytes, _stream()), "rqhip_weight_planes")
-    return planes
+F16X2, BF16X3 = _lib.SPLIT_F16X2, _lib.SPLIT_BF16X3
 
 
-def gemm_split(a: Tensor, planes: Tensor, n_cols: int, relu: bool = False, tile_rows: int = 0) -> Tensor:
-    """C [M, n_cols] = a [M, R] . image^T with the optional ReLU epilogue (rqhip_gemm_split)."""
-    _need_gpu(a, planes)
-    a = _f32c(a, "a")
+def weight_images(jobs, arith: int = F16X2):
+    """The split-GEMM images of several weight matrices in ONE launch (rqhip_weight_images): `jobs` = [(w, transpose), ...];
+    of w [rows, cols] itself (forward: C = A w^T) or of w^T (`transpose`: data gradient, C = A w).  Returns one opaque
+    uint8 tensor per job (views of a single allocation)."""
+    if not jobs:
+        return []
+    ws = [_f32c(w.detach(), "w") for w, _ in jobs]
+    dev = _need_gpu(*ws)
+    l = _lib.lib()
+    sizes = []
+    for w, (_, tr) in zip(ws, jobs):
+        rows, cols = w.shape
+        Nc, R = (cols, rows) if tr else (rows, cols)
+        nb = l.rqhip_weight_image_bytes(Nc, R, int(arith))
+        if nb == 0:
+            raise RqHipError(f"weight_images: unsupported shape {tuple(w.shape)} (transpose={bool(tr)})")
+        sizes.append((nb + 255) // 256 * 256)
+    with torch.cuda.device(dev):
+        arena = torch.empty((sum(sizes),), dtype=torch.uint8, device=dev)
+        arr = (_lib.ImageJob * len(jobs))()
+        images, off = [], 0
+        for i, (w, (_, tr), nb) in enumerate(zip(ws, jobs, sizes)):
+            img = arena[off:off + nb]
+            off += nb
+            arr[i].w, arr[i].rows, arr[i].cols = w.data_ptr(), w.shape[0], w.shape[1]
+            arr[i].transpose, arr[i].arith = int(bool(tr)), int(arith)
+            arr[i].image, arr[i].image_bytes = img.data_ptr(), nb
+            images.append(img)
+        check(l.rqhip_weight_images(arr, len(jobs), _stream()), "rqhip_weight_images")
+    return images
+
+
+def weight_planes(w: Tensor, transpose: bool = False, arith: int = BF16X3) -> Tensor:
+    """One image (`weight_images` with a single job; round 3's name and default arithmetic)."""
+    return weight_images([(w, transpose)], arith)[0]
+
+
+def maxima(a: Tensor, y: Optional[Tensor] = None, *, rows: bool = True, cols: bool = True, write_masked: bool = False):
+    """(row_max [1, M] or None, col_max [R] or None, masked or None): int32 tensors holding the bit patterns of the largest
+    |value| of every row / column of a [M, R] (rqhip_maxima) -- the exact power-of-two scales of the fp16 split kernels are
+    derived from them.  With y: of `a` masked by y > 0 (the ReLU backward), returned as `masked` when `write_masked`."""
+    _need_gpu(a, y)
+    a, y = _f32c(a, "a"), _f32c(y, "y")
     M, R = a.shape
+    if y is not None and y.shape != a.shape:
+        raise RqHipError(f"maxima: y is {tuple(y.shape)}, expected {tuple(a.shape)}")
     with torch.cuda.device(a.device):
+        rm = torch.empty((1, M), dtype=torch.int32, device=a.device) if rows else None
+        cm = torch.zeros((R,), dtype=torch.int32, device=a.device) if cols else None
+        out = torch.empty_like(a) if (write_masked and y is not None) else None
+        check(_lib.lib().rqhip_maxima(_ptr(a), _ptr(y), _ptr(out), M, R, _ptr(rm), _ptr(cm), _stream()), "rqhip_maxima")
+    return rm, cm, out
+
+
+def gemm_split_ex(a: Tensor, image: Tensor, n_cols: int, *, arith: int = F16X2, epilogue: int = _lib.EPI_STORE,
+                  aux: Optional[Tensor] = None, row_scale: float = 0.0, a_row_max: Optional[Tensor] = None,
+                  want_row_max: bool = False, col_max_out: Optional[Tensor] = None, tile_rows: int = 0):
+    """C [M, n_cols] = epilogue(a [M, R] . image^T) (rqhip_gemm_split_ex).  Returns (C, loss_rows or None, c_row_max or None):
+    loss_rows for EPI_RECON; c_row_max [column tiles, M] int32 when `want_row_max`; `col_max_out` (int32 [n_cols], ZEROED by
+    the caller, or a slice of a zeroed arena) receives the column maxima of C.  arith F16X2 needs `a_row_max` [parts, M]."""
+    _need_gpu(a, image, aux, a_row_max, col_max_out)
+    a, aux = _f32c(a, "a"), _f32c(aux, "aux")
+    M, R = a.shape
+    if aux is not None and tuple(aux.shape) != (M, n_cols):
+        raise RqHipError(f"gemm_split: aux is {tuple(aux.shape)}, expected {(M, n_cols)}")
+    if a_row_max is not None and (a_row_max.dtype != torch.int32 or a_row_max.dim() != 2 or a_row_max.shape[1] != M
+                                  or not a_row_max.is_contiguous()):
+        raise RqHipError("gemm_split: a_row_max must be a contiguous int32 [parts, M] tensor")
+    if col_max_out is not None and (col_max_out.dtype != torch.int32 or col_max_out.numel() != n_cols
+                                    or not col_max_out.is_contiguous()):
+        raise RqHipError("gemm_split: col_max_out must be a contiguous int32 [n_cols] tensor")
+    with torch.cuda.device(a.device):
+        l = _lib.lib()
         c = torch.empty((M, n_cols), dtype=torch.float32, device=a.device)
-        check(_lib.lib().rqhip_gemm_split(_ptr(a), M, R, _ptr(planes), int(n_cols), int(relu) | (int(tile_rows) << 8), _ptr(c),
-                                          _stream()),
-              "rqhip_gemm_split")
-    return c
+        args = _lib.GemmArgs()
+        args.A, args.M, args.R, args.image, args.Nc = a.data_ptr(), M, R, image.data_ptr(), int(n_cols)
+        args.arith, args.epilogue, args.tile_rows, args.C = int(arith), int(epilogue), int(tile_rows), c.data_ptr()
+        args.aux, args.row_scale = _ptr(aux), float(row_scale)
+        rows = ws = None
+        if epilogue == _lib.EPI_RECON:
+            rows = torch.empty((M,), dtype=torch.float32, device=a.device)
+            nbytes = l.rqhip_gemm_split_recon_workspace_bytes(M, int(n_cols))
+            ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=a.device)
+            args.loss_rows, args.workspace, args.workspace_bytes = rows.data_ptr(), ws.data_ptr(), nbytes
+        if a_row_max is not None:
+            args.a_row_max, args.a_row_parts = a_row_max.data_ptr(), a_row_max.shape[0]
+        crm = torch.empty((n_cols // (256 if n_cols % 256 == 0 else 128), M), dtype=torch.int32, device=a.device) if want_row_max else None
+        args.c_row_max, args.c_col_max = _ptr(crm), _ptr(col_max_out)
+        import ctypes as C
+        check(l.rqhip_gemm_split_ex(C.byref(args), _stream()), "rqhip_gemm_split_ex")
+    return c, rows, crm
 
 
-def gemm_split_recon(a: Tensor, planes: Tensor, n_cols: int, x: Tensor, row_scale: float):
-    """The last decoder layer fused with the reconstruction loss (rqhip_gemm_split_recon): with x_hat = a . image^T (never
-    stored) returns (g, loss_rows): g [M, n_cols] = (2 (x_hat - x)) * row_scale and loss_rows [M] = sum (x_hat - x)^2."""
-    _need_gpu(a, planes, x)
-    a, x = _f32c(a, "a"), _f32c(x, "x")
-    M, R = a.shape
-    if tuple(x.shape) != (M, n_cols):
-        raise RqHipError(f"gemm_split_recon: x is {tuple(x.shape)}, expected {(M, n_cols)}")
-    with torch.cuda.device(a.device):
-        l = _lib.lib()
-        g = torch.empty((M, n_cols), dtype=torch.float32, device=a.device)
-        rows = torch.empty((M,), dtype=torch.float32, device=a.device)
-        nbytes = l.rqhip_gemm_split_recon_workspace_bytes(M, int(n_cols))
-        ws = torch.empty((max(nbytes, 4),), dtype=torch.uint8, device=a.device)
-        check(l.rqhip_gemm_split_recon(_ptr(a), M, R, _ptr(planes), int(n_cols), _ptr(x), float(row_scale), _ptr(g), _ptr(rows),
-                                       _ptr(ws), nbytes, _stream()), "rqhip_gemm_split_recon")
+def gemm_split(a: Tensor, planes: Tensor, n_cols: int, relu: bool = False, tile_rows: int = 0, arith: int = BF16X3) -> Tensor:
+    """C [M, n_cols] = a [M, R] . image^T with the optional ReLU epilogue.  arith BF16X3 (default here: round 3's call) or
+    F16X2, for which the row maxima of `a` are computed by a `maxima` pass first (callers that chain layers use
+    `gemm_split_ex` and hand the maxima over instead)."""
+    rm = maxima(a, cols=False)[0] if arith == F16X2 else None
+    return gemm_split_ex(a, planes, n_cols, arith=arith, epilogue=_lib.EPI_RELU if relu else _lib.EPI_STORE, a_row_max=rm,
+                         tile_rows=tile_rows)[0]
+
+
+def gemm_split_recon(a: Tensor, planes: Tensor, n_cols: int, x: Tensor, row_scale: float, arith: int = BF16X3):
+    """The last decoder layer fused with the reconstruction loss (RQHIP_EPI_RECON): with x_hat = a . image^T (never stored)
+    returns (g, loss_rows): g [M, n_cols] = (2 (x_hat - x)) * row_scale and loss_rows [M] = sum (x_hat - x)^2."""
+    if tuple(x.shape) != (a.shape[0], n_cols):
+        raise RqHipError(f"gemm_split_recon: x is {tuple(x.shape)}, expected {(a.shape[0], n_cols)}")
+    rm = maxima(a, cols=False)[0] if arith == F16X2 else None
+    g, rows, _ = gemm_split_ex(a, planes, n_cols, arith=arith, epilogue=_lib.EPI_RECON, aux=x, row_scale=row_scale, a_row_max=rm)
     return g, rows
 
 
-def recon_rescale_rows(g_spec: Tensor, g_out: Tensor, row_scale: float) -> Tensor:
+def recon_rescale_rows(g_spec: Tensor, g_out: Tensor, row_scale: float, row_max: Optional[Tensor] = None,
+                       col_max: Optional[Tensor] = None) -> Tensor:
     """In place: rows of g_spec whose upstream gradient g_out[row] is not row_scale (bit compare) are multiplied by
-    g_out[row] / row_scale (rqhip_recon_rescale_rows); returns g_spec."""
-    _need_gpu(g_spec, g_out)
+    g_out[row] / row_scale (rqhip_recon_rescale_rows_ex); returns g_spec.  row_max [parts, B] / col_max [N] (int32, the
+    maxima the fused epilogue emitted for g_spec) are brought up to date for the rows that change."""
+    _need_gpu(g_spec, g_out, row_max, col_max)
     g_out = _f32c(g_out, "g_out")
     B, N = g_spec.shape
     with torch.cuda.device(g_spec.device):
-        check(_lib.lib().rqhip_recon_rescale_rows(_ptr(g_out), B, N, float(row_scale), _ptr(g_spec), _stream()),
-              "rqhip_recon_rescale_rows")
+        check(_lib.lib().rqhip_recon_rescale_rows_ex(_ptr(g_out), B, N, float(row_scale), _ptr(g_spec), _ptr(row_max),
+                                                     0 if row_max is None else row_max.shape[0], _ptr(col_max), _stream()),
+              "rqhip_recon_rescale_rows_ex")
     return g_spec

@@ -103,15 +103,10 @@ def _(x, w):
 
 @torch.library.custom_op("rqhip::linear_backward", mutates_args=())
 def linear_backward(gy: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, need_x: bool) -> List[Tensor]:
-    """(gx, gw) of y = relu(x w^T) (y given) or y = x w^T (y None): rqhip_linear_wgrad + one library GEMM."""
-    gy = gy.contiguous()
-    if ops.linear_wgrad_supported(w.shape[0], w.shape[1]) and gy.shape[0] > 0:
-        gw, g = ops.linear_wgrad(gy, y, x, want_masked=need_x)
-    else:
-        g = gy if y is None else torch.ops.aten.threshold_backward(gy, y, 0.0)
-        gw = g.t().mm(x)
-    gx = _lin.input_grad(g, w) if need_x else gy.new_empty((0,))
-    return [gx, gw]
+    """(gx, gw) of y = relu(x w^T) (y given) or y = x w^T (y None): the per-layer backward of rqhip/linear.py (the kernels the
+    autograd Functions of modules/encoder.py run)."""
+    gx, gw = _lin.backward(gy, y, x, w, need_x, True)
+    return [gx if need_x else gy.new_empty((0,)), gw]
 
 
 @linear_backward.register_fake

@@ -101,15 +101,18 @@ def test_split_piece_bounds_hold_for_every_mantissa():
 
 def test_library_threshold_covers_the_derived_bound():
     from rqhip import ops
-    c1, c2 = ops.filter_bound()
     for D in (32, 64):
+        c1, c2 = ops.filter_bound(D)
         n1, n2 = derived_bound(D)
         assert c1 >= n1, f"D={D}: c1 = {c1:.4g} does not cover the derived {n1:.4g}"
         assert c2 >= n2, f"D={D}: c2 = {c2:.4g} does not cover the derived {n2:.4g}"
-        # and the margin is what the source says, not more (a 'safe' retune must come back here)
-        assert c1 / n1 < 1.5 and c2 / n2 < 2.0
+        # and the margin is what the source says, not more (a 'safe' retune must come back here): 1.38 at D = 32; D = 64 takes
+        # 2^-11 (2.1) because 2^-12 would leave 6 % over a bound that rests on the measured hardware assumption H
+        assert c1 / n1 < (1.5 if D == 32 else 2.2) and c2 / n2 < 2.0
+    c1, c2 = ops.filter_bound(32)
     n1, n2 = derived_bound(32)
     assert c1 / 2 < n1, "halving c1 must break the proof (it would silently break bit-exactness)"
+    assert abs(ops.filter_bound(64)[0] - 2.0 ** -11) < 1e-12
     assert abs(c1 - 2.0 ** -12) < 1e-12 and abs(c2 - 2.0 ** -19) < 1e-15
 
 
@@ -173,7 +176,7 @@ def scan_scores(x, cb, csq, model):
 def worst_pair_error(x, cb):
     """max over rows and code pairs of (e_a + e_b) / T, and the same with the oracle-rounding share removed."""
     from rqhip import ops
-    c1, c2 = ops.filter_bound()
+    c1, c2 = ops.filter_bound(x.shape[1])
     d, xsq, csq = oracle_dist(x, cb)
     worst = 0.0
     for model in ("exact", "chop"):
@@ -221,15 +224,16 @@ def test_worst_case_operands_stay_inside_the_threshold(D):
     w = worst_pair_error(x, cb)
     print(f"D={D}: worst (e_a + e_b) / T on the constructed operands = {w:.3f}")
     assert w <= 1.0
-    # the construction is meant to bite: it must use a real share of the threshold (random data uses ~5 %)
-    assert w > 0.35, w
+    # the construction is meant to bite: it must use a real share of the threshold (random data uses ~5 %); D = 64 runs with
+    # twice the constant (2^-11, see test_library_threshold_covers_the_derived_bound), so the same errors are half the share
+    assert w > (0.35 if D == 32 else 0.2), w
 
 
 def test_threshold_would_fail_if_the_split_dropped_another_term():
     """Sanity of the emulation itself: removing the xl.ch chain (a two-term split) must blow through T on the same
     operands -- the test above is able to fail."""
     from rqhip import ops
-    c1, c2 = ops.filter_bound()
+    c1, c2 = ops.filter_bound(32)
     x, cb = _worst_case_operands(32, n_rows=16)
     d, xsq, csq = oracle_dist(x, cb)
     xh, _ = split2(x)

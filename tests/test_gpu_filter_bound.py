@@ -68,7 +68,7 @@ def test_matrix_chain_accumulation_error_within_assumption(D):
 @pytest.mark.parametrize("D", [32, 64])
 def test_hardware_scores_keep_two_code_errors_under_the_threshold(D):
     from rqhip import ops
-    c1, c2 = ops.filter_bound()
+    c1, c2 = ops.filter_bound(D)
     for name, (x, cb) in _operand_sets(D).items():
         d, xsq, csq = fb.oracle_dist(x, cb)
         sc = _scores(x, cb).astype(np.float64)

@@ -1,6 +1,7 @@
-"""csrc/gemm_split.hip: the activation GEMMs of the MLPs (forward `relu(x W^T)`, data gradient `g W`) on the bf16 matrix
-cores with three exact bf16 pieces per operand.  Held to: no less exact than the library's own fp32 GEMM against fp64
-(VERDICT r2 item 5's gate), bit-reproducible, ReLU epilogue exact, ragged row counts, values spread over many decades."""
+"""csrc/gemm_split.hip: the activation GEMMs of the MLPs (forward `relu(x W^T)`, data gradient `g W`) on the 16-bit matrix
+cores -- two fp16 pieces per operand under exact power-of-two scales (f16x2, the product path) or three exact bf16 pieces
+(bf16x3, round 3).  Held to: no less exact than the library's own fp32 GEMM against fp64 on every operand family (VERDICT r3
+item 1a's gate), bit-reproducible, epilogues exact, ragged row counts, values spread over many decades."""
 import pytest
 import torch
 
@@ -10,11 +11,19 @@ SHAPES = [(512, 768), (768, 512), (256, 512), (512, 256),    # (Nc, R) of the la
           (128, 256), (128, 32), (384, 64)]                   # 128 (mod 256) columns: the 256 x 128 tile
 
 
-def _check(a, w, transpose, relu):
+ARITHS = ["f16x2", "bf16x3"]   # the product arithmetic (round 4) and round 3's, kept for A/B
+
+
+def _arith(name):
     from rqhip import ops
-    planes = ops.weight_planes(w, transpose=transpose)
+    return {"f16x2": ops.F16X2, "bf16x3": ops.BF16X3}[name]
+
+
+def _check(a, w, transpose, relu, arith):
+    from rqhip import ops
+    planes = ops.weight_planes(w, transpose=transpose, arith=_arith(arith))
     n_cols = w.shape[1] if transpose else w.shape[0]
-    c = ops.gemm_split(a, planes, n_cols, relu=relu)
+    c = ops.gemm_split(a, planes, n_cols, relu=relu, arith=_arith(arith))
     b = w if transpose else w.t()                      # [R, Nc]
     ref = a.double() @ b.double()
     lib = a @ b
@@ -23,66 +32,187 @@ def _check(a, w, transpose, relu):
     scale = ref.abs().max().item()
     err = (c.double() - ref).abs().max().item() / scale
     lerr = (lib.double() - ref).abs().max().item() / scale
-    c2 = ops.gemm_split(a, planes, n_cols, relu=relu)
+    c2 = ops.gemm_split(a, planes, n_cols, relu=relu, arith=_arith(arith))
     assert torch.equal(c, c2)                          # tiles are dealt dynamically; the bits do not depend on it
     return err, lerr
 
 
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("transpose", [False, True])
 @pytest.mark.parametrize("Nc,R", SHAPES)
-def test_gemm_split_full_size_vs_fp64(Nc, R, transpose, relu):
+def test_gemm_split_full_size_vs_fp64(Nc, R, transpose, relu, arith):
     g = torch.Generator().manual_seed(Nc + R)
     M = 100_000
     a = torch.randn(M, R, generator=g).cuda()
     w = (torch.randn(R, Nc, generator=g) if transpose else torch.randn(Nc, R, generator=g)).cuda() / R ** 0.5
-    err, lerr = _check(a, w, transpose, relu)
-    print(f"C [{M},{Nc}] = A [{M},{R}] B^T (transpose={transpose}, relu={relu}): max err / max|C| = {err:.3e} "
+    err, lerr = _check(a, w, transpose, relu, arith)
+    print(f"{arith}: C [{M},{Nc}] = A [{M},{R}] B^T (transpose={transpose}, relu={relu}): max err / max|C| = {err:.3e} "
           f"(library fp32 GEMM: {lerr:.3e})")
     assert err < 2e-6 and err <= max(lerr, 2e-7), (err, lerr)
 
 
+def worst_mantissa(shape, g):
+    """Every value on the worst case of the 11 + 11-bit split: v = +-(1 + a 2^-10 + 2^-12 + (4 j + 1) 2^-23): hi = RN16(v)
+    leaves a low part in the top binade of its fp16 range with the 2^-23 bit set, a tie that rounds to even the same way
+    every time, so v - hi - lo = +2^-23 for every element (the sign of v): the representation errors of a row add up
+    coherently, and so do the dropped lo x lo products."""
+    a = torch.randint(0, 1024, shape, generator=g).double()
+    j = torch.randint(0, 256, shape, generator=g).double()
+    sgn = torch.randint(0, 2, shape, generator=g).double() * 2 - 1
+    v = sgn * (1 + a * 2.0 ** -10 + 2.0 ** -12 + (4 * j + 1) * 2.0 ** -23)
+    out = v.float()
+    assert (out.double() == v).all()
+    return out
+
+
+def cancelling(M, R, N, g):
+    """rows of A = [u, -u (1 + 1e-4 noise)], B = [w, w (1 + 1e-4 noise)]: every output is the small difference of two large sums"""
+    u = torch.randn(M, R // 2, generator=g)
+    w = torch.randn(N, R // 2, generator=g) / R ** 0.5
+    A = torch.cat([u, -u * (1 + 1e-4 * torch.randn(M, R // 2, generator=g))], dim=1)
+    B = torch.cat([w, w * (1 + 1e-4 * torch.randn(N, R // 2, generator=g))], dim=1)
+    return A, B
+
+
+def _families(Nc, R):
+    """operand families (A [M, R], B [Nc, R]) of the gate `max error vs fp64 <= the library fp32 GEMM's`"""
+    g = torch.Generator().manual_seed(1000 * Nc + R)
+    M = 8192
+    x = torch.nn.functional.normalize(torch.randn(M, R, generator=g), dim=-1)
+    w = torch.randn(Nc, R, generator=g) / R ** 0.5
+    yield "unit-norm rows", x, w
+    yield "post-ReLU activations", torch.relu(torch.randn(M, R, generator=g)), w
+    yield "1e-5-scale masked gradient", torch.randn(M, R, generator=g) * 1e-5 * (torch.rand(M, R, generator=g) > 0.5), w
+    yield ("twelve decades of row scales", torch.randn(M, R, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (M, 1), generator=g).float()),
+           torch.randn(Nc, R, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (Nc, 1), generator=g).float()))
+    yield "five decades inside every row", torch.randn(M, R, generator=g) * torch.pow(10.0, torch.randint(-4, 1, (M, R), generator=g).float()), w
+    yield "worst-case mantissas of the 11-bit split", worst_mantissa((M, R), g), worst_mantissa((Nc, R), g) * 2.0 ** -5
+    yield "worst-case mantissas, all positive", worst_mantissa((M, R), g).abs(), worst_mantissa((Nc, R), g).abs()
+    yield ("cancellation-heavy rows",) + cancelling(M, R, Nc, g)
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+@pytest.mark.parametrize("Nc,R", [(512, 768), (768, 512), (256, 512), (512, 256)])
+def test_gemm_split_operand_families_vs_fp64(Nc, R, arith):
+    """The gate of the fp16 path (11 + 11 bits per operand are NARROWER per product than fp32): on every operand family the
+    maximum error against fp64 stays at or below the library fp32 GEMM's on the same inputs."""
+    for name, A, B in _families(Nc, R):
+        err, lerr = _check(A.cuda().contiguous(), B.cuda().contiguous(), False, False, arith)
+        print(f"{arith} {R}->{Nc} {name}: {err:.3e} (library {lerr:.3e})")
+        # (the gate is the product arithmetic's.  Round 3's three-piece arm, kept for A/B only, misses it on two families at
+        # 512 -> 768 -- post-ReLU activations 7.3e-7 against the library's 6.4e-7, 1e-5-scale masked gradients 8.3e-7 against
+        # 6.5e-7: six accumulation steps per product instead of three -- and is held to 1.4 x)
+        assert err <= max(lerr, 2e-7) * (1.0 if arith == "f16x2" else 1.4), (name, err, lerr)
+
+
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("M", [1, 127, 129, 4099])
-def test_gemm_split_ragged_rows_and_scales(M):
+def test_gemm_split_ragged_rows_and_scales(M, arith):
     g = torch.Generator().manual_seed(M)
     a = (torch.randn(M, 768, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (M, 1), generator=g).float())).cuda()
     w = (torch.randn(512, 768, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (512, 1), generator=g).float())).cuda()
     from rqhip import ops
-    planes = ops.weight_planes(w)
-    c = ops.gemm_split(a, planes, 512)
+    ar = _arith(arith)
+    planes = ops.weight_planes(w, arith=ar)
+    c = ops.gemm_split(a, planes, 512, arith=ar)
     ref = a.double() @ w.double().t()
     bound = a.double().abs() @ w.double().abs().t() * (768 ** 0.5 + 8) * 2.0 ** -24 + 1e-30
     assert ((c.double() - ref).abs() <= bound).all(), float(((c.double() - ref).abs() / bound).max())
     with pytest.raises(ops.RqHipError):
-        ops.weight_planes(torch.zeros(100, 768, device="cuda"))          # Nc not a multiple of 128
+        ops.weight_planes(torch.zeros(100, 768, device="cuda"), arith=ar)          # Nc not a multiple of 128
     # the 128-column tile (its leftover tiles are 128 rows high), same bound
     w2 = (torch.randn(128, 768, generator=g) * torch.pow(10.0, torch.randint(-3, 4, (128, 1), generator=g).float())).cuda()
-    c2 = ops.gemm_split(a, ops.weight_planes(w2), 128, relu=True)
+    c2 = ops.gemm_split(a, ops.weight_planes(w2, arith=ar), 128, relu=True, arith=ar)
     ref2 = torch.relu(a.double() @ w2.double().t())
     bound2 = a.double().abs() @ w2.double().abs().t() * (768 ** 0.5 + 8) * 2.0 ** -24 + 1e-30
     assert ((c2.double() - ref2).abs() <= bound2).all()
 
 
+def test_gemm_split_f16_special_rows():
+    """zero rows, rows of subnormals, a row with an Inf / a NaN: zero rows give zeros, tiny rows keep fp32's accuracy (the scale is
+    the row's own maximum), non-finite rows are not scaled and give non-finite results, as an fp32 GEMM would."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(300, 256, generator=g)
+    a[3] = 0.0
+    a[5] *= 1e-41
+    a[7, 11] = float("inf")
+    a[9, 0] = float("nan")
+    a[11] *= 1e30
+    w = torch.randn(256, 256, generator=g) / 16
+    a, w = a.cuda(), w.cuda()
+    c = ops.gemm_split(a, ops.weight_planes(w, arith=ops.F16X2), 256, arith=ops.F16X2)
+    ref = a.double() @ w.double().t()
+    assert (c[3] == 0).all() and not torch.isfinite(c[7]).all() and torch.isnan(c[9]).all()
+    ok = torch.ones(300, dtype=torch.bool)
+    ok[[7, 9]] = False
+    bound = a.double().abs() @ w.double().abs().t() * (256 ** 0.5 + 8) * 2.0 ** -24 + 2.0 ** -149
+    assert ((c.double() - ref).abs()[ok] <= bound[ok]).all()
+
+
+def test_maxima_and_epilogue_emitted_scales():
+    """rqhip_maxima == torch's amax bits (rows, columns, masked); the maxima a GEMM epilogue emits for what it stores equal
+    the maxima of the stored matrix; a GEMM fed with emitted maxima gives the bits of one fed by a pass; the masked epilogue
+    (RQHIP_EPI_MASK) equals the plain result masked afterwards."""
+    from rqhip import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    M = 5003
+    a = torch.randn(M, 512, generator=g).cuda() * torch.pow(10.0, torch.randint(-3, 4, (M, 1), generator=g).float()).cuda()
+    y = torch.randn(M, 512, generator=g).cuda()
+    r, c, _ = ops.maxima(a)
+    assert torch.equal(r[0].view(torch.float32), a.abs().amax(dim=1)) and torch.equal(c.view(torch.float32), a.abs().amax(dim=0))
+    r, c, am = ops.maxima(a, y, write_masked=True)
+    want = torch.where(y > 0, a, torch.zeros_like(a))
+    assert torch.equal(am, want) and torch.equal(r[0].view(torch.float32), want.abs().amax(dim=1))
+    assert torch.equal(c.view(torch.float32), want.abs().amax(dim=0))
+    w1 = (torch.randn(768, 512, generator=g) / 512 ** 0.5).cuda()
+    w2 = (torch.randn(256, 768, generator=g) / 768 ** 0.5).cuda()
+    i1, i2 = ops.weight_images([(w1, False), (w2, False)])
+    assert torch.equal(i1, ops.weight_planes(w1, arith=ops.F16X2)) and torch.equal(i2, ops.weight_planes(w2, arith=ops.F16X2))
+    rows_a = ops.maxima(a, cols=False)[0]
+    for epi in (_lib.EPI_STORE, _lib.EPI_RELU):
+        col = torch.zeros(768, dtype=torch.int32, device="cuda")
+        h, _, hr = ops.gemm_split_ex(a, i1, 768, epilogue=epi, a_row_max=rows_a, want_row_max=True, col_max_out=col)
+        assert tuple(hr.shape) == (3, M)
+        assert torch.equal(hr.view(torch.float32).amax(dim=0), h.abs().amax(dim=1))
+        assert torch.equal(col.view(torch.float32), h.abs().amax(dim=0))
+        chained = ops.gemm_split_ex(h, i2, 256, a_row_max=hr)[0]
+        passed = ops.gemm_split_ex(h, i2, 256, a_row_max=ops.maxima(h, cols=False)[0])[0]
+        assert torch.equal(chained, passed)
+    yy = torch.randn(M, 768, generator=g).cuda()
+    col = torch.zeros(768, dtype=torch.int32, device="cuda")
+    plain = ops.gemm_split_ex(a, i1, 768, a_row_max=rows_a)[0]
+    masked, _, mr = ops.gemm_split_ex(a, i1, 768, epilogue=_lib.EPI_MASK, aux=yy, a_row_max=rows_a, want_row_max=True, col_max_out=col)
+    want = torch.where(yy > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(masked, want)
+    assert torch.equal(mr.view(torch.float32).amax(dim=0), want.abs().amax(dim=1)) and torch.equal(col.view(torch.float32), want.abs().amax(dim=0))
+    with pytest.raises(ops.RqHipError):
+        ops.gemm_split_ex(a, i1, 768)                                  # the fp16 arithmetic needs the row maxima of A
+
+
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("M", [100_000, 5003, 77])
-def test_gemm_split_recon_equals_gemm_then_loss(M):
+def test_gemm_split_recon_equals_gemm_then_loss(M, arith):
     """Epilogue 2 (last decoder layer + ReconstructionLoss, reference modules/rqvae.py:146,152 + loss.py:5-10): the gradient
     matrix has the bits of gemm_split followed by recon_loss_forward_spec (same x_hat, same arithmetic per element); the row
     sums run in another order (column tiles, waves) -> relative 1e-6."""
     from rqhip import ops
+    ar = _arith(arith)
     g = torch.Generator().manual_seed(M)
     h = torch.relu(torch.randn(M, 512, generator=g)).cuda()
     w = (torch.randn(768, 512, generator=g) / 512 ** 0.5).cuda()
     x = torch.nn.functional.normalize(torch.randn(M, 768, generator=g), dim=-1).cuda()
     scale = 1.0 / M
-    planes = ops.weight_planes(w)
-    x_hat = ops.gemm_split(h, planes, 768)
+    planes = ops.weight_planes(w, arith=ar)
+    x_hat = ops.gemm_split(h, planes, 768, arith=ar)
     rows_ref, g_ref = ops.recon_loss_forward_spec(x_hat, x, scale)
-    g_fused, rows = ops.gemm_split_recon(h, planes, 768, x, scale)
+    g_fused, rows = ops.gemm_split_recon(h, planes, 768, x, scale, arith=ar)
     assert torch.equal(g_fused, g_ref)
     assert torch.allclose(rows, rows_ref, rtol=1e-6, atol=0.0)
     ref64 = ((h.double() @ w.double().t()) - x.double()).pow(2).sum(-1)
     assert torch.allclose(rows.double(), ref64, rtol=2e-6)
-    g2, rows2 = ops.gemm_split_recon(h, planes, 768, x, scale)
+    g2, rows2 = ops.gemm_split_recon(h, planes, 768, x, scale, arith=ar)
     assert torch.equal(g2, g_fused) and torch.equal(rows2, rows)          # run-to-run
 
 
@@ -100,5 +230,12 @@ def test_recon_rescale_rows():
     got = ops.recon_rescale_rows(spec.clone(), g_out, s)
     assert torch.equal(got[~odd], spec[~odd])                            # matching rows are not touched
     assert torch.allclose(got[odd], want[odd], rtol=4e-7, atol=0.0)      # (one extra rounding on the rescaled rows)
+    # with the maxima the fused epilogue emitted: brought up to date for the rescaled rows
+    rm = torch.stack([spec[:, 256 * p:256 * (p + 1)].abs().amax(dim=1) for p in range(3)]).view(torch.int32).contiguous()
+    cm = spec.abs().amax(dim=0).view(torch.int32).contiguous()
+    got2 = ops.recon_rescale_rows(spec.clone(), g_out, s, rm, cm)
+    assert torch.equal(got2, got)
+    assert torch.equal(rm.view(torch.float32).amax(dim=0), got.abs().amax(dim=1))
+    assert (cm.view(torch.float32) >= got.abs().amax(dim=0)).all()
     with pytest.raises(ops.RqHipError):
         ops.recon_rescale_rows(spec, g_out, 0.0)

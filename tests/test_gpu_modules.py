@@ -501,6 +501,49 @@ def test_split_gemms_follow_the_optimizer():
         assert abs(la - lb) <= 2e-5 * abs(lb), (a, b)
 
 
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3"])
+def test_mlp_stack_node_equals_the_per_layer_functions_bit_for_bit(arith):
+    """modules/encoder.py: the whole-stack autograd node (weight images in one launch, scales handed from epilogue to epilogue,
+    the ReLU backward in the data-gradient epilogues) runs the arithmetic of the per-layer Functions (one node per layer, scales
+    from maxima passes, mask in its own pass): the same maxima give the same exponents, so outputs and every gradient are
+    bit-identical."""
+    from modules.encoder import MLP
+    from rqhip import linear
+    before = linear.use_arith(arith)
+    try:
+        torch.manual_seed(5)
+        mlp = MLP(768, [512, 256, 128], 32).cuda()
+        x = torch.nn.functional.normalize(torch.randn(9000, 768, device="cuda"), dim=-1).requires_grad_(True)
+        gout = torch.randn(9000, 32, device="cuda") * 1e-4
+
+        def run(fn):
+            for p in mlp.parameters():
+                p.grad = None
+            x.grad = None
+            y = fn(x, list(mlp.mlp))
+            y.backward(gout)
+            return [y.detach().clone()] + [p.grad.clone() for p in mlp.parameters()] + [x.grad.clone()]
+
+        a, b = run(mlp._run), run(mlp._run_layerwise)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        dec = MLP(32, [128, 256, 512], 768).cuda()            # the decoder's shape: its input needs a gradient
+        z = torch.randn(9000, 32, device="cuda", requires_grad=True)
+        g2 = torch.randn(9000, 768, device="cuda") * 1e-5
+        outs = []
+        for fn in (dec._run, dec._run_layerwise):
+            for p in dec.parameters():
+                p.grad = None
+            z.grad = None
+            y = fn(z, list(dec.mlp))
+            y.backward(g2)
+            outs.append([y.detach().clone()] + [p.grad.clone() for p in dec.parameters()] + [z.grad.clone()])
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+    finally:
+        linear.use_arith(before)
+
+
 def _rqvae_768(seed=0):
     from modules.quantize import QuantizeForwardMode
     from modules.rqvae import RqVae
@@ -516,14 +559,14 @@ def _rqvae_768(seed=0):
 @pytest.mark.parametrize("case", ["mean", "half_without_hint", "second_backward"])
 def test_fused_last_layer_and_reconstruction_loss_equals_the_composed_pair(case, monkeypatch):
     """RqVae.forward at a large batch runs the last decoder layer and ReconstructionLoss as one kernel (x_hat is never
-    stored; modules/encoder.py:_LinearRecon).  Losses and every parameter gradient must equal the composed path (decoder,
+    stored; modules/encoder.py:_MLPStack with a target).  Losses and every parameter gradient must equal the composed path (decoder,
     then the loss kernel) -- also when the upstream row gradient is not the announced one (rows are rescaled) and on a
     second backward through a retained graph (x_hat is recomputed)."""
     from data.schemas import SeqBatch
-    from modules.encoder import MLP, _LinearRecon
+    from modules.encoder import MLP, _MLPStack
     x = torch.nn.functional.normalize(torch.randn(8192, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(3)), dim=-1)
     calls = []
-    real_apply = _LinearRecon.apply
+    real_apply = _MLPStack.apply
 
     def run(fused):
         m = _rqvae_768()
@@ -531,7 +574,7 @@ def test_fused_last_layer_and_reconstruction_loss_equals_the_composed_pair(case,
             monkeypatch.setattr(MLP, "reconstruction_rows", lambda self, z, t: None)
         else:
             monkeypatch.undo()
-            monkeypatch.setattr(_LinearRecon, "apply", lambda *a: (calls.append(1), real_apply(*a))[1])
+            monkeypatch.setattr(_MLPStack, "apply", lambda *a: (calls.append(1) if a[1] is not None else None, real_apply(*a))[1])
         out = m(SeqBatch(None, None, None, x, None, None), 0.2)
         loss = out.loss * 0.5 if case == "half_without_hint" else out.loss
         if case == "second_backward":

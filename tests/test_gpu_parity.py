@@ -206,7 +206,7 @@ def _recheck_rate(x, cb, mode):
     """Fraction of (row, level) decisions whose EXACT top-2 distance gap is below the filter's threshold T: an estimate
     of how many rows the filtered kernel re-decides exactly (it tests the approximate gap, which differs by < T)."""
     from rqhip import ops
-    c1, c2 = ops.filter_bound()
+    c1, c2 = ops.filter_bound(cb.shape[-1])
     out = ops.rq_forward(x, cb, mode, 0.25, want_margin=True, want_embs=False)
     res = out.residuals                                     # [L,B,D]
     xsq = (res.double() ** 2).sum(-1)                       # [L,B]

@@ -2,9 +2,11 @@
 backward fused.
 
 fp32-MFMA kernel (small layers always; large layers with RQHIP_WGRAD_FP32): bit-exact against the oracle's restatement of
-its fixed summation order at sizes the scalar oracle finishes in seconds.  bf16-split kernel (the default on the large
-layers): its six-term product is held to "no less exact than the library's fp32 GEMM" against fp64 at the bench's full
-size, the ReLU mask bit for bit, run-to-run bit reproducibility; and the MLP module against plain torch autograd.
+its fixed summation order at sizes the scalar oracle finishes in seconds.  Split kernels on the large layers -- "f16": two
+fp16 pieces per operand under exact power-of-two COLUMN scales, three products (rqhip_linear_wgrad_f16, the product path);
+"bf16": three exact bf16 pieces, six products (round 3) -- are held to "no less exact than the library's fp32 GEMM" against
+fp64 at the bench's full size and on adversarial operand families, the ReLU mask bit for bit, run-to-run bit reproducibility;
+and the MLP module against plain torch autograd.
 """
 import ctypes as C
 
@@ -24,6 +26,20 @@ def _msplit(M, N, K):
     n = C.c_int(0)
     assert _lib.lib().rqhip_linear_wgrad_plan(M, N, K, C.byref(n)) >= 0
     return n.value
+
+
+def _wgrad(gy, y, x, kind):
+    """(dW, g_pre) by kernel kind.  "f16" as the product path runs it: one pass masks gy, writes g_pre and takes its column
+    maxima (in a training step a GEMM epilogue does all three), the kernel then reads g_pre unmasked."""
+    from rqhip import ops
+    if kind != "f16":
+        return ops.linear_wgrad(gy, y, x, exact_fp32=kind == "fp32")
+    if y is not None:
+        _, gc, gp = ops.maxima(gy, y, rows=False, write_masked=True)
+    else:
+        gc, gp = ops.maxima(gy, rows=False)[1], gy
+    dw, _ = ops.linear_wgrad(gp, None, x, g_col_max=gc, x_col_max=ops.maxima(x, rows=False)[1])
+    return dw, gp
 
 
 def _inputs(M, N, K, seed):
@@ -46,48 +62,90 @@ def test_wgrad_bitexact_vs_oracle(M, N, K, mask):
     assert np.array_equal(dw.cpu().numpy().view(np.uint32), ref_dw.view(np.uint32))
 
 
-@pytest.mark.parametrize("exact_fp32", [False, True])
+@pytest.mark.parametrize("kind", ["f16", "bf16", "fp32"])
 @pytest.mark.parametrize("N,K", LAYERS)
-def test_wgrad_full_size_vs_fp64(N, K, exact_fp32):
-    """Both kernels at 100 000 rows.  The default one (bf16-split on the large layers) must be no less exact than the
-    library's own fp32 GEMM of the same product (VERDICT r2 item 5's gate) -- measured and printed."""
-    from rqhip import ops
+def test_wgrad_full_size_vs_fp64(N, K, kind):
+    """All kernels at 100 000 rows.  The split ones (large layers) must be no less exact than the library's own fp32 GEMM of
+    the same product (VERDICT r2 item 5's gate) -- measured and printed."""
     M = 100_000
     gy, y, x = (t.cuda() for t in _inputs(M, N, K, N * 7 + K))
-    dw, gpre = ops.linear_wgrad(gy, y, x, exact_fp32=exact_fp32)
+    dw, gpre = _wgrad(gy, y, x, kind)
     assert torch.equal(gpre, torch.ops.aten.threshold_backward(gy, y, 0.0))       # the mask, bit for bit
     ref = gpre.double().t().mm(x.double())
     scale = ref.abs().max().item()
     err = (dw.double() - ref).abs().max().item() / scale
     lib = (gpre.t().mm(x).double() - ref).abs().max().item() / scale             # the library's fp32 GEMM, same operands
-    print(f"dW [{N},{K}] exact_fp32={exact_fp32}: max err / max|dW| = {err:.3e} (library fp32 GEMM: {lib:.3e})")
+    print(f"dW [{N},{K}] {kind}: max err / max|dW| = {err:.3e} (library fp32 GEMM: {lib:.3e})")
     assert err < 2e-6, err
     assert err <= max(lib, 2e-7), (err, lib)
-    dw2, _ = ops.linear_wgrad(gy, y, x, exact_fp32=exact_fp32)
+    dw2, _ = _wgrad(gy, y, x, kind)
     assert torch.equal(dw, dw2)                                                   # fixed reduction order
-    dw3, same = ops.linear_wgrad(gy, None, x, exact_fp32=exact_fp32)
+    dw3, same = _wgrad(gy, None, x, kind)
     assert same is gy
     err = (dw3.double() - gy.double().t().mm(x.double())).abs().max().item() / scale
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
 @pytest.mark.parametrize("mask", [True, False])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 256), (17, 128, 256), (1000, 256, 128), (4099, 512, 768), (33, 768, 512)])
-def test_wgrad_split_ragged_rows_vs_fp64(M, N, K, mask):
-    """The bf16-split kernel on row counts that do not fill a 16-row stage or a 32-row granule, and on adversarial
-    magnitudes (entries spread over twelve decades: the three bf16 pieces must carry all 24 bits of each)."""
-    from rqhip import ops
+def test_wgrad_split_ragged_rows_vs_fp64(M, N, K, mask, kind):
+    """The split kernels on row counts that do not fill a 16-row stage or a 32-row granule, and on adversarial magnitudes
+    (entries spread over twelve decades: the pieces must carry the bits of each)."""
     g = torch.Generator().manual_seed(M + N)
     gy = (torch.randn(M, N, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (M, 1), generator=g).float())).cuda()
     y = torch.relu(torch.randn(M, N, generator=g)).cuda()
     x = (torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (1, K), generator=g).float())).cuda()
-    dw, gpre = ops.linear_wgrad(gy, y if mask else None, x)
+    dw, gpre = _wgrad(gy, y if mask else None, x, kind)
     gp = torch.ops.aten.threshold_backward(gy, y, 0.0) if mask else gy
     assert torch.equal(gpre, gp)
     ref = gp.double().t().mm(x.double())
     # elementwise: the error of an entry is bounded by a few ulps of the sum of its terms' magnitudes
     bound = gp.double().abs().t().mm(x.double().abs()) * (M ** 0.5 + 8) * 2.0 ** -24 + 1e-30
     assert ((dw.double() - ref).abs() <= bound).all(), float(((dw.double() - ref).abs() / bound).max())
+
+
+def _col_worst_mantissa(shape, g):
+    """tests/test_gpu_gemm_split.py:worst_mantissa: every value on the coherent worst case of the 11 + 11-bit split"""
+    a = torch.randint(0, 1024, shape, generator=g).double()
+    j = torch.randint(0, 256, shape, generator=g).double()
+    sgn = torch.randint(0, 2, shape, generator=g).double() * 2 - 1
+    return (sgn * (1 + a * 2.0 ** -10 + 2.0 ** -12 + (4 * j + 1) * 2.0 ** -23)).float()
+
+
+@pytest.mark.parametrize("N,K", [(512, 768), (256, 512), (768, 512)])
+def test_wgrad_f16_operand_families_vs_fp64(N, K):
+    """The fp16 path's gate on adversarial operands: error against fp64 <= the library fp32 GEMM's.  Families: 1/B-scale
+    gradients; twelve decades of COLUMN scales on both operands (what the column exponents are for); five decades inside
+    every column; the worst-case mantissas of the 11-bit split (coherent representation errors), signed and all positive;
+    also the mask applied INSIDE the kernel with the column maxima of the unmasked gradient (an upper bound)."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(N + K)
+    M = 16384
+    fams = {
+        "1/B-scale gradient x unit-norm rows": (torch.randn(M, N, generator=g) / 1e5, torch.nn.functional.normalize(torch.randn(M, K, generator=g), dim=-1)),
+        "twelve decades of column scales": (torch.randn(M, N, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (1, N), generator=g).float()),
+                                            torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (1, K), generator=g).float())),
+        "five decades inside every column": (torch.randn(M, N, generator=g) * torch.pow(10.0, torch.randint(-4, 1, (M, N), generator=g).float()),
+                                             torch.relu(torch.randn(M, K, generator=g))),
+        "worst-case mantissas": (_col_worst_mantissa((M, N), g), _col_worst_mantissa((M, K), g)),
+        "worst-case mantissas, all positive": (_col_worst_mantissa((M, N), g).abs(), _col_worst_mantissa((M, K), g).abs()),
+    }
+    for name, (gy, x) in fams.items():
+        gy, x = gy.cuda(), x.cuda()
+        dw, _ = _wgrad(gy, None, x, "f16")
+        ref = gy.double().t().mm(x.double())
+        scale = ref.abs().max().item()
+        err = (dw.double() - ref).abs().max().item() / scale
+        lib = (gy.t().mm(x).double() - ref).abs().max().item() / scale
+        print(f"dW [{N},{K}] f16, {name}: {err:.3e} (library {lib:.3e})")
+        assert err <= max(lib, 2e-7), (name, err, lib)
+    gy, y, x = (t.cuda() for t in _inputs(M, N, K, 5))
+    gc, xc = ops.maxima(gy, rows=False)[1], ops.maxima(x, rows=False)[1]      # maxima of the UNMASKED gradient
+    dw, gp = ops.linear_wgrad(gy, y, x, g_col_max=gc, x_col_max=xc)
+    assert torch.equal(gp, torch.ops.aten.threshold_backward(gy, y, 0.0))
+    ref = gp.double().t().mm(x.double())
+    assert (dw.double() - ref).abs().max().item() <= max((gp.t().mm(x).double() - ref).abs().max().item(), 2e-7 * ref.abs().max().item())
 
 
 def test_mlp_backward_matches_torch_autograd():

@@ -69,6 +69,28 @@ def report(name, A, B):
     print("  |  ".join(out), flush=True)
 
 
+def worst_mantissa(shape, g):
+    """Every value on the worst case of the 11 + 11-bit split: v = +-(1 + a 2^-10 + 2^-12 + (4 j + 1) 2^-23) 2^e: hi = RN16(v) leaves a
+    low part in the top binade of its fp16 range with the 2^-23 bit set, a tie that rounds to even the same way every time, so
+    v - hi - lo = +2^-23 2^e for every element (same sign as v): the representation errors of a row add up coherently."""
+    a = torch.randint(0, 1024, shape, generator=g).double()
+    j = torch.randint(0, 256, shape, generator=g).double()
+    sgn = torch.randint(0, 2, shape, generator=g).double() * 2 - 1
+    v = sgn * (1 + a * 2.0 ** -10 + 2.0 ** -12 + (4 * j + 1) * 2.0 ** -23)
+    out = v.float()
+    assert (out.double() == v).all()
+    return out
+
+
+def cancelling(M, R, N, g):
+    """rows of A = [u, -u (1 + 1e-4 noise)], B = [w, w (1 + 1e-4 noise)]: every output is the small difference of two large sums"""
+    u = torch.randn(M, R // 2, generator=g)
+    w = torch.randn(N, R // 2, generator=g) / R ** 0.5
+    A = torch.cat([u, -u * (1 + 1e-4 * torch.randn(M, R // 2, generator=g))], dim=1)
+    B = torch.cat([w, w * (1 + 1e-4 * torch.randn(N, R // 2, generator=g))], dim=1)
+    return A, B
+
+
 torch.manual_seed(0)
 M, K, N = 8192, 768, 512
 x = torch.nn.functional.normalize(torch.randn(M, K), dim=-1)
@@ -80,6 +102,11 @@ report("1e-5-scale masked gradient", torch.randn(M, N) * 1e-5 * (torch.rand(M, N
 report("twelve decades of row scales", torch.randn(M, K) * torch.pow(10.0, torch.randint(-6, 7, (M, 1)).float()),
        torch.randn(N, K) * torch.pow(10.0, torch.randint(-3, 4, (N, 1)).float()))
 report("five decades inside every row", torch.randn(M, K) * torch.pow(10.0, torch.randint(-4, 1, (M, K)).float()), w)
+gg = torch.Generator().manual_seed(7)
+for (Nn, Kk) in ((512, 768), (768, 512), (256, 512), (512, 256)):
+    report(f"worst-case mantissas of the 11-bit split {Kk}->{Nn}", worst_mantissa((M, Kk), gg), worst_mantissa((Nn, Kk), gg) * 2.0 ** -5)
+    report(f"worst-case mantissas, all positive {Kk}->{Nn}", worst_mantissa((M, Kk), gg).abs(), worst_mantissa((Nn, Kk), gg).abs())
+    report(f"cancellation-heavy rows {Kk}->{Nn}", *cancelling(M, Kk, Nn, gg))
 for (Nc, R) in ((512, 768), (768, 512), (256, 512)):
     a = torch.randn(100_000, R, device="cuda")
     ww = torch.randn(Nc, R, device="cuda") / R ** 0.5
