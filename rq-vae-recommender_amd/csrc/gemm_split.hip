@@ -46,8 +46,7 @@ typedef unsigned gs_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));
 typedef int gs_i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGsWaves = 8, kGsUB = 2;     // a wave's tile is (32 TA) x (32 UB)
-constexpr int kGsThreads = 64 * kGsWaves;
+constexpr int kGsUB = 2;                    // a wave's tile is (32 TA) x (32 UB)
 constexpr int kGsK = 16;                    // reduction depth of a stage = one K step of the matrix instruction
 constexpr int kGsColmaxLds = 1024;          // column maxima are pre-reduced in LDS for Nc up to this (else straight to memory)
 
@@ -269,8 +268,9 @@ struct GemmSplitParams {
 
 // one output tile of ROWS x COLS: 8 waves of (32 TA) x 64, WN = COLS / 64 of them side by side
 // EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss, 3 = masked by Y > 0 (see GemmSplitParams)
-template <int EPI, int TA, int COLS, int NP>
+template <int EPI, int TA, int COLS, int NP, int WAVES>
 __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf, int *s_aexp, unsigned *s_colmax, long long m0, int n0) {
+    constexpr int kGsWaves = WAVES, kGsThreads = 64 * WAVES;
     constexpr int UB = kGsUB, WN = COLS / (32 * UB), WM = kGsWaves / WN;
     constexpr int ROWS = WM * 32 * TA, AQ = (ROWS * 4 + kGsThreads - 1) / kGsThreads;   // float4s of A per thread and stage
     constexpr int PA = NP * 2 * ROWS * 4, PB = NP * 2 * COLS * 4;                       // dwords per stage image
@@ -579,10 +579,14 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     }
 }
 
-template <int EPI, int COLS, int NP>
-__global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitParams p) {
-    constexpr int kSmallRows = (8 / (COLS / 64)) * 32;   // 64 (COLS = 256) or 128 (COLS = 128)
-    constexpr int kBigRows = 256;
+// WAVES = 8: one workgroup per CU (256-row tiles); WAVES = 4: TWO workgroups per CU (128-row tiles, the same 128 x 64 wave
+// tile): the two run out of phase, so one's staging, barriers, pipeline fill and -- above all -- its epilogue (a tile's
+// result stores, plus the aux reads of EPI 2 / 3) overlap the other's matrix instructions.
+template <int EPI, int COLS, int NP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSplitParams p) {
+    constexpr int kGsThreads = 64 * WAVES;
+    constexpr int kSmallRows = (WAVES / (COLS / 64)) * 32;   // WAVES = 8: 64 (COLS = 256) or 128 (COLS = 128); WAVES = 4: half
+    constexpr int kBigRows = 32 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
     __shared__ unsigned s_tile;
@@ -606,16 +610,16 @@ __global__ __launch_bounds__(kGsThreads) void gemm_split_kernel(const GemmSplitP
             break;
         }
         // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2).  Whole rounds of
-        // the chip take 256-row tiles (fewest LDS reads per matrix instruction); what is left over after the last whole
-        // round is cut into 64-row tiles so that it spreads over all CUs instead of giving a few of them a fourth big
+        // the chip take big tiles (fewest LDS reads per matrix instruction); what is left over after the last whole
+        // round is cut into small tiles so that it spreads over all CUs instead of giving a few of them one more big
         // tile (100 000 x 512: 782 big tiles on 256 CUs were 4 tile times for 3.05 rounds of work).
         if (tile < p.n_big) {
             const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
-            gs_tile<EPI, kBigRows / kSmallRows, COLS, NP>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
+            gs_tile<EPI, kBigRows / kSmallRows, COLS, NP, WAVES>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
         } else {
             const unsigned st = tile - p.n_big;
             const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
-            gs_tile<EPI, 1, COLS, NP>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
+            gs_tile<EPI, 1, COLS, NP, WAVES>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
         }
     }
     if (lds_colmax) {   // (every wave of the workgroup passed the loop's barriers after its last LDS maximum)
@@ -755,53 +759,59 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
     p.b_exp = reinterpret_cast<const int *>(p.counter + 16);
     const int cus = cu_count();
-    const int small_rows = cols == 256 ? 64 : 128;
+    // workgroup shape: 4 waves, two workgroups per CU (the default) or 8 waves, one per CU (round 3's; RQHIP_GEMM_WAVES=8 or
+    // tile_rows 256 / 64 for A/B)
+    static const int env_waves = [] { const char *e = getenv("RQHIP_GEMM_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
+    const int tr = a->tile_rows;          // tools only: 8 / 4 = that workgroup shape, tile heights chosen as usual
+    const int waves = (tr == 256 || tr == 64 || tr == 8) ? 8 : (tr == 128 || tr == 32 || tr == 4) ? 4 : env_waves;
+    const int big_rows = 32 * waves;
+    const int small_rows = (waves / (cols / 64)) * 32;
     p.n_col_tiles = Nc / cols;
-    // whole rounds of 256-row tiles, the remainder as 64-row (128-row for the 128-column tile) tiles (see the kernel);
-    // tile_rows (tools only): 256 = big tiles for every row, 64 = small tiles for every row
-    const int big_rows = 256;
-    const long long rt256 = (M + big_rows - 1) / big_rows;
-    long long rt_big = ((rt256 * p.n_col_tiles) / cus) * cus / p.n_col_tiles;   // row tiles of the whole rounds
+    const long long slots = (long long)cus * (waves == 4 ? 2 : 1);
+    // whole rounds of big tiles, the remainder as small tiles (see the kernel);
+    // tile_rows (tools only): 256 / 128 = big tiles for every row, 64 / 32 = small tiles for every row
+    const long long rt_all = (M + big_rows - 1) / big_rows;
+    long long rt_big = ((rt_all * p.n_col_tiles) / slots) * slots / p.n_col_tiles;   // row tiles of the whole rounds
     if (rt_big * big_rows > M) rt_big = M / big_rows;
     // (measured at 100 000 rows: worth it when the leftover is a small part of a round -- Nc = 512: 14 of 256 slots, 517 ->
     // 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
-    if ((rt256 * p.n_col_tiles) % cus > (3 * cus) / 10 && rt256 * p.n_col_tiles >= cus) rt_big = rt256;
-    if (a->tile_rows == 256) rt_big = rt256;
-    if (a->tile_rows == 64) rt_big = 0;
+    if ((rt_all * p.n_col_tiles) % slots > (3 * slots) / 10 && rt_all * p.n_col_tiles >= slots) rt_big = rt_all;
+    if (a->tile_rows == 256 || a->tile_rows == 128) rt_big = rt_all;
+    if (a->tile_rows == 64 || a->tile_rows == 32) rt_big = 0;
     const long long rem_rows = M - rt_big * big_rows > 0 ? M - rt_big * big_rows : 0;
     const long long rt_small = (rem_rows + small_rows - 1) / small_rows;
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
-    const size_t lds = (size_t)2 * (np * 2 * (256 + cols) * 16);
+    const size_t lds = (size_t)2 * (np * 2 * (big_rows + cols) * 16);
     const long long tiles = (long long)p.n_tiles;
-    const long long slots = (long long)cus;                // one workgroup per CU
     const int grid = (int)(tiles < slots ? tiles : slots);
     auto go = [&](auto kern) -> int {
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)lds));   // (+ the static LDS)
         // algorithmic work of the launch: 2 M Nc R FLOP; bytes: A once, C once (+ the aux matrix)
         profile_begin(s, RQHIP_PROF_GEMM_SPLIT, 2.0 * (double)M * Nc * R, 4.0 * (double)M * (R + Nc * (epi >= 2 ? 2 : 1)));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kGsThreads), lds, s, p);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, s, p);
         profile_end(s);
         RQ_CHECK_LAUNCH("gemm_split_kernel");
         return 0;
     };
     int rc;
+#define GS_GO(E, C, P) (waves == 4 ? go(gemm_split_kernel<E, C, P, 4>) : go(gemm_split_kernel<E, C, P, 8>))
     if (np == 2) {
         if (cols == 128)
-            rc = epi == 3 ? go(gemm_split_kernel<3, 128, 2>) : epi == 1 ? go(gemm_split_kernel<1, 128, 2>) : go(gemm_split_kernel<0, 128, 2>);
+            rc = epi == 3 ? GS_GO(3, 128, 2) : epi == 1 ? GS_GO(1, 128, 2) : GS_GO(0, 128, 2);
         else
-            rc = epi == 3 ? go(gemm_split_kernel<3, 256, 2>) : epi == 2 ? go(gemm_split_kernel<2, 256, 2>)
-                 : epi == 1 ? go(gemm_split_kernel<1, 256, 2>) : go(gemm_split_kernel<0, 256, 2>);
+            rc = epi == 3 ? GS_GO(3, 256, 2) : epi == 2 ? GS_GO(2, 256, 2) : epi == 1 ? GS_GO(1, 256, 2) : GS_GO(0, 256, 2);
     } else {
         if (epi == 3) {
             set_error("gemm_split: the masked epilogue exists for RQHIP_SPLIT_F16X2 only");
             return RQHIP_EUNSUPPORTED;
         }
-        if (cols == 128) rc = epi == 1 ? go(gemm_split_kernel<1, 128, 3>) : go(gemm_split_kernel<0, 128, 3>);
-        else rc = epi == 2 ? go(gemm_split_kernel<2, 256, 3>) : epi == 1 ? go(gemm_split_kernel<1, 256, 3>) : go(gemm_split_kernel<0, 256, 3>);
+        if (cols == 128) rc = epi == 1 ? GS_GO(1, 128, 3) : GS_GO(0, 128, 3);
+        else rc = epi == 2 ? GS_GO(2, 256, 3) : epi == 1 ? GS_GO(1, 256, 3) : GS_GO(0, 256, 3);
     }
+#undef GS_GO
     if (rc) return rc;
     if (epi == RQHIP_EPI_RECON) {
         hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,

@@ -562,14 +562,15 @@ def weight_images(jobs, arith: int = F16X2):
         nb = l.rqhip_weight_image_bytes(Nc, R, int(arith))
         if nb == 0:
             raise RqHipError(f"weight_images: unsupported shape {tuple(w.shape)} (transpose={bool(tr)})")
-        sizes.append((nb + 255) // 256 * 256)
+        sizes.append(nb)
     with torch.cuda.device(dev):
-        arena = torch.empty((sum(sizes),), dtype=torch.uint8, device=dev)
+        slots = [(nb + 255) // 256 * 256 for nb in sizes]          # every image 256-byte aligned inside the arena
+        arena = torch.empty((sum(slots),), dtype=torch.uint8, device=dev)
         arr = (_lib.ImageJob * len(jobs))()
         images, off = [], 0
-        for i, (w, (_, tr), nb) in enumerate(zip(ws, jobs, sizes)):
-            img = arena[off:off + nb]
-            off += nb
+        for i, (w, (_, tr), nb, slot) in enumerate(zip(ws, jobs, sizes, slots)):
+            img = arena[off:off + nb]                               # exactly the image: no uninitialised padding in the view
+            off += slot
             arr[i].w, arr[i].rows, arr[i].cols = w.data_ptr(), w.shape[0], w.shape[1]
             arr[i].transpose, arr[i].arith = int(bool(tr)), int(arith)
             arr[i].image, arr[i].image_bytes = img.data_ptr(), nb
