@@ -250,6 +250,7 @@ struct GemmSplitParams {
     // tiles 0 .. n_big - 1 are 256 rows high (rows [0, 256 rt_big)), the rest 64 rows high (from row 256 rt_big on)
     unsigned n_big, n_tiles;
     int rt_big;
+    int stagger;             // gemm_f16_kernel: the second workgroup of a CU starts with a small tile
     unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
     // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
     // rowsum[ct][m] the squared error of row m over column tile ct.  EPI == 3: X is Y, the activation whose ReLU is undone
@@ -265,6 +266,157 @@ struct GemmSplitParams {
     // (atomic maxima: zeroed by the caller) -- the scales of the kernels that read C next
     unsigned *c_rowmax, *c_colmax;
 };
+
+// developer-only phase-skipping probes of gs_tile2 (tools/ab_build.sh <name> gemm_split.hip -DGS_PROBE=<bits>; results are WRONG
+// with any bit set): 1 no stage barriers, 2 no split / LDS writes, 4 no A loads, 8 no B loads, 16 no matrix instructions,
+// 32 no LDS reads of A, 64 A loads in a contiguous pattern (same bytes, wrong values), 128 epilogue loads / stores in a
+// contiguous pattern (same bytes, wrong places -- NEVER with real outputs: it writes C as a flat array of tile blocks)
+#ifndef GS_PROBE
+#define GS_PROBE 0
+#endif
+
+// (probe 128) element offset of float4 number `i4` x 64 + lane of the tile's block in a flat, tile-blocked image of C
+__device__ __forceinline__ size_t gs_probe_flat(const GemmSplitParams &p, long long m0, int n0, int ROWS, int COLS, int i4, int lane) {
+    size_t base = (size_t)m0 * p.Nc + (size_t)(n0 / COLS) * ROWS * COLS;     // row tiles are whole-width blocks of ROWS x Nc
+    if (base + (size_t)ROWS * COLS > (size_t)p.M * p.Nc) base = 0;
+    return base + ((size_t)i4 * 64 + lane) * 4;
+}
+
+// The epilogue of a tile (shared by the tile loops below): undo the scales, apply EPI, store, emit maxima / row losses.
+template <int EPI, int TA, int COLS, int NP, int WAVES>
+__device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 (&acc)[TA][kGsUB], unsigned *sbuf, const int *s_aexp,
+                                            unsigned *s_colmax, long long m0, int n0) {
+    constexpr int kGsThreads = 64 * WAVES;
+    constexpr int UB = kGsUB, WN = COLS / (32 * UB), WM = WAVES / WN, ROWS = WM * 32 * TA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
+    // Column group (u, g) outer, row block t inner: the four columns of a group are finished for all of the lane's rows
+    // before the next group starts, so their column maxima need four registers, not sixty-four; a row's statistics (squared
+    // error, maximum) still accumulate over (u, g, j) ascending -- the order of round 3's row-major epilogue, same bits.
+    // EPI 2 / 3 read X / Y beside every result they store.  The compiler may not move a load above a store that could alias
+    // it, so the aux values of a whole column group are requested before its stores, and the next group's before that.
+    const bool want_rowmax = p.c_rowmax != nullptr, want_colmax = p.c_colmax != nullptr;
+    float rowsq[TA];
+    unsigned rowmx[TA];
+    long long rows[TA];
+    int er[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        rowsq[t] = 0.0f;
+        rowmx[t] = 0u;
+        rows[t] = m0 + 32 * TA * wm + 32 * t + il;
+        er[t] = NP == 2 ? s_aexp[32 * TA * wm + 32 * t + il] : 0;
+    }
+    const int col0 = n0 + 32 * UB * wn + 4 * h;        // + 32 u + 8 g (+ j)
+    constexpr int kAuxDepth = 2;           // column groups whose aux values are in flight ahead of the one being stored
+    gs_f32x4 xv[kAuxDepth + 1][TA];
+    auto load_aux = [&](int ug, gs_f32x4 *dst) {
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+            if (GS_PROBE & 128) dst[t] = *reinterpret_cast<const gs_f32x4 *>(p.X + gs_probe_flat(p, m0, n0, ROWS, COLS, wave * TA * UB * 4 + t * UB * 4 + ug, lane));
+            else dst[t] = *reinterpret_cast<const gs_f32x4 *>(p.X + (size_t)(rows[t] < p.M ? rows[t] : p.M - 1) * p.Nc + col0 + 32 * (ug >> 2) + 8 * (ug & 3));
+    };
+    if (EPI >= 2) {
+#pragma unroll
+        for (int a = 0; a < kAuxDepth; ++a) load_aux(a, xv[a]);
+    }
+#pragma unroll
+    for (int ug = 0; ug < UB * 4; ++ug) {
+        const int u = ug >> 2, g = ug & 3, col = col0 + 32 * u + 8 * g;
+        if (EPI >= 2 && ug + kAuxDepth < UB * 4) load_aux(ug + kAuxDepth, xv[(ug + kAuxDepth) % (kAuxDepth + 1)]);
+        gs_i32x4 ec = {0, 0, 0, 0};
+        if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + col);
+        unsigned cmx[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+            if (NP == 2) {   // undo the row and column scales (exact)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er[t] + ec[j]);
+            }
+            if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
+                v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
+                v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+            }
+            if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
+                const gs_f32x4 x4 = xv[ug % (kAuxDepth + 1)][t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[j] - x4[j];
+                    rowsq[t] = rowsq[t] + d * d;
+                    v[j] = (2.0f * d) * p.row_scale;
+                }
+            }
+            if (EPI == 3) {   // threshold_backward(g, y, 0): 0 where y <= 0
+                const gs_f32x4 y4 = xv[ug % (kAuxDepth + 1)][t];
+                v.x = y4.x <= 0.0f ? 0.0f : v.x; v.y = y4.y <= 0.0f ? 0.0f : v.y;
+                v.z = y4.z <= 0.0f ? 0.0f : v.z; v.w = y4.w <= 0.0f ? 0.0f : v.w;
+            }
+            if (rows[t] < p.M) {
+                if (want_rowmax | want_colmax) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned b = gs_abs_bits(v[j]);
+                        rowmx[t] = gs_umax(rowmx[t], b);
+                        cmx[j] = gs_umax(cmx[j], b);
+                    }
+                }
+                if (GS_PROBE & 128) *reinterpret_cast<gs_f32x4 *>(p.C + gs_probe_flat(p, m0, n0, ROWS, COLS, wave * TA * UB * 4 + t * UB * 4 + ug, lane)) = v;
+                else *reinterpret_cast<gs_f32x4 *>(p.C + (size_t)rows[t] * p.Nc + col) = v;   // (non-temporal stores: +2 ... +36 %)
+            }
+        }
+        if (want_colmax) {   // the 32 rows of the half-wave (DPP: no LDS traffic), then one LDS (or memory) atomic per column
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned m = gs_half_wave_umax(cmx[j]);      // valid in lanes 31 and 63
+                if (il == 31 && m != 0u) {
+                    if (p.Nc <= kGsColmaxLds) atomicMax(&s_colmax[col + j], m);
+                    else atomicMax(p.c_colmax + col + j, m);
+                }
+            }
+        }
+    }
+    if (want_rowmax) {
+        // a row's maximum over this column tile: both lane halves, then the WN column waves through LDS (free: the loop's
+        // last barrier has been passed; EPI 2's `red` lies behind it) -- one part per column tile, one plain store per row
+        unsigned *mred = sbuf + WN * ROWS;                       // [WN][ROWS]
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const unsigned mx = gs_umax(rowmx[t], (unsigned)__shfl_xor((int)rowmx[t], 32, 64));
+            if (h == 0) mred[wn * ROWS + 32 * TA * wm + 32 * t + il] = mx;
+        }
+        __syncthreads();
+        unsigned *dst = p.c_rowmax + (size_t)(n0 / COLS) * p.M;
+        for (int r = tid; r < ROWS; r += kGsThreads) {
+            if (m0 + r >= p.M) continue;
+            unsigned mx = mred[r];
+#pragma unroll
+            for (int w = 1; w < WN; ++w) mx = gs_umax(mx, mred[w * ROWS + r]);
+            dst[m0 + r] = mx;
+        }
+    }
+    if (EPI == 2) {
+        // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
+        // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
+        float *red = reinterpret_cast<float *>(sbuf);          // [WN][ROWS]
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
+            if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
+        }
+        __syncthreads();
+        for (int r = tid; r < ROWS; r += kGsThreads) {
+            if (m0 + r >= p.M) continue;
+            float sum = red[r];
+#pragma unroll
+            for (int w = 1; w < WN; ++w) sum = sum + red[w * ROWS + r];
+            p.rowsum[(size_t)(n0 / COLS) * p.M + m0 + r] = sum;
+        }
+        // (the persistent loop's barrier at its top keeps the next tile's staging off `red`)
+    }
+}
 
 // one output tile of ROWS x COLS: 8 waves of (32 TA) x 64, WN = COLS / 64 of them side by side
 // EPI: 0 = store, 1 = ReLU, 2 = reconstruction loss, 3 = masked by Y > 0 (see GemmSplitParams)
@@ -454,129 +606,160 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         __syncthreads();
     }
 
-    // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
-    // Column group (u, g) outer, row block t inner: the four columns of a group are finished for all of the lane's rows
-    // before the next group starts, so their column maxima need four registers, not sixty-four; a row's statistics (squared
-    // error, maximum) still accumulate over (u, g, j) ascending -- the order of round 3's row-major epilogue, same bits.
-    // EPI 2 / 3 read X / Y beside every result they store.  The compiler may not move a load above a store that could alias
-    // it, so the aux values of a whole column group are requested before its stores, and the next group's before that.
-    const bool want_rowmax = p.c_rowmax != nullptr, want_colmax = p.c_colmax != nullptr;
-    float rowsq[TA];
-    unsigned rowmx[TA];
-    long long rows[TA];
-    int er[TA];
+    gs_epilogue<EPI, TA, COLS, NP, WAVES>(p, acc, sbuf, s_aexp, s_colmax, m0, n0);
+}
+
+// ---- the product tile loop (round 4): f16x2, 256-column tiles, 4 waves side by side (each 32 TA rows x 64 columns) -------------
+// What differs from gs_tile above:
+//   * a wave's weight columns are its own (no other wave of the workgroup multiplies by them), so its B operands go from the
+//     (L2-resident) weight image straight into the matrix instruction's registers, one stage ahead: no LDS round trip for B
+//     (a third of the LDS reads and two thirds of the LDS write bytes of a stage), the LDS holds the split A stage only;
+//   * the A fragments of row block t + 1 are read while the matrix instructions of block t run (two register sets);
+//   * every load is unconditional (rows past M re-read row M - 1 and are never stored): the loop body is ONE basic block,
+//     which lets the scheduler overlap the split arithmetic of the next stage with the matrix instructions of this one.
+// Same products in the same order per accumulator as gs_tile<.., NP = 2, ..>: identical result bits.
+template <int EPI, int TA>
+__device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbuf, int *s_aexp, unsigned *s_colmax, long long m0, int n0) {
+    constexpr int COLS = 256, WAVES = 4, UB = kGsUB, kThreads = 64 * WAVES;
+    constexpr int ROWS = 32 * TA;
+    constexpr int AQ = (ROWS * 4 + kThreads - 1) / kThreads;         // float4s of A per thread and stage (2 for 128 rows, 1 for 32)
+    constexpr bool kAllLive = (ROWS * 4) % kThreads == 0;
+    constexpr int kRegion = ROWS * 4 + 32;                           // dwords per [piece][half] region of the A stage (+ 128 bytes:
+                                                                     // the two halves a ds_write pair of lanes fills land in different banks)
+    constexpr int PA = 4 * kRegion;                                  // dwords per A stage
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int il = lane & 31, h = lane >> 5;
+    const int n_stage = p.R / kGsK;
+    constexpr int APASS = kThreads / 4;
+    const int arow = tid >> 2, akq = tid & 3;
+    const float *asrc[AQ];
+    int a_e[AQ];
+    bool a_live[AQ];
 #pragma unroll
-    for (int t = 0; t < TA; ++t) {
-        rowsq[t] = 0.0f;
-        rowmx[t] = 0u;
-        rows[t] = m0 + 32 * TA * wm + 32 * t + il;
-        er[t] = NP == 2 ? s_aexp[32 * TA * wm + 32 * t + il] : 0;
+    for (int q = 0; q < AQ; ++q) {
+        a_live[q] = kAllLive || arow + APASS * q < ROWS;
+        long long arow_g = m0 + arow + APASS * q;
+        arow_g = arow_g < p.M ? arow_g : p.M - 1;
+        asrc[q] = p.A + (size_t)arow_g * p.R + 4 * akq;
+        unsigned mx = 0u;
+        const unsigned *am = p.a_max + arow_g;
+        for (int part = 0; part < p.a_parts; part += 4) {
+            unsigned v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = am[(size_t)(part + j < p.a_parts ? part + j : part) * p.M];
+            mx = gs_umax(gs_umax(mx, gs_umax(v[0], v[1])), gs_umax(v[2], v[3]));
+        }
+        a_e[q] = gs_exp_of_bits(mx);
+        if (a_live[q] && akq == 0) s_aexp[arow + APASS * q] = a_e[q];   // (read by the epilogue, many barriers later)
     }
-    const int col0 = n0 + 32 * UB * wn + 4 * h;        // + 32 u + 8 g (+ j)
-    constexpr int kAuxDepth = 2;           // column groups whose aux values are in flight ahead of the one being stored
-    gs_f32x4 xv[kAuxDepth + 1][TA];
-    auto load_aux = [&](int ug, gs_f32x4 *dst) {
+
+    gs_f32x16 acc[TA][UB];
 #pragma unroll
-        for (int t = 0; t < TA; ++t)
-            dst[t] = *reinterpret_cast<const gs_f32x4 *>(p.X + (size_t)(rows[t] < p.M ? rows[t] : p.M - 1) * p.Nc + col0 + 32 * (ug >> 2) + 8 * (ug & 3));
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
+
+    // this lane's B elements of a stage: image[stage][pc][h][n0 + 64 wn + 32 u + il]
+    const gs_u32x4 *bsrc = reinterpret_cast<const gs_u32x4 *>(p.planes) + (size_t)h * p.Nc + n0 + 64 * wn + il;
+    const size_t b_stage = (size_t)4 * p.Nc, b_piece = (size_t)2 * p.Nc;
+    gs_f32x4 ra0[AQ], ra1[AQ];
+    gs_u32x4 fb0[UB][2], fb1[UB][2];
+    auto fetchA = [&](int stage, gs_f32x4 *dst) {
+        stage = stage < n_stage ? stage : n_stage - 1;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            if (GS_PROBE & 4) dst[q] = gs_f32x4{1.f + stage, 2.f, 3.f, 4.f};
+            else if (GS_PROBE & 64) {   // the strip of ROWS whole rows is one contiguous block: stage s takes its s-th ROWS x 64 bytes
+                size_t o = (size_t)m0 * p.R + (size_t)stage * ROWS * kGsK + (size_t)(tid + kThreads * q) * 4;
+                if (o + 4 > (size_t)p.M * p.R) o = 0;
+                dst[q] = *reinterpret_cast<const gs_f32x4 *>(p.A + o);
+            }
+            else dst[q] = *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK);
+        }
     };
-    if (EPI >= 2) {
+    auto fetchB = [&](int stage, gs_u32x4 (*dst)[2]) {
+        stage = stage < n_stage ? stage : n_stage - 1;
+        const gs_u32x4 *img = bsrc + (size_t)stage * b_stage;
 #pragma unroll
-        for (int a = 0; a < kAuxDepth; ++a) load_aux(a, xv[a]);
-    }
+        for (int u = 0; u < UB; ++u)
 #pragma unroll
-    for (int ug = 0; ug < UB * 4; ++ug) {
-        const int u = ug >> 2, g = ug & 3, col = col0 + 32 * u + 8 * g;
-        if (EPI >= 2 && ug + kAuxDepth < UB * 4) load_aux(ug + kAuxDepth, xv[(ug + kAuxDepth) % (kAuxDepth + 1)]);
-        gs_i32x4 ec = {0, 0, 0, 0};
-        if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + col);
-        unsigned cmx[4] = {0u, 0u, 0u, 0u};
+            for (int pc = 0; pc < 2; ++pc) {
+                if (GS_PROBE & 8) dst[u][pc] = gs_u32x4{(unsigned)stage, 1u, 2u, 3u};
+                else dst[u][pc] = img[(size_t)pc * b_piece + 32 * u];
+            }
+    };
+    auto stash = [&](int buf, const gs_f32x4 *ra) {
+        unsigned *dA = sbuf + buf * PA;
+        if (GS_PROBE & 2) return;
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            if (!kAllLive && !a_live[q]) continue;
+            unsigned h01, m01, h23, m23;
+            gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
+            gs_split2_f16(ldexpf(ra[q].z, -a_e[q]), ldexpf(ra[q].w, -a_e[q]), h23, m23);
+            // region [piece][half = akq >> 1], element [row] = 16 bytes (r 8 half .. 8 half + 7); this thread fills its 8 bytes
+            unsigned *d = dA + (akq >> 1) * kRegion + (arow + APASS * q) * 4 + 2 * (akq & 1);
+            *reinterpret_cast<gs_u32x2 *>(d) = gs_u32x2{h01, h23};
+            *reinterpret_cast<gs_u32x2 *>(d + 2 * kRegion) = gs_u32x2{m01, m23};
+        }
+    };
+    auto loadA = [&](int buf, int t, gs_f16x8 *fa) {
+        const gs_u32x4 *aA = reinterpret_cast<const gs_u32x4 *>(sbuf + buf * PA);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            if (GS_PROBE & 32) fa[pc] = gs_f16x8{(_Float16)(float)(t + buf), 1, 2, 3, 4, 5, 6, 7};
+            else fa[pc] = __builtin_bit_cast(gs_f16x8, aA[(pc * 2 + h) * (kRegion / 4) + 32 * t + il]);
+        }
+    };
+    auto multiply = [&](int buf, const gs_u32x4 (*fbr)[2]) {
+        gs_f16x8 fa[2][2];
+        loadA(buf, 0, fa[0]);
 #pragma unroll
         for (int t = 0; t < TA; ++t) {
-            gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
-            if (NP == 2) {   // undo the row and column scales (exact)
+            if (t + 1 < TA) loadA(buf, t + 1, fa[(t + 1) & 1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er[t] + ec[j]);
-            }
-            if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
-                v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
-                v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
-            }
-            if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
-                const gs_f32x4 x4 = xv[ug % (kAuxDepth + 1)][t];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = v[j] - x4[j];
-                    rowsq[t] = rowsq[t] + d * d;
-                    v[j] = (2.0f * d) * p.row_scale;
+            for (int u = 0; u < UB; ++u) {
+                const gs_f16x8 bh = __builtin_bit_cast(gs_f16x8, fbr[u][0]), bm = __builtin_bit_cast(gs_f16x8, fbr[u][1]);
+                gs_f32x16 c16 = acc[t][u];
+                if (GS_PROBE & 16) {   // (keeps every operand alive without the matrix pipe)
+                    c16[0] += (float)bh[0] + (float)bm[1] + (float)fa[t & 1][0][2] + (float)fa[t & 1][1][3];
+                } else {
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, fa[t & 1][1], c16, 0, 0, 0);   // m h (smallest first)
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bm, fa[t & 1][0], c16, 0, 0, 0);   // h m
+                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, fa[t & 1][0], c16, 0, 0, 0);   // h h
                 }
-            }
-            if (EPI == 3) {   // threshold_backward(g, y, 0): 0 where y <= 0
-                const gs_f32x4 y4 = xv[ug % (kAuxDepth + 1)][t];
-                v.x = y4.x <= 0.0f ? 0.0f : v.x; v.y = y4.y <= 0.0f ? 0.0f : v.y;
-                v.z = y4.z <= 0.0f ? 0.0f : v.z; v.w = y4.w <= 0.0f ? 0.0f : v.w;
-            }
-            if (rows[t] < p.M) {
-                if (want_rowmax | want_colmax) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned b = gs_abs_bits(v[j]);
-                        rowmx[t] = gs_umax(rowmx[t], b);
-                        cmx[j] = gs_umax(cmx[j], b);
-                    }
-                }
-                *reinterpret_cast<gs_f32x4 *>(p.C + (size_t)rows[t] * p.Nc + col) = v;   // (non-temporal stores: +2 ... +36 %)
+                acc[t][u] = c16;
             }
         }
-        if (want_colmax) {   // the 32 rows of the half-wave (DPP: no LDS traffic), then one LDS (or memory) atomic per column
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned m = gs_half_wave_umax(cmx[j]);      // valid in lanes 31 and 63
-                if (il == 31 && m != 0u) {
-                    if (p.Nc <= kGsColmaxLds) atomicMax(&s_colmax[col + j], m);
-                    else atomicMax(p.c_colmax + col + j, m);
-                }
-            }
-        }
+    };
+
+    fetchA(0, ra0);
+    fetchB(0, fb0);
+    fetchA(1, ra1);
+    stash(0, ra0);
+    fetchB(1, fb1);
+    fetchA(2, ra0);
+    __syncthreads();
+    const int n_pair = n_stage & ~1;
+    for (int c = 0; c < n_pair; c += 2) {
+        stash(1, ra1);                             // stage c + 1
+        fetchA(c + 3, ra1);
+        multiply(0, fb0);
+        fetchB(c + 2, fb0);
+        if (!(GS_PROBE & 1)) __syncthreads();
+        stash(0, ra0);                             // stage c + 2 (past the end: the last stage again, never multiplied)
+        fetchA(c + 4, ra0);
+        multiply(1, fb1);
+        fetchB(c + 3, fb1);
+        if (!(GS_PROBE & 1)) __syncthreads();
     }
-    if (want_rowmax) {
-        // a row's maximum over this column tile: both lane halves, then the WN column waves through LDS (free: the loop's
-        // last barrier has been passed; EPI 2's `red` lies behind it) -- one part per column tile, one plain store per row
-        unsigned *mred = sbuf + WN * ROWS;                       // [WN][ROWS]
-#pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const unsigned mx = gs_umax(rowmx[t], (unsigned)__shfl_xor((int)rowmx[t], 32, 64));
-            if (h == 0) mred[wn * ROWS + 32 * TA * wm + 32 * t + il] = mx;
-        }
+    if (n_stage & 1) {                             // the last stage of an odd count lies in buffer 0
+        multiply(0, fb0);
         __syncthreads();
-        unsigned *dst = p.c_rowmax + (size_t)(n0 / COLS) * p.M;
-        for (int r = tid; r < ROWS; r += kGsThreads) {
-            if (m0 + r >= p.M) continue;
-            unsigned mx = mred[r];
-#pragma unroll
-            for (int w = 1; w < WN; ++w) mx = gs_umax(mx, mred[w * ROWS + r]);
-            dst[m0 + r] = mx;
-        }
     }
-    if (EPI == 2) {
-        // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
-        // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
-        float *red = reinterpret_cast<float *>(sbuf);          // [WN][ROWS]
-#pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
-            if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
-        }
-        __syncthreads();
-        for (int r = tid; r < ROWS; r += kGsThreads) {
-            if (m0 + r >= p.M) continue;
-            float sum = red[r];
-#pragma unroll
-            for (int w = 1; w < WN; ++w) sum = sum + red[w * ROWS + r];
-            p.rowsum[(size_t)(n0 / COLS) * p.M + m0 + r] = sum;
-        }
-        // (the persistent loop's barrier at its top keeps the next tile's staging off `red`)
-    }
+    gs_epilogue<EPI, TA, COLS, 2, WAVES>(p, acc, sbuf, s_aexp, s_colmax, m0, n0);
 }
 
 // WAVES = 8: one workgroup per CU (256-row tiles); WAVES = 4: TWO workgroups per CU (128-row tiles, the same 128 x 64 wave
@@ -624,6 +807,73 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSpl
     }
     if (lds_colmax) {   // (every wave of the workgroup passed the loop's barriers after its last LDS maximum)
         for (int c = tid; c < p.Nc; c += kGsThreads)
+            if (s_colmax[c]) atomicMax(p.c_colmax + c, s_colmax[c]);
+    }
+}
+
+// The product kernel: gs_tile2 tiles of 128 rows (and 64-row tiles for the stagger and the leftover), 4 waves, TWO persistent
+// workgroups per CU.  Equal workgroups that start together stay in step -- both would compute, then both would store.  So the
+// second workgroup of every CU (the one whose LDS allocation does not start at 0) begins with a half-height tile: from then on
+// one workgroup's epilogue (a tile's result stores, the aux reads of EPI 2 / 3), tile prologue and barriers fall into the
+// other's matrix instructions.  Two dispensers: counter[0] big tiles, counter[2] small tiles (the late workgroups' first tile,
+// then whoever runs out of big tiles); counter[1] counts the workgroups that have left (the last one re-arms all three).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams p) {
+    constexpr int kThreads = 256, kBigRows = 128, kSmallRows = 64, COLS = 256;
+    constexpr unsigned kSmallBit = 0x80000000u, kNone = 0xffffffffu;
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
+    __shared__ unsigned s_tile;
+    __shared__ int s_aexp[kBigRows];
+    __shared__ unsigned s_colmax[kGsColmaxLds];
+    const int tid = threadIdx.x;
+    const bool lds_colmax = p.c_colmax != nullptr && p.Nc <= kGsColmaxLds;
+    if (lds_colmax)
+        for (int c = tid; c < p.Nc; c += kThreads) s_colmax[c] = 0u;
+    const unsigned n_small = p.n_tiles - p.n_big;
+    // HW_REG_LDS_ALLOC (id 6), LDS_BASE = bits 7:0: zero for the first workgroup placed on a CU
+    bool late_start = p.stagger && (__builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xff) != 0;
+    for (;;) {
+        __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
+        if (tid == 0) {
+            unsigned t = kNone;
+            if (late_start) {
+                const unsigned i = atomicAdd(p.counter + 2, 1u);
+                if (i < n_small) t = i | kSmallBit;
+            }
+            if (t == kNone) {
+                const unsigned i = atomicAdd(p.counter, 1u);
+                if (i < p.n_big) t = i;
+            }
+            if (t == kNone && !late_start) {
+                const unsigned i = atomicAdd(p.counter + 2, 1u);
+                if (i < n_small) t = i | kSmallBit;
+            }
+            s_tile = t;
+        }
+        late_start = false;
+        __syncthreads();
+        const unsigned tile = s_tile;
+        if (tile == kNone) {
+            if (tid == 0 && atomicAdd(p.counter + 1, 1u) == gridDim.x - 1) {
+                p.counter[0] = 0u;
+                p.counter[1] = 0u;
+                p.counter[2] = 0u;
+            }
+            break;
+        }
+        // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2)
+        if (!(tile & kSmallBit)) {
+            const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+            gs_tile2<EPI, kBigRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
+        } else {
+            const unsigned st = tile & ~kSmallBit;
+            const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
+            gs_tile2<EPI, kSmallRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
+        }
+    }
+    if (lds_colmax) {   // (every wave of the workgroup passed the loop's barriers after its last LDS maximum)
+        for (int c = tid; c < p.Nc; c += kThreads)
             if (s_colmax[c]) atomicMax(p.c_colmax + c, s_colmax[c]);
     }
 }
@@ -763,9 +1013,13 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     // tile_rows 256 / 64 for A/B)
     static const int env_waves = [] { const char *e = getenv("RQHIP_GEMM_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
     const int tr = a->tile_rows;          // tools only: 8 / 4 = that workgroup shape, tile heights chosen as usual
-    const int waves = (tr == 256 || tr == 64 || tr == 8) ? 8 : (tr == 128 || tr == 32 || tr == 4) ? 4 : env_waves;
+    const int waves = (tr == 256 || tr == 64 || tr == 8) ? 8 : (tr == 128 || tr == 32 || tr == 4 || tr == 2 || tr == 3) ? 4 : env_waves;
+    // the product loop (gs_tile2: B operands straight from the image, A fragments prefetched): f16x2, 256-column tiles, 4 waves;
+    // RQHIP_GEMM_TILE2=0 or a tile_rows code other than 0 / 2 keeps the staged-B loop for A/B
+    static const bool env_tile2 = [] { const char *e = getenv("RQHIP_GEMM_TILE2"); return !(e && atoi(e) == 0); }();
+    const bool tile2 = np == 2 && cols == 256 && waves == 4 && (tr == 2 || tr == 3 || (tr == 0 && env_tile2));   // (3: without the stagger)
     const int big_rows = 32 * waves;
-    const int small_rows = (waves / (cols / 64)) * 32;
+    const int small_rows = tile2 ? 64 : (waves / (cols / 64)) * 32;
     p.n_col_tiles = Nc / cols;
     const long long slots = (long long)cus * (waves == 4 ? 2 : 1);
     // whole rounds of big tiles, the remainder as small tiles (see the kernel);
@@ -773,17 +1027,30 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     const long long rt_all = (M + big_rows - 1) / big_rows;
     long long rt_big = ((rt_all * p.n_col_tiles) / slots) * slots / p.n_col_tiles;   // row tiles of the whole rounds
     if (rt_big * big_rows > M) rt_big = M / big_rows;
-    // (measured at 100 000 rows: worth it when the leftover is a small part of a round -- Nc = 512: 14 of 256 slots, 517 ->
-    // 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
+    p.stagger = 0;
+    // (measured at 100 000 rows: cutting the leftover into small tiles is worth it when it is a small part of a round -- Nc = 512:
+    // 14 of 256 slots, 517 -> 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
     if ((rt_all * p.n_col_tiles) % slots > (3 * slots) / 10 && rt_all * p.n_col_tiles >= slots) rt_big = rt_all;
-    if (a->tile_rows == 256 || a->tile_rows == 128) rt_big = rt_all;
-    if (a->tile_rows == 64 || a->tile_rows == 32) rt_big = 0;
+    if (tile2) {
+        // gemm_f16_kernel's stagger (RQHIP_GEMM_STAGGER=1 or tile_rows 2; off by default: measured neutral to -7 %, tools/gemm_wg_ab.py):
+        // with two rounds of work or more, half a round of it goes into small tiles -- one for the late workgroup of every CU to
+        // start with, as many for the early ones to end with -- plus what is left over
+        static const bool env_stagger = [] { const char *e = getenv("RQHIP_GEMM_STAGGER"); return e && atoi(e) == 1; }();
+        const long long rounds = (rt_all * p.n_col_tiles) / slots;
+        if (rounds >= 2 && (tr == 2 || (tr == 0 && env_stagger))) {
+            p.stagger = 1;
+            rt_big = (rounds * slots - slots / 2) / p.n_col_tiles;
+        }
+    } else {
+        if (a->tile_rows == 256 || a->tile_rows == 128) rt_big = rt_all;
+        if (a->tile_rows == 64 || a->tile_rows == 32) rt_big = 0;
+    }
     const long long rem_rows = M - rt_big * big_rows > 0 ? M - rt_big * big_rows : 0;
     const long long rt_small = (rem_rows + small_rows - 1) / small_rows;
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
-    const size_t lds = (size_t)2 * (np * 2 * (big_rows + cols) * 16);
+    const size_t lds = tile2 ? (size_t)2 * 4 * (128 * 4 + 32) * 4 : (size_t)2 * (np * 2 * (big_rows + cols) * 16);
     const long long tiles = (long long)p.n_tiles;
     const int grid = (int)(tiles < slots ? tiles : slots);
     auto go = [&](auto kern) -> int {
@@ -798,7 +1065,10 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     };
     int rc;
 #define GS_GO(E, C, P) (waves == 4 ? go(gemm_split_kernel<E, C, P, 4>) : go(gemm_split_kernel<E, C, P, 8>))
-    if (np == 2) {
+#define GS_GO2(E) go(gemm_f16_kernel<E>)
+    if (tile2) {
+        rc = epi == 3 ? GS_GO2(3) : epi == 2 ? GS_GO2(2) : epi == 1 ? GS_GO2(1) : GS_GO2(0);
+    } else if (np == 2) {
         if (cols == 128)
             rc = epi == 3 ? GS_GO(3, 128, 2) : epi == 1 ? GS_GO(1, 128, 2) : GS_GO(0, 128, 2);
         else
@@ -812,6 +1082,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         else rc = epi == 2 ? GS_GO(2, 256, 3) : epi == 1 ? GS_GO(1, 256, 3) : GS_GO(0, 256, 3);
     }
 #undef GS_GO
+#undef GS_GO2
     if (rc) return rc;
     if (epi == RQHIP_EPI_RECON) {
         hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,

@@ -28,7 +28,7 @@ def timeit(fn, n=20):
 
 
 g = torch.Generator().manual_seed(3)
-print(f"{'R -> Nc  epilogue':>26} | " + " ".join(f"{c:>9}" for c in ("w8 auto", "w8 big", "w4 auto", "w4 big", "w4 small")) + " | bits equal")
+print(f"{'R -> Nc  epilogue':>26} | " + " ".join(f"{c:>9}" for c in ("w4 staged", "direct", "direct+stagger")) + " | bits equal")
 for R, Nc in ((768, 512), (512, 768), (512, 256), (256, 512), (128, 256), (256, 768)):
     a = torch.randn(M, R, generator=g).cuda()
     w = (torch.randn(Nc, R, generator=g) / R ** 0.5).cuda()
@@ -39,7 +39,7 @@ for R, Nc in ((768, 512), (512, 768), (512, 256), (256, 512), (128, 256), (256, 
         if epi == _lib.EPI_RECON and Nc % 256:
             continue
         outs, ts = [], []
-        for tr in (8, 256, 4, 128, 32):
+        for tr in (4, 3, 2):
             def run(tr=tr):
                 cm = torch.zeros((Nc,), dtype=torch.int32, device="cuda")
                 return ops.gemm_split_ex(a, img, Nc, epilogue=epi, aux=aux if epi >= _lib.EPI_RECON else None, row_scale=1e-5,
