@@ -379,6 +379,51 @@ def gen_config3_step(q, r, km, sch):
     np.savez_compressed(os.path.join(OUT, "config3_step.npz"), **save)
 
 
+def gen_wide(q, km):
+    """Shapes / mode combinations the HIP kernels do not cover (rq-vae-recommender_amd/rqhip/wide.py runs them as PyTorch-ROCm
+    operators): COSINE x GUMBEL_SOFTMAX (quantize.py:118-136), embed_dim > 128, Gumbel-softmax with more than 1024 codes,
+    k-means on rows wider than 128.  The uniform noise is recorded as in gen_gumbel."""
+    cases = [("cosine_gumbel", 24, 16, 20, 71, q.QuantizeForwardMode.GUMBEL_SOFTMAX, q.QuantizeDistance.COSINE, True, 0.5),
+             ("d160_ste", 21, 160, 40, 72, q.QuantizeForwardMode.STE, q.QuantizeDistance.L2, True, 0.2),
+             ("d160_rotation", 9, 160, 40, 73, q.QuantizeForwardMode.ROTATION_TRICK, q.QuantizeDistance.L2, True, 0.2),
+             ("d160_eval", 17, 160, 40, 74, q.QuantizeForwardMode.STE, q.QuantizeDistance.L2, False, 0.2),
+             ("gumbel_k1100", 12, 8, 1100, 75, q.QuantizeForwardMode.GUMBEL_SOFTMAX, q.QuantizeDistance.L2, True, 0.3)]
+    for tag, B, D, K, seed, fm, dm, training, T in cases:
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, D, generator=g) * 0.5
+        cb = torch.randn(K, D, generator=g) * torch.rand(K, 1, generator=g).add(0.3)
+        layer = q.Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=fm, distance_mode=dm,
+                           commitment_weight=0.25)
+        with torch.no_grad():
+            layer.embedding.weight.copy_(cb)
+        layer.train(training)
+        xr = x.clone().requires_grad_(True)
+        torch.manual_seed(1000 + seed)
+        out = layer(xr, temperature=T)
+        torch.manual_seed(1000 + seed)
+        U = torch.rand(B, K)
+        g_emb = torch.randn(B, D, generator=g)
+        g_loss = torch.rand(B, generator=g)
+        (out.embeddings * g_emb).sum().add((out.loss * g_loss).sum()).backward()
+        np.savez_compressed(
+            os.path.join(OUT, f"wide_{tag}.npz"),
+            x=np32(x), codebook=np32(cb), U=np32(U), temperature=np.float32(T), training=np.bool_(training),
+            mode=np.int64(fm.value), cosine=np.bool_(dm == q.QuantizeDistance.COSINE),
+            ids=out.ids.numpy().astype(np.int64), embeddings=np32(out.embeddings), loss=np32(out.loss),
+            g_emb=np32(g_emb), g_loss=np32(g_loss), grad_x=np32(xr.grad),
+            grad_codebook=np32(layer.embedding.weight.grad))
+    # k-means on 160-wide rows (kmeans.py:61-72), seeds as in gen_kmeans
+    B, D, K, seed = 240, 160, 6, 76
+    g = torch.Generator().manual_seed(seed)
+    centers = torch.randn(K, D, generator=g) * 2.0
+    x = centers[torch.randint(0, K, (B,), generator=g)] + 0.3 * torch.randn(B, D, generator=g)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    out = km.Kmeans(k=K).run(x.clone())
+    np.savez_compressed(os.path.join(OUT, "wide_kmeans_d160.npz"), x=np32(x), k=np.int64(K), seed=np.int64(seed),
+                        centroids=np32(out.centroids), assignment=out.assignment.numpy().astype(np.int64))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -389,9 +434,13 @@ def main():
     if "--only-config3" in sys.argv:
         gen_config3_step(q, r, km, sch)
         return
+    if "--only-wide" in sys.argv:
+        gen_wide(q, km)
+        return
     gen_quantize(q)
     gen_gumbel(q)
     gen_cosine(q)
+    gen_wide(q, km)
     gen_rqvae(q, r, sch)
     gen_kmeans(km)
     gen_dedup(q, r, sem, sch)

@@ -9,7 +9,7 @@
 //
 // Two arithmetics behind one kernel template (`NP` = pieces per operand):
 //   NP = 2  RQHIP_SPLIT_F16X2 (the product path, round 4): every row of A and every row of B is scaled by an EXACT power of two
-//           (2^-e, e = exponent of the row's largest |value|: the scaled row has its maximum in [1, 2)), every scaled value is
+//           (2^-e, e = exponent of the row's largest |value| - 14: the scaled row has its maximum in [2^14, 2^15), the top of fp16's range), every scaled value is
 //           split into two fp16 pieces h = RN16(v), m = RN16(v - h) (11 + 11 significant bits and a sign: v - h - m is 0 or
 //           +-2^-23 of the row maximum's binade), the product is hh + hm + mh -- three v_mfma_f32_32x32x16_f16 (products of two
 //           fp16 values are exact in fp32, accumulation in fp32; dropped: mm <= 2^-22 of a product) -- and the epilogue
@@ -69,11 +69,16 @@ __device__ __forceinline__ void gs_split2_f16(float a, float b, unsigned &h, uns
     const gs_f16x2 mm = __builtin_convertvector(gs_f32x2{a - hf.x, b - hf.y}, gs_f16x2);
     m = __builtin_bit_cast(unsigned, mm);
 }
-// floor(log2) of the positive float with these bits; 0 for 0 / inf / nan (such rows are not scaled)
+// The scale exponent of a row / column whose largest |value| has these bits: the row is multiplied by 2^-e, which puts its maximum
+// into [2^14, 2^15) -- the top of fp16's range (largest finite value 65504) -- so that the low piece m = RN16(v - h) of every entry
+// down to 2^-16 of the row maximum is still a NORMAL-precision fp16 number (spacing of fp16 subnormals: 2^-24; with the maximum
+// in [1, 2), round 4's first form, entries below a quarter of the maximum already lost bits of their low piece).
+// 0 for 0 / inf / nan (such rows are not scaled).
+constexpr int kGsF16Top = 14;
 __device__ __forceinline__ int gs_exp_of_bits(unsigned b) {
     b &= 0x7fffffffu;
     const int e = (int)(b >> 23);
-    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127);
+    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127) - kGsF16Top;
 }
 __device__ __forceinline__ unsigned gs_abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
 // max of the bit patterns of |values| == bit pattern of the largest |value| for everything that is not a NaN; a NaN wins

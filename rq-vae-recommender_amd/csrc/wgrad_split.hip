@@ -15,7 +15,7 @@
 //
 // Round 4, the product path (NP = 2, rqhip_linear_wgrad_f16): TWO fp16 pieces per operand and the three products hh + hm + mh
 // (csrc/gemm_split.hip, RQHIP_SPLIT_F16X2).  The reduction runs over the batch rows, so the exact power-of-two scale has to be
-// constant along them: every COLUMN of g_pre and of x is multiplied by 2^-e, e = exponent of the column's largest |value| (from
+// constant along them: every COLUMN of g_pre and of x is multiplied by 2^-e, e = exponent of the column's largest |value| - 14 (from
 // the epilogue that wrote the matrix, or rqhip_maxima), and dW[n, k] is multiplied back by 2^(e_n + e_k).  Half the matrix
 // instructions, two thirds of the LDS bytes; error against fp64 below the three-piece kernel's (tests/test_gpu_wgrad.py).
 //
@@ -73,10 +73,12 @@ __device__ __forceinline__ void ws_split2_f16(float a, float b, unsigned &h, uns
     const ws_f16x2 mm = __builtin_convertvector(ws_f32x2{a - hf.x, b - hf.y}, ws_f16x2);
     m = __builtin_bit_cast(unsigned, mm);
 }
-__device__ __forceinline__ int ws_exp_of_bits(unsigned b) {   // floor(log2) of the positive float with these bits; 0 for 0 / inf / nan
+// the scale exponent of a column whose largest |value| has these bits (csrc/gemm_split.hip:gs_exp_of_bits: the scaled maximum lies in
+// [2^14, 2^15), the top of fp16's range); 0 for 0 / inf / nan
+__device__ __forceinline__ int ws_exp_of_bits(unsigned b) {
     b &= 0x7fffffffu;
     const int e = (int)(b >> 23);
-    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127);
+    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127) - 14;
 }
 
 // TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given; NP: pieces per operand (3 bf16 / 2 fp16 under column scales)

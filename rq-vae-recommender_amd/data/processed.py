@@ -84,10 +84,10 @@ class ItemData(Dataset):
         elif train_test_split == "eval":
             keep = ~is_train
         elif train_test_split == "all":
-            keep = torch.ones_like(is_train, dtype=torch.bool)
+            keep = None            # every row: the matrix itself, no masked copy (10 M x 768 fp32 is 30.7 GB)
         else:
             raise ValueError(f"unknown train_test_split {train_test_split!r}")
-        self.item_data = item_matrix[keep.to(item_matrix.device)]
+        self.item_data = item_matrix if keep is None else item_matrix[keep.to(item_matrix.device)]
 
     def to_device(self, device) -> "ItemData":
         """Make the feature matrix resident on `device` (HBM); later `ds[idx]` gathers happen there."""

@@ -20,7 +20,7 @@ import torch
 
 import torch.distributed as dist
 
-from rqhip import ops
+from rqhip import ops, wide
 
 
 def kmeans_init_(tensor: torch.Tensor, x: torch.Tensor, rows_sharded: bool = False) -> None:
@@ -59,8 +59,12 @@ class Kmeans:
     def _update_centroids(self, x: torch.Tensor) -> float:
         """One Lloyd step (assign + update + reseed of empty clusters); returns the max centroid shift."""
         before = self.centroids.clone()
-        assign = ops.kmeans_assign(x, self.centroids)
-        counts, shift_sq = ops.kmeans_update(x, assign, self.centroids)
+        if wide.kmeans_covers(x.shape[1]):
+            assign = ops.kmeans_assign(x, self.centroids)
+            counts, shift_sq = ops.kmeans_update(x, assign, self.centroids)
+        else:   # D > 128: the same step as PyTorch-ROCm operators (rqhip/wide.py)
+            assign, counts = wide.kmeans_update(x, self.centroids)
+            shift_sq = ((self.centroids - before) ** 2).sum(dim=1).max()
         any_empty, shift_sq = torch.stack([(counts == 0).any().to(torch.float32), shift_sq]).tolist()  # one sync
         shift = float(np.sqrt(np.float32(shift_sq)))
         if any_empty:
@@ -79,9 +83,13 @@ class Kmeans:
 
     def run(self, x: torch.Tensor, sharded: bool = False) -> KmeansOutput:
         if sharded:
+            if not wide.kmeans_covers(x.shape[1]):
+                raise ops.RqHipError(f"row-sharded k-means needs the HIP kernels (latent width {x.shape[1]} > 128)")
             return self._run_sharded(x)
         x = x.detach().to(torch.float32).contiguous()
         self._init_centroids(x)
+        if not wide.kmeans_covers(x.shape[1]):
+            return self._run_stepwise(x)
         B = x.shape[0]
         dev = x.device
         assign = torch.empty((B,), dtype=torch.int64, device=dev)
@@ -113,6 +121,19 @@ class Kmeans:
                 continue
             i += ran             # the whole batch ran without converging
         self.assignment = assign
+        return KmeansOutput(centroids=self.centroids, assignment=self.assignment)
+
+    def _run_stepwise(self, x: torch.Tensor) -> KmeansOutput:
+        """The reference's loop (kmeans.py:61-72), one `_update_centroids` per iteration: latent widths the batched kernels do
+        not take (D > 128)."""
+        wide._note(f"Kmeans on {x.shape[1]}-wide rows")
+        if x.shape[0] == 0:
+            raise ValueError("Can not choose random element from x, x is empty")
+        i = 0
+        while self.iters is None or i < self.iters:
+            if self._update_centroids(x) < self.stop_threshold:
+                break
+            i += 1
         return KmeansOutput(centroids=self.centroids, assignment=self.assignment)
 
     # ---- row-sharded run (one process per GPU, torch.distributed) ---------------------------------------------

@@ -7,7 +7,9 @@ gather, STE / rotation-trick / Gumbel-softmax output and the quantize loss are O
 through the C ABI of include/rqhip.h.  `RqVae` does not even call this per level: it hands all its levels to
 the same kernel at once (modules/rqvae.py); `Quantize.forward` is that kernel with L = 1.
 
-There is no CPU implementation: tensors must live on a ROCm device (rqhip.RqHipError otherwise).
+There is no CPU implementation: tensors must live on a ROCm device (rqhip.RqHipError otherwise).  Shapes the kernels do not
+keep on chip (embed_dim > 128; Gumbel-softmax with more than 1024 codes) and COSINE x GUMBEL_SOFTMAX run the reference's
+expression as PyTorch-ROCm operators on the same device tensors (rqhip/wide.py), with a one-time warning.
 """
 from enum import Enum
 from typing import NamedTuple
@@ -18,7 +20,7 @@ from torch import Tensor, nn
 from init.kmeans import kmeans_init_
 from modules.loss import QuantizeLoss
 from modules.normalize import L2NormalizationLayer
-from rqhip import MODE_EVAL, MODE_ROTATION, MODE_STE
+from rqhip import MODE_EVAL, MODE_ROTATION, MODE_STE, wide
 from rqhip.autograd import GumbelLevelFunction, RqStackFunction
 
 try:
@@ -105,6 +107,12 @@ class Quantize(nn.Module):
         """True when out_proj is the identity (all shipped configs)."""
         return all(isinstance(m, nn.Identity) for m in self.out_proj)
 
+    def kernel_covers(self) -> bool:
+        """Do the HIP kernels take this level's shape in its current mode?  (else: rqhip/wide.py)"""
+        if self.training and self.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
+            return self.distance_mode == QuantizeDistance.L2 and wide.gumbel_covers(self.embed_dim, self.n_embed)
+        return wide.stack_covers(self.embed_dim, self.n_embed)
+
     def codebook(self) -> Tensor:
         """out_proj(embedding.weight): the [K,D] matrix distances are taken against (quantize.py:110)."""
         return self.embedding.weight if self.plain_codebook else self.out_proj(self.embedding.weight)
@@ -126,7 +134,7 @@ class Quantize(nn.Module):
     def get_item_embeddings(self, item_ids: Tensor) -> Tensor:
         return self.out_proj(self.embedding(item_ids))
 
-    def _forward_cosine(self, x: Tensor) -> QuantizeOutput:
+    def _forward_cosine(self, x: Tensor, temperature: float) -> QuantizeOutput:
         """QuantizeDistance.COSINE (reference quantize.py:118-124; RqVae never selects it).  The argmin of
         -(x/|x|).c_k/|c_k| runs on the HIP kernel as the nearest unit codeword of the unit query (for unit vectors
         |a-b|^2 = 2 - 2 a.b, the same ordering); everything after the ids -- gather, STE / rotation output, loss --
@@ -134,9 +142,10 @@ class Quantize(nn.Module):
         Near-tie caveat: the kernel ranks by (|xn|^2 + |cn_k|^2) - 2 xn.cn_k, where |cn_k|^2 is 1 up to an ulp PER CODE,
         while the reference ranks by -(xn.cn_k) alone; two codes whose cosines differ by less than ~1e-7 can therefore
         be ordered differently (the same class of sub-ulp ties as tests/parity_gate.py describes for the L2 path).
-        GUMBEL_SOFTMAX with COSINE has no accelerated path and raises NotImplementedError."""
-        if self.training and self.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
-            raise NotImplementedError("COSINE distance with GUMBEL_SOFTMAX has no accelerated path")
+        GUMBEL_SOFTMAX with COSINE (softmax over the cosines, gradient through both normalisations) has no kernel: the
+        reference's expression in PyTorch-ROCm operators (rqhip/wide.py)."""
+        if (self.training and self.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX) or not wide.stack_covers(self.embed_dim, self.n_embed):
+            return QuantizeOutput(*wide.quantize_forward(self, x, float(temperature)))
         codebook = self.codebook()
         with torch.no_grad():
             xn = x / x.norm(dim=1, keepdim=True)
@@ -160,9 +169,11 @@ class Quantize(nn.Module):
         if self.do_kmeans_init and not self.kmeans_initted:
             self._kmeans_init(x=x)
         if self.distance_mode == QuantizeDistance.COSINE:
-            return self._forward_cosine(x)
+            return self._forward_cosine(x, temperature)
         if self.distance_mode != QuantizeDistance.L2:
             raise Exception("Unsupported Quantize distance mode.")
+        if not self.kernel_covers():
+            return QuantizeOutput(*wide.quantize_forward(self, x, float(temperature)))
 
         codebook = self.codebook()
         beta = float(self.commitment_weight)

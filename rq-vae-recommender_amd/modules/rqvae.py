@@ -118,8 +118,12 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
     def _can_fuse(self) -> bool:
         """All levels in one launch: needs every level past its lazy k-means init and a mode the stack
         kernel implements (eval, STE, rotation trick)."""
+        if len(self.layers) > 16:
+            return False
         for layer in self.layers:
             if layer.do_kmeans_init and not layer.kmeans_initted:
+                return False
+            if not layer.kernel_covers():        # e.g. embed_dim > 128: level by level through rqhip/wide.py
                 return False
             if layer.training and layer.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
                 return False

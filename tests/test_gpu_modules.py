@@ -592,3 +592,64 @@ def test_fused_last_layer_and_reconstruction_loss_equals_the_composed_pair(case,
     for n in g_c:
         scale = g_c[n].abs().max().item() + 1e-30
         assert (g_f[n] - g_c[n]).abs().max().item() <= 2e-6 * scale, n
+
+
+@pytest.mark.parametrize("name", ["wide_cosine_gumbel.npz", "wide_d160_ste.npz", "wide_d160_rotation.npz", "wide_d160_eval.npz",
+                                  "wide_gumbel_k1100.npz"])
+def test_shapes_outside_the_kernels_match_reference(name, monkeypatch):
+    """COSINE x GUMBEL_SOFTMAX, embed_dim > 128 and Gumbel-softmax with more than 1024 codes (reference quantize.py:104-163
+    has no limits): rqhip/wide.py runs the reference's expression as PyTorch-ROCm operators on the device tensors; checked
+    against reference outputs and autograd gradients (oracle/gen_golden.py:gen_wide), the reference's uniform noise fed in."""
+    import warnings
+    from modules.quantize import Quantize, QuantizeDistance, QuantizeForwardMode
+    g = load_golden(name)
+    K, D = g["codebook"].shape
+    q = Quantize(embed_dim=D, n_embed=K, do_kmeans_init=False, forward_mode=QuantizeForwardMode(int(g["mode"])),
+                 distance_mode=QuantizeDistance.COSINE if bool(g["cosine"]) else QuantizeDistance.L2).cuda()
+    assert not q.train(bool(g["training"])).kernel_covers()
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(g["codebook"]))
+    U = torch.from_numpy(g["U"]).cuda()
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: U if tuple(a[0]) == tuple(U.shape) else real_rand(*a, **k))
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        out = q(x, temperature=float(g["temperature"]))
+    assert out.embeddings.is_cuda and np.array_equal(out.ids.cpu().numpy(), g["ids"])
+    np.testing.assert_allclose(out.embeddings.detach().cpu().numpy(), g["embeddings"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out.loss.detach().cpu().numpy(), g["loss"], rtol=2e-5, atol=1e-5)
+    ((out.embeddings * torch.from_numpy(g["g_emb"]).cuda()).sum() + (out.loss * torch.from_numpy(g["g_loss"]).cuda()).sum()).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grad_x"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(q.embedding.weight.grad.cpu().numpy(), g["grad_codebook"], rtol=1e-4, atol=2e-5)
+
+
+def test_wide_latents_through_rqvae_and_kmeans():
+    """embed_dim = 160: k-means init (reference seeds -> reference centroids), then RqVae forward + backward level by level."""
+    import warnings
+    from data.schemas import SeqBatch
+    from init.kmeans import Kmeans
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    g = load_golden("wide_kmeans_d160.npz")
+    x = torch.from_numpy(g["x"]).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        np.random.seed(int(g["seed"]))
+        torch.manual_seed(int(g["seed"]))
+        out = Kmeans(k=int(g["k"])).run(x)
+        assert np.array_equal(out.assignment.cpu().numpy(), g["assignment"])
+        np.testing.assert_allclose(out.centroids.cpu().numpy(), g["centroids"], rtol=1e-5, atol=1e-6)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = RqVae(input_dim=64, embed_dim=160, hidden_dims=[96], codebook_size=12, n_layers=2, n_cat_features=0,
+                  codebook_kmeans_init=True, codebook_mode=QuantizeForwardMode.STE).cuda()
+        xb = torch.nn.functional.normalize(torch.randn(300, 64, device="cuda"), dim=-1)
+        m.train()
+        res = m(SeqBatch(None, None, None, xb, None, None), 0.2)
+        res.loss.backward()
+        assert not m._can_fuse() and all(l.kmeans_initted for l in m.layers)
+        assert torch.isfinite(res.loss).item() and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+        m.eval()
+        sem = m.get_semantic_ids(xb)
+        assert sem.sem_ids.shape == (300, 2) and int(sem.sem_ids.max()) < 12

@@ -158,6 +158,16 @@ def test_quantize_asserts_and_unsupported_modes():
                   forward_mode=QuantizeForwardMode.STE)
     with pytest.raises(RqHipError):          # implemented, but GPU only like everything else
         qc(torch.randn(3, 8), temperature=0.2)
+    # shapes / combinations outside the kernels run as PyTorch-ROCm operators ON THE DEVICE (rqhip/wide.py): no CPU path either
+    from rqhip import wide
+    assert wide.stack_covers(128, 65536, 16) and not wide.stack_covers(129, 256) and not wide.stack_covers(32, 256, 17)
+    assert wide.gumbel_covers(32, 256) and wide.gumbel_covers(64, 256) and not wide.gumbel_covers(8, 1100) and not wide.gumbel_covers(160, 40)
+    for kw in (dict(embed_dim=160, n_embed=4, forward_mode=QuantizeForwardMode.STE),
+               dict(embed_dim=8, n_embed=4, forward_mode=QuantizeForwardMode.GUMBEL_SOFTMAX, distance_mode=QuantizeDistance.COSINE)):
+        qw = Quantize(do_kmeans_init=False, **kw)
+        assert not qw.kernel_covers()
+        with pytest.raises(RqHipError):
+            qw(torch.randn(3, kw["embed_dim"]), temperature=0.2)
 
 
 def test_item_data_contract():
