@@ -368,7 +368,7 @@ typedef struct {
     int Nc;
     int arith;           /* RQHIP_SPLIT_* the image was built with */
     int epilogue;        /* RQHIP_EPI_* */
-    int tile_rows;       /* 0 (tools only: 8 / 4 = waves per workgroup; 256 / 64 (8 waves) or 128 / 32 (4 waves) force one tile height) */
+    int tile_rows;       /* 0 (tools only, staged-B kernels: 256 / 128 force big tiles, 64 / 32 small ones) */
     float *C;            /* [M, Nc] */
     const float *aux;    /* RQHIP_EPI_RECON: X [M, Nc]; RQHIP_EPI_MASK: Y [M, Nc]; else NULL */
     float row_scale;     /* RQHIP_EPI_RECON */

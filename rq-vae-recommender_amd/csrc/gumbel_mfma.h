@@ -21,7 +21,7 @@ int gumbel_mfma_forward(const GumbelMfmaParams &p, hipStream_t s);
 int gumbel_mfma_backward_grid(long long B);
 int gumbel_mfma_backward(const GumbelMfmaParams &p, hipStream_t s);
 // rows from which the 32-rows-per-wave kernels beat the one-row-per-wave ones of gumbel.hip (fewer rows cannot fill
-// the chip with 32-row tiles); RQ_GUMBEL_MFMA_MIN_ROWS overrides (developer / test switch)
+// the chip with 32-row tiles); rqhip_gumbel_matrix_path_min_rows overrides (developer / test switch)
 long long gumbel_mfma_min_rows();
 void gumbel_mfma_set_min_rows(long long n);
 
@@ -35,11 +35,26 @@ void gumbel_mfma_set_min_rows(long long n);
 //     per row.
 // Results differ from the oracle's libm / division chain by a few 1e-7 relative (tests: rtol 2e-4 forward, 2e-3
 // backward); ids come from the noise-free distances and are not affected.
+// RQ_GUMBEL_LIBM (developer A/B switch, tools/gumbel_libm_ab.sh): the library's logf / expf (__ocml_log_f32 / __ocml_exp_f32,
+// <= 1 ulp) in place of the hardware instructions -- what the tolerance would be bought with; measured in DESIGN.md section 4.3.
+#ifndef RQ_GUMBEL_LIBM
+#define RQ_GUMBEL_LIBM 0
+#endif
 __device__ __forceinline__ float gm_gumbel(float u) {   // -log(-log(u + 1e-20) + 1e-20), gumbel.py:10-11
+#if RQ_GUMBEL_LIBM
+    return -logf(-logf(u + 1e-20f) + 1e-20f);
+#else
     const float t = -(__builtin_amdgcn_logf(u + 1e-20f) * 0.69314718055994530942f);
     return -(__builtin_amdgcn_logf(t + 1e-20f) * 0.69314718055994530942f);
+#endif
 }
-__device__ __forceinline__ float gm_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float gm_exp(float x) {
+#if RQ_GUMBEL_LIBM
+    return expf(x);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
+}
 #endif
 
 }  // namespace rqhip

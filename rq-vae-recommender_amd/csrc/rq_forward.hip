@@ -691,20 +691,24 @@ __device__ __forceinline__ void split_row(const float (&r)[KSTEPS], rq_bf16x8 (&
         }
 }
 
+// S = 2 (D = 32): per tile only the maximum, the index walk and the in-tile runner-up once per level (finish_split); S = 4: per tile
+__host__ __device__ constexpr bool split_walk_deferred(int S) { return S == 2; }
+
 // The filtered scan of Kc staged codes (see stage_codes_bf16): scores x.c - |c|^2/2 of 32 rows against 32 codes per
 // tile entirely on the bf16 matrix cores, then the (best, runner-up, index) tournament on the 16 scores of the lane --
 // the mirror image (max for min) of scan_codes<.., MARGIN = true>, without any arithmetic in front of it.
-template <int S, bool GROUPS>
+template <int S, bool GROUPS, int NS>
 __device__ __forceinline__ void scan_codes_split(const rq_bf16x8 *__restrict__ img, const rq_bf16x4 *__restrict__ qimg, int Kc,
                                                  int kbase, int il, int h, const rq_bf16x8 (&xh)[S], const rq_bf16x8 (&xl)[S],
-                                                 float &best, int &bidx, float &second, GroupMax &gm, int t_begin = 0,
-                                                 int t_step = 1) {
+                                                 float &best, int &bcode, float &second, float (&saved)[NS], GroupMax &gm,
+                                                 int t_begin = 0, int t_step = 1) {
     const int ntiles = Kc / 32;
     auto lda = [&](int t, int blk) { return img[(size_t)(blk * 2 + h) * Kc + t * 32 + il]; };   // blk = plane * S + s
     auto ldq = [&](int t) {
         const rq_bf16x4 q = qimg[t * 32 + il];
         return rq_bf16x8{q[0], q[1], q[2], q[3], (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
     };
+    constexpr bool kDeferredWalk = split_walk_deferred(S);
     const rq_bf16x8 ones = split_ones(h);
     const int t0 = t_begin < ntiles ? t_begin : 0;
     rq_bf16x8 a[2 * S], aq;
@@ -719,38 +723,94 @@ __device__ __forceinline__ void scan_codes_split(const rq_bf16x8 *__restrict__ i
 #pragma unroll
         for (int b = 0; b < 2 * S; ++b) a[b] = lda(tn, b);
         aq = ldq(tn);
-        // acc[j]: code = 32 t + 8 (j>>2) + 4 h + (j&3), item = il.  (max, runner-up) tree and top-down walk for the index
-        float w1[8], l1[8], w2[4], l2[4], l3a, l3b, t2, a07, b07, tmax;
+        if constexpr (kDeferredWalk) {
+            // acc[j]: code = 32 t + 8 (j>>2) + 4 h + (j&3), item = il.  Per tile only the lane's MAXIMUM is formed (eight v_max3) and
+            // merged into the running (best, second-best) of the TILE maxima; the 16 scores of the tile that holds the best are
+            // copied aside when it changes.  Which of them it is (first occurrence) and the runner-up inside that tile are found
+            // once per level by finish_split -- 30 instead of 65 VALU instructions per 32 codes.  Strict `>` over ascending tiles
+            // keeps the first of equal maxima.
+            const float m0 = rq_max3(acc[0], acc[1], acc[2]), m1 = rq_max3(acc[3], acc[4], acc[5]), m2 = rq_max3(acc[6], acc[7], acc[8]);
+            const float m3 = rq_max3(acc[9], acc[10], acc[11]), m4 = rq_max3(acc[12], acc[13], acc[14]);
+            const float tmax = rq_max(rq_max3(m0, m1, acc[15]), rq_max3(m2, m3, m4));
+            second = rq_max(second, rq_min(best, tmax));    // second-best over the tile maxima (uses `best` before this tile's update)
+            if (GROUPS) gm.add(tmax);
+            const bool better = tmax > best;
+            best = better ? tmax : best;
+            bcode = better ? kbase + t * 32 : bcode;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            w1[i] = rq_max(acc[2 * i], acc[2 * i + 1]);
-            l1[i] = rq_min(acc[2 * i], acc[2 * i + 1]);
+            for (int j = 0; j < 16; ++j) saved[j] = better ? acc[j] : saved[j];
+        } else {
+            // D = 64 (S = 4: 256 registers, two waves per SIMD): the tournament of round 3, the index carried per tile -- the 16 saved
+            // scores of the deferred form spill there (measured 103 vs 99 us at 100 000 x 3 x 256 x 64)
+            // acc[j]: code = 32 t + 8 (j>>2) + 4 h + (j&3), item = il.  (max, runner-up) tree and top-down walk for the index
+            float w1[8], l1[8], w2[4], l2[4], l3a, l3b, t2, a07, b07, tmax;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w1[i] = rq_max(acc[2 * i], acc[2 * i + 1]);
+                l1[i] = rq_min(acc[2 * i], acc[2 * i + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rq_merge2max(w1[2 * i], l1[2 * i], w1[2 * i + 1], l1[2 * i + 1], w2[i], l2[i]);
+            rq_merge2max(w2[0], l2[0], w2[1], l2[1], a07, l3a);
+            rq_merge2max(w2[2], l2[2], w2[3], l2[3], b07, l3b);
+            rq_merge2max(a07, l3a, b07, l3b, tmax, t2);
+            const float a01 = w1[0], a45 = w1[2], b01 = w1[4], b45 = w1[6];
+            const float a03 = w2[0], b03 = w2[2];
+            second = rq_max3(second, t2, rq_min(best, tmax));
+            if (GROUPS) gm.add(tmax);
+            const bool c3 = a07 != tmax;
+            const float q03 = c3 ? b03 : a03;
+            const bool c2 = q03 != tmax;
+            const float s01 = c3 ? b01 : a01, s45 = c3 ? b45 : a45;
+            const float p01 = c2 ? s45 : s01;
+            const bool c1 = p01 != tmax;
+            const float u0a = c3 ? acc[8] : acc[0], u2a = c3 ? acc[10] : acc[2], u4a = c3 ? acc[12] : acc[4], u6a = c3 ? acc[14] : acc[6];
+            const float u0 = c2 ? u4a : u0a, u2 = c2 ? u6a : u2a;
+            const float e0 = c1 ? u2 : u0;
+            const bool c0 = e0 != tmax;
+            const int slot = (c3 ? 16 : 0) | (c2 ? 8 : 0) | (c1 ? 2 : 0) | (c0 ? 1 : 0);
+            const int cand = kbase + t * 32 + 4 * h + slot;
+            const bool better = tmax > best;
+            best = better ? tmax : best;
+            bcode = better ? cand : bcode;   // (the winner's code itself: finish_split is not called)
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rq_merge2max(w1[2 * i], l1[2 * i], w1[2 * i + 1], l1[2 * i + 1], w2[i], l2[i]);
-        rq_merge2max(w2[0], l2[0], w2[1], l2[1], a07, l3a);
-        rq_merge2max(w2[2], l2[2], w2[3], l2[3], b07, l3b);
-        rq_merge2max(a07, l3a, b07, l3b, tmax, t2);
-        const float a01 = w1[0], a45 = w1[2], b01 = w1[4], b45 = w1[6];
-        const float a03 = w2[0], b03 = w2[2];
-        second = rq_max3(second, t2, rq_min(best, tmax));
-        if (GROUPS) gm.add(tmax);
-        const bool c3 = a07 != tmax;
-        const float q03 = c3 ? b03 : a03;
-        const bool c2 = q03 != tmax;
-        const float s01 = c3 ? b01 : a01, s45 = c3 ? b45 : a45;
-        const float p01 = c2 ? s45 : s01;
-        const bool c1 = p01 != tmax;
-        const float u0a = c3 ? acc[8] : acc[0], u2a = c3 ? acc[10] : acc[2], u4a = c3 ? acc[12] : acc[4], u6a = c3 ? acc[14] : acc[6];
-        const float u0 = c2 ? u4a : u0a, u2 = c2 ? u6a : u2a;
-        const float e0 = c1 ? u2 : u0;
-        const bool c0 = e0 != tmax;
-        const int slot = (c3 ? 16 : 0) | (c2 ? 8 : 0) | (c1 ? 2 : 0) | (c0 ? 1 : 0);
-        const int cand = kbase + t * 32 + 4 * h + slot;
-        const bool better = tmax > best;
-        best = better ? tmax : best;
-        bidx = better ? cand : bidx;
     }
+}
+
+// The level's finish of the filtered scan for one lane: `saved` = the 16 scores of the tile that holds `best` (codes
+// bcode + 8 (j>>2) + 4 h + (j&3)).  second <- max(second-best tile maximum, runner-up inside the best tile) (a duplicate of the
+// maximum counts), bidx <- the code of the FIRST slot that equals best.  bcode < 0: the lane scanned nothing.
+template <int NS>
+__device__ __forceinline__ void finish_split(float best, int bcode, const float (&saved)[NS], int h, float &second, int &bidx) {
+    static_assert(NS == 16, "the deferred walk keeps the 16 scores of one tile");
+    if (bcode < 0) return;
+    float w1[8], l1[8], w2[4], l2[4], l3a, l3b, t2, a07, b07, tmax;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w1[i] = rq_max(saved[2 * i], saved[2 * i + 1]);
+        l1[i] = rq_min(saved[2 * i], saved[2 * i + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rq_merge2max(w1[2 * i], l1[2 * i], w1[2 * i + 1], l1[2 * i + 1], w2[i], l2[i]);
+    rq_merge2max(w2[0], l2[0], w2[1], l2[1], a07, l3a);
+    rq_merge2max(w2[2], l2[2], w2[3], l2[3], b07, l3b);
+    rq_merge2max(a07, l3a, b07, l3b, tmax, t2);
+    second = rq_max(second, t2);
+    const float a01 = w1[0], a45 = w1[2], b01 = w1[4], b45 = w1[6];
+    const float a03 = w2[0], b03 = w2[2];
+    const bool c3 = a07 != tmax;
+    const float q03 = c3 ? b03 : a03;
+    const bool c2 = q03 != tmax;
+    const float s01 = c3 ? b01 : a01, s45 = c3 ? b45 : a45;
+    const float p01 = c2 ? s45 : s01;
+    const bool c1 = p01 != tmax;
+    const float u0a = c3 ? saved[8] : saved[0], u2a = c3 ? saved[10] : saved[2], u4a = c3 ? saved[12] : saved[4], u6a = c3 ? saved[14] : saved[6];
+    const float u0 = c2 ? u4a : u0a, u2 = c2 ? u6a : u2a;
+    const float e0 = c1 ? u2 : u0;
+    const bool c0 = e0 != tmax;
+    const int slot = (c3 ? 16 : 0) | (c2 ? 8 : 0) | (c1 ? 2 : 0) | (c0 ? 1 : 0);
+    bidx = bcode + 4 * h + slot;
+    (void)best;
 }
 
 // One 32-row tile through all L levels.
@@ -805,6 +865,13 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
 
         float best = FILT ? -__builtin_inff() : __builtin_inff(), second = best;
         int bidx = 0x7fffffff;
+        // filtered scan: the scores of the tile that holds the lane's best (see scan_codes_split / finish_split)
+        float saved[(FILT && split_walk_deferred(S)) ? 16 : 1];
+        int bcode = -1;
+        if constexpr (FILT && split_walk_deferred(S)) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) saved[j] = -__builtin_inff();
+        }
         // filtered scan: this level's input rows as bf16 hi / lo planes, K-step s = features 2 (8 s + j) + h
         rq_bf16x8 xh[S], xl[S];
         GroupMax gm;
@@ -833,9 +900,9 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
             }
             if (active) {
                 if constexpr (FILT)
-                    scan_codes_split<S, !COOP>(reinterpret_cast<const rq_bf16x8 *>(buf),
+                    scan_codes_split<S, !COOP, (split_walk_deferred(S) ? 16 : 1)>(reinterpret_cast<const rq_bf16x8 *>(buf),
                                                reinterpret_cast<const rq_bf16x4 *>(buf + KSTEPS * 2 * Kc), Kc, kbase, il, h, xh,
-                                               xl, best, bidx, second, gm, COOP ? wave : 0, COOP ? kCoopWaves : 1);
+                                               xl, best, bcode, second, saved, gm, COOP ? wave : 0, COOP ? kCoopWaves : 1);
                 else
                     scan_codes<KSTEPS, MARGIN>(reinterpret_cast<const f32x4 *>(buf), buf + KSTEPS * 2 * Kc, Kc, kbase, il, h,
                                                r, xsq, best, bidx, second, COOP ? wave : 0, COOP ? kCoopWaves : 1);
@@ -845,6 +912,10 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         // (read after the scans: with in-kernel norms a non-resident level's maximum is complete only after its staging barrier)
         const float csqmax_l = csqmax_s[l];
         if constexpr (FILT) {
+            if (active) {
+                if constexpr (split_walk_deferred(S)) finish_split(best, bcode, saved, h, second, bidx);
+                else bidx = bcode < 0 ? bidx : bcode;
+            }
             if (!COOP && gm.gcnt) gm.flush();   // a partly filled last group
             if (l == L - 1 && next_tile >= 0) load_tile_rows<KSTEPS, FULLD>(p, next_tile, il, h, D, rn);
         }

@@ -95,7 +95,7 @@ class _MLPStack(torch.autograd.Function):
         need_in = [bool(ctx.needs_input_grad[0]) or any(need_w[:i]) for i in range(n)]   # gradient wrt layer i's input wanted
         fwd_split = [_lin.split_shape_ok(M, w.shape[0], w.shape[1]) for w in weights]
         dg_split = [need_in[i] and _lin.split_shape_ok(M, w.shape[1], w.shape[0]) for i, w in enumerate(weights)]
-        wg_f16 = [need_w[i] and _lin.wgrad_f16_ok(w.shape[0], w.shape[1]) for i, w in enumerate(weights)]
+        wg_f16 = [need_w[i] and _lin.wgrad_f16_ok(w.shape[0], w.shape[1], M) for i, w in enumerate(weights)]
         jobs = [(w, False) for i, w in enumerate(weights) if fwd_split[i]] + [(w, True) for i, w in enumerate(weights) if dg_split[i]]
         imgs = iter(_lin.images(jobs))
         img_f = [next(imgs) if fwd_split[i] else None for i in range(n)]

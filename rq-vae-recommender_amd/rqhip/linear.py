@@ -96,10 +96,12 @@ def split_shape_ok(rows: int, n_cols: int, n_red: int) -> bool:
                 and ops.gemm_split_supported(n_cols, n_red))
 
 
-def wgrad_f16_ok(n_out: int, n_in: int) -> bool:
-    """Does the weight gradient of an [n_out, n_in] layer run on the fp16 split kernel (and therefore want column maxima)?
-    The shapes csrc/wgrad_split.hip tiles: both multiples of 128, one of them of 256."""
-    return bool(f16() and n_out % 128 == 0 and n_in % 128 == 0 and (n_out % 256 == 0 or n_in % 256 == 0))
+def wgrad_f16_ok(n_out: int, n_in: int, rows: int = _SPLIT_MIN_ROWS) -> bool:
+    """Does the weight gradient of an [n_out, n_in] layer over `rows` batch rows run on the fp16 split kernel (and therefore
+    want column maxima)?  The shapes csrc/wgrad_split.hip tiles: both multiples of 128, one of them of 256 -- and batches of
+    4096 rows and more: below that a step is launch-bound, and the maxima passes / zeroed arenas the scales need are launches
+    (batch 640: 71 device activities per step with them, 1.55 ms; the fused-mask kernels of csrc/wgrad.hip need none)."""
+    return bool(f16() and rows >= _SPLIT_MIN_ROWS and n_out % 128 == 0 and n_in % 128 == 0 and (n_out % 256 == 0 or n_in % 256 == 0))
 
 
 def images(jobs: List[Tuple[Tensor, bool]]) -> List[Tensor]:
@@ -170,7 +172,7 @@ def weight_grad(g: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, *, out: Op
         return gw, gp, None
     if premasked:
         y = None
-    if wgrad_f16_ok(w.shape[0], w.shape[1]):
+    if wgrad_f16_ok(w.shape[0], w.shape[1], g.shape[0]):
         if y is not None:   # mask + maxima in one pass; the weight-gradient kernel then runs without a mask
             r, c, g = ops.maxima(g, y, rows=want_masked, cols=True, write_masked=True)
             g_scales = Scales(r, c)

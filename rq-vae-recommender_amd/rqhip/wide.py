@@ -103,7 +103,11 @@ def kmeans_update(x: Tensor, centroids: Tensor):
         d = ((x[r0:r0 + step, None, :] - centroids[None, :, :]) ** 2).sum(dim=2)
         assign[r0:r0 + step] = d.min(dim=1).indices
     counts = torch.bincount(assign, minlength=K)
-    sums = torch.zeros((K, D), dtype=x.dtype, device=x.device).index_add_(0, assign, x)
+    # per-cluster sums in a FIXED order (rows sorted by cluster, stable; segment sums): `index_add_` on the GPU adds with float
+    # atomics in whatever order they land, the centroids then differ in their last bits from one iteration to the next and the
+    # loop's stop test (max shift < 1e-10, kmeans.py:68) never fires
+    order = torch.argsort(assign, stable=True)
+    sums = torch.segment_reduce(x[order], "sum", lengths=counts, axis=0)
     filled = counts > 0
     centroids[filled] = sums[filled] / counts[filled].unsqueeze(1).to(x.dtype)
     return assign, counts

@@ -23,6 +23,16 @@ def pytest_configure(config):
     _ensure_native_built()
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every GPU test gets a wall-clock limit (pytest-timeout, when installed): a test that hangs on the GPU box would
+    otherwise burn the whole call's budget (round 4: a non-converging loop cost ten GPU-minutes)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(180))
+
+
 def _ensure_native_built():
     """Build the HIP library / oracle when a fresh checkout has not run __graft_entry__.build() yet (the built
     .so files are git-ignored).  hipcc cross-compiles gfx950 without a GPU; on the GPU box the prebuilt files

@@ -442,7 +442,7 @@ def test_gumbel_forward_backward_vs_oracle(B, D, K, T):
     ids, emb, loss = ops.gumbel_forward(_gpu(x), _gpu(cb), _gpu(U), T, 0.25)
     assert np.array_equal(ids.cpu().numpy(), ref["ids"])                      # noise-free argmin: exact
     np.testing.assert_allclose(emb.cpu().numpy(), ref["emb"], rtol=2e-4, atol=1e-5)  # exp((.)/T) amplifies 1-ulp distance differences
-    np.testing.assert_allclose(loss.cpu().numpy(), ref["loss"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref["loss"], rtol=1e-5, atol=1e-5)   # north_star: losses within 1e-5
     rng = np.random.default_rng(1)
     g_emb = rng.standard_normal((B, D)).astype(np.float32)
     g_loss = rng.random(B).astype(np.float32)
@@ -462,7 +462,7 @@ def test_gumbel_vs_reference_golden(name):
     ids, emb, loss = ops.gumbel_forward(_gpu(g["x"]), _gpu(g["codebook"]), _gpu(g["U"]), T, beta)
     assert np.array_equal(ids.cpu().numpy(), g["ids"])
     np.testing.assert_allclose(emb.cpu().numpy(), g["embeddings"], rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-5, atol=1e-5)   # north_star: losses within 1e-5
     g_x, g_cb = ops.gumbel_backward(_gpu(g["x"]), _gpu(g["codebook"]), _gpu(g["U"]), T, beta, g_emb=_gpu(g["g_emb"]),
                                     g_loss=_gpu(g["g_loss"]))
     sx, sc = max(1.0, float(np.abs(g["grad_x"]).max())), max(1.0, float(np.abs(g["grad_codebook"]).max()))

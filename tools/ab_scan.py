@@ -11,6 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")]
+if os.environ.get("RQ_LIB"):   # another build of librqhip.so (tools/ab_build.sh), loaded before the first op
+    from rqhip import _lib  # noqa: E402
+    _lib.load(os.path.abspath(os.environ["RQ_LIB"]))
 from rqhip import ops  # noqa: E402
 
 PEAK_F32 = 157.3

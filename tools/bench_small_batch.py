@@ -62,6 +62,10 @@ try:   # kernel launches of one eager step
     n = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
     ours = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "rqhip" in e.name)
     print(f"launches per step: {n} device activities ({ours} hand-written kernels)")
+    if os.environ.get("RQ_LIST_LAUNCHES"):
+        for e in prof.events():
+            if e.device_type == torch.autograd.DeviceType.CUDA:
+                print(f"    {e.name[:110]:110s} {e.device_time:8.1f} us")
 except Exception as e:  # noqa
     print("launch count unavailable:", repr(e)[:200])
 try:

@@ -22,22 +22,15 @@
 // Mapping
 //   * both operands are consumed along the reduction index as they lie in memory (a lane's operand = 8 consecutive r of
 //     one row of A / one row of B): no transposition.  The weight is split once per forward by `weight_images_kernel` (all
-//     layers of an MLP in ONE launch) into the stage-major image [R/16][piece][half][Nc] x 16 bytes.
-//   * the product kernel (`gemm_f16_kernel`, f16x2, layers of 256 (mod 256) columns): tile = 128 rows x 256 columns, 4 waves
-//     side by side (each 128 x 64), TWO persistent workgroups per CU; 16-deep stages: the fp32 rows of A are requested two
-//     stages ahead, split by the VALU into a double-buffered LDS image (the only thing in LDS), a wave's B operands go from
-//     the L2-resident image straight into registers one stage ahead, the A fragments of row block t + 1 are read while the
-//     matrix instructions of block t run; whole rounds of the chip in 128-row tiles, the leftover in 64-row tiles; tiles
-//     are handed out by atomic counters.
-//   * `gemm_split_kernel` (both operands staged through LDS: round 3's loop) remains for the bf16x3 A/B arm (256 x 256 tiles,
-//     8 waves, one workgroup per CU) and for 128-column tiles.
-//   * results do not depend on which workgroup computes a tile, nor on the kernel (same products in the same order per
-//     accumulator): bit-reproducible run to run and across the variants.
-// Where the time goes (tools/gemm_probe2.py, GS_PROBE builds; 768 -> 512 at 100 000 rows, 340 us): tile prologue + epilogue +
-// loop skeleton alone 105 us, matrix instructions alone + that 171 us, everything but the matrix instructions 251 us; the
-// split arithmetic costs 77 us, the B loads 50, the LDS reads 40, the A loads 35, the stage barriers nothing; the same
-// stores in a contiguous pattern would save 27 us (62 on the reconstruction epilogue).  DESIGN.md section 4.3d.
-// The round-3 / round-4 schedule experiments live in tools/experiments/gemm_split_r0{3,4}_variants.hip.
+//     layers of an MLP in ONE launch) into the stage-major image [R/16][piece][half][Nc] x 16 bytes, so a workgroup's B stage
+//     is NP contiguous runs.
+//   * tile = 256 rows x 256 columns (8 waves of 128 x 64) for whole rounds of the chip, 64 x 256 (8 waves of 32 x 64) for
+//     what is left over; layers with 128 (mod 256) output columns take 256 x 128 tiles (8 waves of 64 x 64) and 128 x 128
+//     for the leftover; 16-deep stages through a double-buffered LDS image, A rows requested two stages ahead.  Tiles are
+//     handed out by an atomic counter (persistent workgroups, one per CU).
+//   * results do not depend on which workgroup computes a tile: bit-reproducible run to run.
+// The round-3 schedule experiments (wave specialisation, 128 x 128 wave tiles, weight image from L2, phase-skipping probes,
+// s_memtime stamps) live in tools/experiments/gemm_split_r03_variants.hip; what they measured is in DESIGN.md section 4.3d.
 #include "rqhip_common.h"
 
 namespace rqhip {
@@ -262,6 +255,7 @@ struct GemmSplitParams {
     // tiles 0 .. n_big - 1 are 256 rows high (rows [0, 256 rt_big)), the rest 64 rows high (from row 256 rt_big on)
     unsigned n_big, n_tiles;
     int rt_big;
+    int stagger;             // gemm_f16_kernel: the second workgroup of a CU starts with a small tile
     unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
     // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
     // rowsum[ct][m] the squared error of row m over column tile ct.  EPI == 3: X is Y, the activation whose ReLU is undone
@@ -773,9 +767,9 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
     gs_epilogue<EPI, TA, COLS, 2, WAVES>(p, acc, sbuf, s_aexp, s_colmax, m0, n0);
 }
 
-// The staged-B loop (gs_tile): instantiated for the two shapes the product kernel does not take -- the three-piece bf16
-// arithmetic (A/B arm `bench.py --mlp split6`: 8 waves, one workgroup per CU, 256-row tiles) and 128-column tiles of the
-// f16x2 arithmetic (layers of 128 (mod 256) columns: 4 waves, two workgroups per CU, 128-row tiles).
+// WAVES = 8: one workgroup per CU (256-row tiles); WAVES = 4: TWO workgroups per CU (128-row tiles, the same 128 x 64 wave
+// tile): the two run out of phase, so one's staging, barriers, pipeline fill and -- above all -- its epilogue (a tile's
+// result stores, plus the aux reads of EPI 2 / 3) overlap the other's matrix instructions.
 template <int EPI, int COLS, int NP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSplitParams p) {
     constexpr int kGsThreads = 64 * WAVES;
@@ -822,12 +816,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSpl
     }
 }
 
-// The product kernel: gs_tile2 tiles of 128 rows (64-row tiles for what is left over after the whole rounds), 4 waves, TWO
-// persistent workgroups per CU: one's tile prologue, barriers and epilogue fall into the other's matrix instructions.
-// Two dispensers: counter[0] big tiles, counter[2] small tiles (taken when the big ones are gone); counter[1] counts the
-// workgroups that have left (the last one re-arms all three).  (Round 4 also tried starting the second workgroup of every CU
-// half a tile late so that epilogues and main loops of a CU interleave by construction: neutral to -7 %,
-// tools/experiments/gemm_split_r04_variants.hip.)
+// The product kernel: gs_tile2 tiles of 128 rows (and 64-row tiles for the stagger and the leftover), 4 waves, TWO persistent
+// workgroups per CU.  Equal workgroups that start together stay in step -- both would compute, then both would store.  So the
+// second workgroup of every CU (the one whose LDS allocation does not start at 0) begins with a half-height tile: from then on
+// one workgroup's epilogue (a tile's result stores, the aux reads of EPI 2 / 3), tile prologue and barriers fall into the
+// other's matrix instructions.  Two dispensers: counter[0] big tiles, counter[2] small tiles (the late workgroups' first tile,
+// then whoever runs out of big tiles); counter[1] counts the workgroups that have left (the last one re-arms all three).
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams p) {
     constexpr int kThreads = 256, kBigRows = 128, kSmallRows = 64, COLS = 256;
@@ -842,18 +836,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams 
     if (lds_colmax)
         for (int c = tid; c < p.Nc; c += kThreads) s_colmax[c] = 0u;
     const unsigned n_small = p.n_tiles - p.n_big;
+    // HW_REG_LDS_ALLOC (id 6), LDS_BASE = bits 7:0: zero for the first workgroup placed on a CU
+    bool late_start = p.stagger && (__builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xff) != 0;
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
         if (tid == 0) {
             unsigned t = kNone;
-            const unsigned i = atomicAdd(p.counter, 1u);
-            if (i < p.n_big) t = i;
+            if (late_start) {
+                const unsigned i = atomicAdd(p.counter + 2, 1u);
+                if (i < n_small) t = i | kSmallBit;
+            }
             if (t == kNone) {
-                const unsigned j = atomicAdd(p.counter + 2, 1u);
-                if (j < n_small) t = j | kSmallBit;
+                const unsigned i = atomicAdd(p.counter, 1u);
+                if (i < p.n_big) t = i;
+            }
+            if (t == kNone && !late_start) {
+                const unsigned i = atomicAdd(p.counter + 2, 1u);
+                if (i < n_small) t = i | kSmallBit;
             }
             s_tile = t;
         }
+        late_start = false;
         __syncthreads();
         const unsigned tile = s_tile;
         if (tile == kNone) {
@@ -1011,24 +1014,42 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
     p.b_exp = reinterpret_cast<const int *>(p.counter + 16);
     const int cus = cu_count();
-    // the product kernel (gemm_f16_kernel: 4 waves, two workgroups per CU, B operands straight from the image) takes the f16x2
-    // arithmetic at 256-column tiles; the staged loop the rest: bf16x3 with 8 waves / one workgroup per CU, f16x2 at 128-column
-    // tiles with 4 waves / two per CU.  tile_rows (tools only): force big (256 / 128) or small (64 / 32) tiles in the staged loop.
-    const bool tile2 = np == 2 && cols == 256;
-    const int waves = np == 3 ? 8 : 4;
+    // workgroup shape: 4 waves, two workgroups per CU (the default) or 8 waves, one per CU (round 3's; RQHIP_GEMM_WAVES=8 or
+    // tile_rows 256 / 64 for A/B)
+    static const int env_waves = [] { const char *e = getenv("RQHIP_GEMM_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
+    const int tr = a->tile_rows;          // tools only: 8 / 4 = that workgroup shape, tile heights chosen as usual
+    const int waves = (tr == 256 || tr == 64 || tr == 8) ? 8 : (tr == 128 || tr == 32 || tr == 4 || tr == 2 || tr == 3) ? 4 : env_waves;
+    // the product loop (gs_tile2: B operands straight from the image, A fragments prefetched): f16x2, 256-column tiles, 4 waves;
+    // RQHIP_GEMM_TILE2=0 or a tile_rows code other than 0 / 2 keeps the staged-B loop for A/B
+    static const bool env_tile2 = [] { const char *e = getenv("RQHIP_GEMM_TILE2"); return !(e && atoi(e) == 0); }();
+    const bool tile2 = np == 2 && cols == 256 && waves == 4 && (tr == 2 || tr == 3 || (tr == 0 && env_tile2));   // (3: without the stagger)
     const int big_rows = 32 * waves;
     const int small_rows = tile2 ? 64 : (waves / (cols / 64)) * 32;
     p.n_col_tiles = Nc / cols;
     const long long slots = (long long)cus * (waves == 4 ? 2 : 1);
-    // whole rounds of big tiles, the remainder as small tiles (see the kernels)
+    // whole rounds of big tiles, the remainder as small tiles (see the kernel);
+    // tile_rows (tools only): 256 / 128 = big tiles for every row, 64 / 32 = small tiles for every row
     const long long rt_all = (M + big_rows - 1) / big_rows;
     long long rt_big = ((rt_all * p.n_col_tiles) / slots) * slots / p.n_col_tiles;   // row tiles of the whole rounds
     if (rt_big * big_rows > M) rt_big = M / big_rows;
+    p.stagger = 0;
     // (measured at 100 000 rows: cutting the leftover into small tiles is worth it when it is a small part of a round -- Nc = 512:
     // 14 of 256 slots, 517 -> 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
     if ((rt_all * p.n_col_tiles) % slots > (3 * slots) / 10 && rt_all * p.n_col_tiles >= slots) rt_big = rt_all;
-    if (!tile2 && (a->tile_rows == 256 || a->tile_rows == 128)) rt_big = rt_all;
-    if (!tile2 && (a->tile_rows == 64 || a->tile_rows == 32)) rt_big = 0;
+    if (tile2) {
+        // gemm_f16_kernel's stagger (RQHIP_GEMM_STAGGER=1 or tile_rows 2; off by default: measured neutral to -7 %, tools/gemm_wg_ab.py):
+        // with two rounds of work or more, half a round of it goes into small tiles -- one for the late workgroup of every CU to
+        // start with, as many for the early ones to end with -- plus what is left over
+        static const bool env_stagger = [] { const char *e = getenv("RQHIP_GEMM_STAGGER"); return e && atoi(e) == 1; }();
+        const long long rounds = (rt_all * p.n_col_tiles) / slots;
+        if (rounds >= 2 && (tr == 2 || (tr == 0 && env_stagger))) {
+            p.stagger = 1;
+            rt_big = (rounds * slots - slots / 2) / p.n_col_tiles;
+        }
+    } else {
+        if (a->tile_rows == 256 || a->tile_rows == 128) rt_big = rt_all;
+        if (a->tile_rows == 64 || a->tile_rows == 32) rt_big = 0;
+    }
     const long long rem_rows = M - rt_big * big_rows > 0 ? M - rt_big * big_rows : 0;
     const long long rt_small = (rem_rows + small_rows - 1) / small_rows;
     p.rt_big = (int)rt_big;
@@ -1048,18 +1069,25 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         return 0;
     };
     int rc;
+#define GS_GO(E, C, P) (waves == 4 ? go(gemm_split_kernel<E, C, P, 4>) : go(gemm_split_kernel<E, C, P, 8>))
+#define GS_GO2(E) go(gemm_f16_kernel<E>)
     if (tile2) {
-        rc = epi == 3 ? go(gemm_f16_kernel<3>) : epi == 2 ? go(gemm_f16_kernel<2>) : epi == 1 ? go(gemm_f16_kernel<1>) : go(gemm_f16_kernel<0>);
+        rc = epi == 3 ? GS_GO2(3) : epi == 2 ? GS_GO2(2) : epi == 1 ? GS_GO2(1) : GS_GO2(0);
     } else if (np == 2) {
-        rc = epi == 3 ? go(gemm_split_kernel<3, 128, 2, 4>) : epi == 1 ? go(gemm_split_kernel<1, 128, 2, 4>) : go(gemm_split_kernel<0, 128, 2, 4>);
+        if (cols == 128)
+            rc = epi == 3 ? GS_GO(3, 128, 2) : epi == 1 ? GS_GO(1, 128, 2) : GS_GO(0, 128, 2);
+        else
+            rc = epi == 3 ? GS_GO(3, 256, 2) : epi == 2 ? GS_GO(2, 256, 2) : epi == 1 ? GS_GO(1, 256, 2) : GS_GO(0, 256, 2);
     } else {
         if (epi == 3) {
             set_error("gemm_split: the masked epilogue exists for RQHIP_SPLIT_F16X2 only");
             return RQHIP_EUNSUPPORTED;
         }
-        if (cols == 128) rc = epi == 1 ? go(gemm_split_kernel<1, 128, 3, 8>) : go(gemm_split_kernel<0, 128, 3, 8>);
-        else rc = epi == 2 ? go(gemm_split_kernel<2, 256, 3, 8>) : epi == 1 ? go(gemm_split_kernel<1, 256, 3, 8>) : go(gemm_split_kernel<0, 256, 3, 8>);
+        if (cols == 128) rc = epi == 1 ? GS_GO(1, 128, 3) : GS_GO(0, 128, 3);
+        else rc = epi == 2 ? GS_GO(2, 256, 3) : epi == 1 ? GS_GO(1, 256, 3) : GS_GO(0, 256, 3);
     }
+#undef GS_GO
+#undef GS_GO2
     if (rc) return rc;
     if (epi == RQHIP_EPI_RECON) {
         hipLaunchKernelGGL(recon_rows_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,
