@@ -292,7 +292,9 @@ def main():
 
     def step():
         reducer.zero_()
-        for b in batches:
+        for bi, b in enumerate(batches):
+            if bi + 1 == n_micro:
+                reducer.arm()                   # last backward of the step: finished gradients go on the wire under the encoder's
             share = b.x.shape[0] / B            # this micro-batch's share of the step's mean loss
             with rq_autograd.loss_scale(share):  # (hint for the speculative reconstruction-loss gradient)
                 out = model(b, gumbel_t=0.2)

@@ -175,7 +175,13 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
     def forward(self, batch: SeqBatch, gumbel_t: float) -> RqVaeComputedLosses:
         x = batch.x
         xin = x.to(next(self.encoder.parameters()).dtype)
-        st = self._quantize_stack(self.encode(xin), gumbel_t, want_levels=False)
+        res0 = self.encode(xin)
+        reducer = getattr(self, "_rq_reducer", None)
+        if reducer is not None and res0.requires_grad:
+            # multi-GPU: when this gradient exists, decoder and codebook gradients are final -- their all-reduce starts under
+            # the encoder's backward (rqhip/dist.py:FlatGradReducer.boundary_hook; a no-op with one rank or an unarmed step)
+            res0.register_hook(reducer.boundary_hook)
+        st = self._quantize_stack(res0, gumbel_t, want_levels=False)
         n = self.n_cat_feats
         reconstruction = None
         if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and type(self.decoder) is MLP and x.dim() == 2:

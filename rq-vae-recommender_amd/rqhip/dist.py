@@ -6,7 +6,10 @@ accelerate's DDP wrap performs implicitly in the reference (train_rqvae.py:153,1
 and MI355X-shaped: after backward all gradients are packed into ONE flat fp32 buffer (4.6 MB for the Amazon
 config) with a single kernel, so a step issues exactly one in-place all-reduce -- the payload is far below
 the xGMI bandwidth regime, what matters is one collective instead of a bucket per layer -- followed by a 1/W
-scale (DDP's mean); the optimizer then reads views of that buffer.  The k-means init is row-sharded too: every rank
+scale (DDP's mean); the optimizer then reads views of that buffer.  The part of the buffer whose gradients are complete before
+the encoder's backward starts (decoder weights, codebooks: half of it) is reduced UNDER the encoder's backward: `arm()` before the
+step's last backward, a tensor hook on the encoder's output launches those all-reduces asynchronously, `allreduce_mean()` waits
+for them and reduces the rest.  The k-means init is row-sharded too: every rank
 takes its block of the first <= 20 000 rows through the model, rank 0 draws the seed / reseed row numbers and
 broadcasts them, and each Lloyd iteration is one all-reduce of the [K, D+1] sums || counts (init/kmeans.py) -- which
 also removes the reference's latent per-rank-divergent init.
@@ -107,6 +110,13 @@ class FlatGradReducer:
         self._views = []
         self._offsets = []
         self.epoch = 0      # bumped by zero_(): a slice may be written in place by ONE backward node per epoch
+        # overlap of the all-reduce with the encoder's backward (see arm / boundary_hook)
+        self._early_params: List[nn.Parameter] = []
+        self._early_runs: List[tuple] = []      # [lo, hi) element ranges of the flat buffer complete at the boundary
+        self._late_runs: List[tuple] = []       # the rest
+        self._armed = False
+        self._pending: list = []
+        self.overlap_launches = 0               # (tests / logs) early launches so far
         offset = 0
         for p in self.params:
             n = p.numel()
@@ -132,7 +142,50 @@ class FlatGradReducer:
                 off = self._offsets[idx[0]]
                 model._rq_cb_grad_sink = SimpleNamespace(view=self.flat[off:off + len(cbs) * K * D].view(len(cbs), K, D),
                                                          params=cbs, owner=self)
+        # what is complete when the gradient of the encoder's OUTPUT exists: everything that is not an encoder parameter
+        enc = getattr(model, "encoder", None)
+        if enc is not None and model is not None:
+            enc_ids = {id(p) for p in enc.parameters()}
+            early = [i for i, p in enumerate(self.params) if id(p) not in enc_ids]
+            if early and len(early) < len(self.params):
+                self._early_params = [self.params[i] for i in early]
+                self._early_runs = self._runs(early)
+                self._late_runs = self._runs([i for i in range(len(self.params)) if i not in set(early)])
+                model._rq_reducer = self
         return self
+
+    def _runs(self, idx: List[int]) -> List[tuple]:
+        """Maximal contiguous [lo, hi) ranges of the flat buffer covered by the parameters `idx` (ascending)."""
+        runs: List[list] = []
+        for i in sorted(idx):
+            lo, hi = self._offsets[i], self._offsets[i] + self.params[i].numel()
+            if runs and runs[-1][1] == lo:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi])
+        return [tuple(r) for r in runs]
+
+    def arm(self) -> None:
+        """Announce that the NEXT backward is the last one before `allreduce_mean()` (every step without gradient accumulation;
+        the last micro-batch with it): its boundary hook may start reducing.  Cleared by `zero_()` and by the launch."""
+        self._armed = True
+
+    def boundary_hook(self, grad: Tensor) -> None:
+        """Tensor hook on the encoder's output (modules/rqvae.py registers it when a reducer is attached): runs when that
+        gradient exists, i.e. after the decoder's and the quantiser's backward and before the encoder's.  With several ranks
+        and an armed step, the finished part of the buffer goes on the wire now (asynchronously: RCCL runs it on its own
+        stream behind an event of this one) while the encoder's backward computes.  Only when every one of those gradients
+        was WRITTEN into the buffer by its backward node in this epoch -- a gradient that still lives elsewhere is packed by
+        `allreduce_mean()`, which then reduces everything at once, as before."""
+        del grad
+        if not self._armed or world_size() == 1 or not self._early_runs:
+            return None
+        self._armed = False
+        if not all(getattr(p, "_rq_sink_epoch", -1) == self.epoch for p in self._early_params):
+            return None
+        self._pending = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in self._early_runs]
+        self.overlap_launches += 1
+        return None
 
     def zero_(self) -> None:
         """Use instead of optimizer.zero_grad().  Starts a new epoch: until the next call, the FIRST backward node that
@@ -140,6 +193,7 @@ class FlatGradReducer:
         producer of the same parameter in the same backward pass -- one module applied twice under one loss -- sees the
         slice taken and returns an ordinary tensor, which autograd accumulates."""
         self.epoch += 1
+        self._armed = False
         for p in self.params:
             p.grad = None
 
@@ -154,7 +208,14 @@ class FlatGradReducer:
             elif p.grad.data_ptr() != v.data_ptr():   # produced by code that does not know the buffer: one small copy
                 v.copy_(p.grad)
             p.grad = v
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self._pending:          # the early part is on the wire (boundary_hook): wait for it, reduce the rest
+            for work in self._pending:
+                work.wait()
+            self._pending = []
+            for lo, hi in self._late_runs:
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / w)
         return self.flat
 

@@ -106,6 +106,7 @@ class _GraphedStep:
         self.x = torch.zeros((batch_size, feature_dim), device=device)
         self.batch_size = batch_size
         self.graph = None
+        self.captures = 0
         self._model, self._opt, self._reducer, self._t = model, optimizer, reducer, gumbel_t
         self.out = None
 
@@ -113,7 +114,9 @@ class _GraphedStep:
         from data.schemas import SeqBatch
         self._reducer.zero_()
         out = self._model(SeqBatch(None, None, None, self.x, None, None), gumbel_t=self._t)
+        self._reducer.arm()
         out.loss.backward()
+        self._reducer.allreduce_mean()     # (one rank: nothing; several: the RCCL all-reduces are part of the captured graph)
         self._opt.step()
         return out
 
@@ -123,8 +126,15 @@ class _GraphedStep:
         capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
         import copy
         self.x.copy_(x)
+        self.captures += 1
+        if self.captures in (2, 10, 100, 1000):     # every eager excursion (a short epoch-tail batch, eval, checkpoint) costs one
+            print(f"use_hip_graph: capture #{self.captures} (two rolled-back warm-up steps + a capture each); with few full batches "
+                  "per epoch this can cost more than the graph saves", flush=True)
         params = [p.detach().clone() for p in self._model.parameters()]
         opt_state = copy.deepcopy(self._opt.state_dict())
+        # the warm-up steps must not advance any random stream either (Gumbel noise, dropout): an eager run and a graphed run
+        # of the same seed see the same draws
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
@@ -135,6 +145,8 @@ class _GraphedStep:
             for p, saved in zip(self._model.parameters(), params):
                 p.copy_(saved)
         self._opt.load_state_dict(opt_state)
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev)
         self._reducer.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -253,7 +265,9 @@ def train(
 
     t = 0.2  # the reference's constant gumbel temperature (train_rqvae.py:177)
     graphed = None
-    if graphable and world == 1:
+    if graphable:
+        # several ranks: the RCCL all-reduces of FlatGradReducer are captured with the step (one graph per rank, replayed in
+        # lockstep: every rank runs the same sequence of full batches; the short batch that ends an epoch is eager on all of them)
         graphed = _GraphedStep(model, optimizer, reducer, batch_size, vae_input_dim, device, t)
     graph_after = start_iter + 3  # a few eager steps first (k-means init, allocator warm-up)
     window: List[torch.Tensor] = []
@@ -291,8 +305,10 @@ def train(
         else:
             reducer.zero_()
             total_loss = 0
-            for _ in range(gradient_accumulate_every):
+            for micro in range(gradient_accumulate_every):
                 data = data if data is not None else next(train_batches)
+                if micro + 1 == gradient_accumulate_every:
+                    reducer.arm()      # the last backward of the step: finished gradients go on the wire under the encoder's
                 with loss_scale(1.0 / gradient_accumulate_every):   # hint for the speculative recon-loss gradient
                     model_output = model(data, gumbel_t=t)
                 loss = model_output.loss / gradient_accumulate_every

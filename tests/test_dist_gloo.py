@@ -63,6 +63,64 @@ def _worker(rank, world, port, out):
     flat2 = reducer.allreduce_mean()
     assert torch.allclose(flat2, want, rtol=1e-5, atol=1e-6)
 
+    # ---- the overlapped reduction: gradients that are final before the encoder's backward go on the wire under it -----------
+    from rqhip.dist import claim_grad_sink
+
+    class SinkLinear(torch.autograd.Function):      # what modules/encoder.py's nodes do: write dW into the flat buffer's slice
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            gw, sink = g.t() @ x, claim_grad_sink(w)
+            if sink is not None:
+                sink.copy_(gw)
+                gw = sink.view_as(sink)
+            return g @ w, gw
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = torch.nn.Linear(6, 4, bias=False)
+            self.decoder = torch.nn.Linear(4, 6, bias=False)
+
+        def forward(self, x):
+            h = torch.relu(SinkLinear.apply(x, self.encoder.weight))
+            red = getattr(self, "_rq_reducer", None)
+            if red is not None:
+                h.register_hook(red.boundary_hook)
+            return SinkLinear.apply(h, self.decoder.weight)
+
+    torch.manual_seed(5)
+    toy, toy_ref = Toy(), Toy()
+    toy_ref.load_state_dict(toy.state_dict())
+    red = rqdist.FlatGradReducer(toy.parameters()).attach(toy)
+    assert red._early_runs == [(24, 48)] and red._late_runs == [(0, 24)]      # decoder weight early, encoder weight late
+    lo, hi = rqdist.shard_bounds(8)
+    toy_ref(X).pow(2).sum(dim=1).mean().backward()
+    want = torch.cat([p.grad.flatten() for p in toy_ref.parameters()])
+    for armed in (False, True):
+        red.zero_()
+        if armed:
+            red.arm()
+        toy(X[lo:hi]).pow(2).sum(dim=1).mean().backward()
+        assert red.overlap_launches == int(armed) and bool(red._pending) == armed
+        got = red.allreduce_mean().clone()
+        assert not red._pending and torch.allclose(got, want, rtol=1e-5, atol=1e-6), (armed, (got - want).abs().max())
+    # gradient accumulation: only the LAST backward of a step may start reducing (armed by the loop just before it)
+    red.zero_()
+    half = (hi - lo) // 2
+    (toy(X[lo:lo + half]).pow(2).sum(dim=1).sum() / (hi - lo)).backward()
+    assert red.overlap_launches == 1
+    red.arm()
+    (toy(X[lo + half:hi]).pow(2).sum(dim=1).sum() / (hi - lo)).backward()
+    assert red.overlap_launches == 2
+    got = red.allreduce_mean()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
+
     # ragged all-gather of id rows
     local = torch.arange(3 + rank).unsqueeze(1).repeat(1, 2) + 100 * rank
     full = rqdist.allgather_rows(local)

@@ -44,14 +44,26 @@ def _items():
     return torch.nn.functional.normalize(torch.randn(ROWS, 768, generator=g), dim=-1).cuda()
 
 
-def _one_step(model, rows, rqdist):
+def _one_step(model, rows, rqdist, micro=1):
+    """One product step (micro > 1: the accumulation form of BASELINE config 4 -- `micro` micro-batches, each weighted by its
+    share of the rows, ONE reduction): zero_ -> [arm before the last] backward(s) -> allreduce_mean -> AdamW."""
     from data.schemas import SeqBatch
+    from rqhip.autograd import loss_scale
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
     reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
     model.train()
     reducer.zero_()
-    out = model(SeqBatch(None, None, None, rows, None, None), gumbel_t=0.2)
-    out.loss.backward()
+    n = rows.shape[0]
+    cuts = [n * i // micro for i in range(micro + 1)]
+    for i in range(micro):
+        part = rows[cuts[i]:cuts[i + 1]]
+        share = part.shape[0] / n
+        if i + 1 == micro:
+            reducer.arm()          # the last backward: decoder / codebook gradients are reduced under the encoder's backward
+        with loss_scale(share):
+            out = model(SeqBatch(None, None, None, part, None, None), gumbel_t=0.2)
+        (out.loss if micro == 1 else out.loss * share).backward()
+    assert reducer.overlap_launches == (1 if rqdist.world_size() > 1 else 0), reducer.overlap_launches
     # the backward kernels wrote every gradient straight into the flat buffer (no packing copy)
     aliased = sum(int(p.grad is not None and p.grad.data_ptr() == v.data_ptr()) for p, v in zip(reducer.params, reducer._views))
     flat = reducer.allreduce_mean().clone()
@@ -125,6 +137,33 @@ def _worker(rank, world, port, tmp):
     gb = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gb, flat)
     assert torch.equal(gb[0], gb[1])
+
+    # (d) the accumulation step of BASELINE config 4: three micro-batches per rank, ONE reduction (armed before the last backward)
+    model4 = _make_model(kmeans_init=False)
+    model4.load_state_dict(start)
+    for layer in model4.layers:
+        layer.kmeans_initted = True
+    flat4, aliased4, _ = _one_step(model4, X[lo:hi], rqdist, micro=3)
+    assert aliased4 == len(list(model4.parameters()))
+    params4 = torch.cat([p.detach().flatten() for p in model4.parameters()])
+    both = [torch.empty_like(params4) for _ in range(world)]
+    dist.all_gather(both, params4)
+    assert torch.equal(both[0], both[1]), "ranks ended the accumulation step with different parameters"
+
+    # (e) the row-sharded corpus tokenisation (semids.py:76-110): every rank tokenises its rows, the table is all-gathered,
+    # the dedup column is computed on the gathered table -- identical on both ranks
+    from data.processed import ItemData, RecDataset
+    from modules.tokenizer.semids import SemanticIdTokenizer
+    tok = SemanticIdTokenizer(input_dim=768, hidden_dims=[512, 256, 128], output_dim=32, codebook_size=256, n_layers=3,
+                              n_cat_feats=0)
+    tok.rq_vae = model
+    ds = ItemData(root="/nonexistent", dataset=RecDataset.AMAZON, train_test_split="all", item_matrix=X[:1501],
+                  is_train=torch.ones(1501, dtype=torch.bool, device="cuda"))
+    table = tok.precompute_corpus_ids(ds, sharded=True)
+    assert table.shape == (1501, 4)
+    both = [torch.empty_like(table) for _ in range(world)]
+    dist.all_gather(both, table.contiguous())
+    assert torch.equal(both[0], both[1])
     rqdist.barrier()
     dist.destroy_process_group()
 
@@ -139,7 +178,15 @@ def _worker(rank, world, port, tmp):
         gscale = max(rflat.abs().max().item(), 1e-6)
         gerr = (flat - rflat).abs().max().item()
         perr = (params - rparams).abs().max().item()
-        torch.save({"gerr": gerr, "gscale": gscale, "perr": perr, "loss": loss, "rloss": rloss}, os.path.join(tmp, "out.pt"))
+        # (d): six micro-batches in two ranks == the full-batch step; (e): sharded table == the single-process table
+        perr4 = (params4 - rparams).abs().max().item()
+        gerr4 = (flat4 - rflat).abs().max().item()
+        tok.reset()
+        local_table = tok.precompute_corpus_ids(ds, sharded=False)
+        ids_differ = int((local_table[:, :3] != table[:, :3]).any(dim=1).sum())
+        torch.save({"gerr": gerr, "gscale": gscale, "perr": perr, "loss": loss, "rloss": rloss, "perr4": perr4, "gerr4": gerr4,
+                    "ids_differ": ids_differ, "dedup_equal": bool(ids_differ > 0 or torch.equal(local_table, table))},
+                   os.path.join(tmp, "out.pt"))
 
 
 def test_two_ranks_on_one_gpu_product_step_and_sharded_kmeans():
@@ -160,3 +207,57 @@ def test_two_ranks_on_one_gpu_product_step_and_sharded_kmeans():
     print("two ranks on one GPU vs single process:", res)
     assert res["gerr"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9, res       # reduced gradients == full-batch gradients
     assert res["perr"] <= 1e-5, res                                           # parameters after AdamW
+    assert res["gerr4"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9 and res["perr4"] <= 1e-5, res   # the accumulation step
+    assert res["ids_differ"] <= 1 and res["dedup_equal"], res                 # sharded tokenisation (a near-tie may flip: tests/parity_gate.py)
+
+
+def _graph_worker(port, tmp):
+    """The hipGraph step with a live RCCL process group (one rank: what a one-GPU box allows): the all-reduces of
+    FlatGradReducer.allreduce_mean are captured with the step and replayed."""
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from rqhip import dist as rqdist
+    from train_rqvae import _GraphedStep
+    rqdist.init_from_env("cuda", force=True)                   # backend "nccl" == RCCL
+    assert dist.is_initialized() and dist.get_backend() == "nccl"
+    X = _items()[:640]
+    losses = []
+    for graphed in (False, True):
+        model = _make_model(kmeans_init=False)
+        for layer in model.layers:
+            layer.kmeans_initted = True
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True, capturable=True)
+        reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
+        step = _GraphedStep(model, opt, reducer, 640, 768, torch.device("cuda", 0), 0.2)
+        model.train()
+        if graphed:
+            step.capture(X)
+            for _ in range(25):
+                out = step.run(X)
+            assert step.captures == 1
+        else:
+            step.x.copy_(X)
+            for _ in range(25):
+                out = step._step()
+        torch.cuda.synchronize()
+        losses.append(float(out.loss))
+    torch.save({"eager": losses[0], "graph": losses[1]}, os.path.join(tmp, "graph.pt"))
+    dist.destroy_process_group()
+
+
+def test_hip_graph_step_with_rccl_group():
+    """`*_graph.gin` with a process group: the captured step contains the RCCL all-reduce (one rank here)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as tmp:
+        p = ctx.Process(target=_graph_worker, args=(_free_port(), tmp))
+        p.start()
+        p.join(timeout=170)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0, p.exitcode
+        res = torch.load(os.path.join(tmp, "graph.pt"))
+    assert res["eager"] == res["eager"] and abs(res["eager"] - res["graph"]) <= 1e-4 * max(1.0, abs(res["eager"])), res
