@@ -116,6 +116,27 @@ def build_model(device, x_init, levels, codes):
     return model, time.perf_counter() - t0
 
 
+def _cpu_limits():
+    """What this process may use of the host: cgroup CPU quota (cores' worth; None = unlimited / unknown) and the affinity mask."""
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                quota = None if q <= 0 else round(q / per, 2)
+        except (OSError, ValueError):
+            pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
+    return quota, affinity
+
+
 def cpu_baseline(batch_rows, levels, codes, budget_s=24.0):
     """Best items/s of the torch-CPU port over thread counts; ~budget_s seconds of CPU work in total."""
     import torch
@@ -140,14 +161,17 @@ def cpu_baseline(batch_rows, levels, codes, budget_s=24.0):
     x640 = x[:640].contiguous()
     r640 = torch_port.time_training_steps(x640, steps=max(5, int(per / 0.05)) if per < 3 else 60, warmup=2, **kw)
     torch.set_num_threads(cores)
+    quota, affinity = _cpu_limits()
     return {"value": round(r["items_per_s"], 1), "unit": "items/s", "cores": t, "host_hardware_threads": cores, "kind": "port",
+            "cgroup_cpu_quota_cores": quota, "affinity_cpus": affinity,
             "sample": f"{r['steps']} fwd+bwd+AdamW steps of {batch_rows} rows ({r['seconds']:.1f} s) at the best of "
                       f"{cand} threads (`cores` = the thread count that won); torch-CPU port of the reference program "
                       f"(oracle/torch_port.py), same model shape",
             "threads_sweep_items_per_s": sweep,
             "batch640_items_per_s": round(r640["items_per_s"], 1),
-            "note": "the reference's own modules on the 8-vCPU build container: BASELINE.md section 2 "
-                    "(tools/time_reference_cpu.py)"}
+            "note": "the reference's own modules on the 8-vCPU build container, and this port beside them on that host: "
+                    "BASELINE.md section 2, profiles/r04_reference_vs_port_cpu.json (tools/time_reference_cpu.py); "
+                    "cgroup_cpu_quota_cores / affinity_cpus: what the box lets this process use of its hardware threads"}
 
 
 def parity_gate(device, tag):

@@ -280,152 +280,177 @@ struct GemmSplitParams {
 
 // developer-only phase-skipping probes of gs_tile2 (tools/ab_build.sh <name> gemm_split.hip -DGS_PROBE=<bits>; results are WRONG
 // with any bit set): 1 no stage barriers, 2 no split / LDS writes, 4 no A loads, 8 no B loads, 16 no matrix instructions,
-// 32 no LDS reads of A, 64 A loads in a contiguous pattern (same bytes, wrong values), 128 epilogue loads / stores in a
-// contiguous pattern (same bytes, wrong places -- NEVER with real outputs: it writes C as a flat array of tile blocks)
+// 32 no LDS reads of A, 64 A loads in a contiguous pattern (same bytes, wrong values).  (Round 4 also had 128: epilogue loads / stores in
+// a contiguous pattern -- what the transposing epilogue below was built on.)
 #ifndef GS_PROBE
 #define GS_PROBE 0
 #endif
 
-// (probe 128) element offset of float4 number `i4` x 64 + lane of the tile's block in a flat, tile-blocked image of C
-__device__ __forceinline__ size_t gs_probe_flat(const GemmSplitParams &p, long long m0, int n0, int ROWS, int COLS, int i4, int lane) {
-    size_t base = (size_t)m0 * p.Nc + (size_t)(n0 / COLS) * ROWS * COLS;     // row tiles are whole-width blocks of ROWS x Nc
-    if (base + (size_t)ROWS * COLS > (size_t)p.M * p.Nc) base = 0;
-    return base + ((size_t)i4 * 64 + lane) * 4;
+// DPP row (16 lanes) reductions: after four row_shr steps lane 15 of every 16-lane row holds the row's result (zeros shifted in)
+__device__ __forceinline__ unsigned gs_row16_umax(unsigned v) {
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = gs_umax(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ float gs_row16_sum(float v) {   // fixed order: ((v + shr1) + shr2) + shr4) + shr8
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
 }
 
+constexpr int kGsTS = 68;     // floats per row of a wave's transposition block (64 + 4: b128 writes of 16 rows hit 64 distinct banks)
+// dynamic LDS the epilogue needs: a [32][kGsTS] transposition block per wave + the two [WN][ROWS] reduction arrays
+__host__ __device__ constexpr size_t gs_epilogue_lds(int waves, int rows, int wn) { return (size_t)waves * 32 * kGsTS * 4 + (size_t)2 * wn * rows * 4; }
+
 // The epilogue of a tile (shared by the tile loops below): undo the scales, apply EPI, store, emit maxima / row losses.
+// The matrix instruction leaves a lane with ONE output row and 4-column pieces of it 32 bytes apart: stored as they lie, every
+// store instruction touched 32 rows x 32 bytes (and the aux loads of EPI 2 / 3 likewise) -- a quarter of every 128-byte line per
+// request; the same bytes in a contiguous pattern were measured 27 us (of 340) faster on 768 -> 512 and 62 us (of 417) on the
+// reconstruction epilogue (tools/gemm_probe2.py).  So every 32-row block of a wave's 128 x 64 tile is transposed through a
+// wave-private LDS block first: written as the accumulators lie, read back with 16 lanes along a row, and all the element-wise
+// work (scales, ReLU / loss / mask, maxima) happens on that side -- a load / store instruction covers 4 rows x 256 contiguous
+// bytes.  Row statistics (squared error, maximum) are reduced over the 16 lanes of a row by DPP, in a fixed order.
 template <int EPI, int TA, int COLS, int NP, int WAVES>
 __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 (&acc)[TA][kGsUB], unsigned *sbuf, const int *s_aexp,
                                             unsigned *s_colmax, long long m0, int n0) {
     constexpr int kGsThreads = 64 * WAVES;
     constexpr int UB = kGsUB, WN = COLS / (32 * UB), WM = WAVES / WN, ROWS = WM * 32 * TA;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(UB == 2, "a wave's tile is 64 columns wide");
+    // (the thread number is laundered through an empty asm: everything below derives from it, so the compiler cannot form the
+    // epilogue's addresses before the main loop and carry them through it -- the loop runs at the register limit)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int il = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // acc[t][u][r]: row = m0 + 32 TA wm + 32 t + il,  column = n0 + 64 wn + 32 u + 8 (r >> 2) + 4 h + (r & 3)
-    // Column group (u, g) outer, row block t inner: the four columns of a group are finished for all of the lane's rows
-    // before the next group starts, so their column maxima need four registers, not sixty-four; a row's statistics (squared
-    // error, maximum) still accumulate over (u, g, j) ascending -- the order of round 3's row-major epilogue, same bits.
-    // EPI 2 / 3 read X / Y beside every result they store.  The compiler may not move a load above a store that could alias
-    // it, so the aux values of a whole column group are requested before its stores, and the next group's before that.
+    const int cl = lane & 15, rl = lane >> 4;                 // after the transposition: column quad cl of the wave's 64, row 4 k + rl
+    float *tb = reinterpret_cast<float *>(sbuf) + (size_t)wave * 32 * kGsTS;
+    float *red = reinterpret_cast<float *>(sbuf) + (size_t)WAVES * 32 * kGsTS;       // [WN][ROWS] squared errors
+    unsigned *mred = reinterpret_cast<unsigned *>(red) + WN * ROWS;                   // [WN][ROWS] row maxima
     const bool want_rowmax = p.c_rowmax != nullptr, want_colmax = p.c_colmax != nullptr;
-    float rowsq[TA];
-    unsigned rowmx[TA];
-    long long rows[TA];
-    int er[TA];
-#pragma unroll
-    for (int t = 0; t < TA; ++t) {
-        rowsq[t] = 0.0f;
-        rowmx[t] = 0u;
-        rows[t] = m0 + 32 * TA * wm + 32 * t + il;
-        er[t] = NP == 2 ? s_aexp[32 * TA * wm + 32 * t + il] : 0;
-    }
-    const int col0 = n0 + 32 * UB * wn + 4 * h;        // + 32 u + 8 g (+ j)
-    constexpr int kAuxDepth = 2;           // column groups whose aux values are in flight ahead of the one being stored
-    gs_f32x4 xv[kAuxDepth + 1][TA];
-    auto load_aux = [&](int ug, gs_f32x4 *dst) {
-#pragma unroll
-        for (int t = 0; t < TA; ++t)
-            if (GS_PROBE & 128) dst[t] = *reinterpret_cast<const gs_f32x4 *>(p.X + gs_probe_flat(p, m0, n0, ROWS, COLS, wave * TA * UB * 4 + t * UB * 4 + ug, lane));
-            else dst[t] = *reinterpret_cast<const gs_f32x4 *>(p.X + (size_t)(rows[t] < p.M ? rows[t] : p.M - 1) * p.Nc + col0 + 32 * (ug >> 2) + 8 * (ug & 3));
+    const int colw = n0 + 64 * wn + 4 * cl;                   // this lane's four columns
+    gs_i32x4 ec = {0, 0, 0, 0};
+    if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + colw);
+    unsigned cmx[4] = {0u, 0u, 0u, 0u};
+    // aux values (X of EPI 2, Y of EPI 3) are requested kAux row quads ahead of their use
+    constexpr int kAux = 4, NQ = 8 * TA;
+    gs_f32x4 xa[kAux];
+    auto aux_of = [&](int q) {
+        long long r = m0 + 32 * TA * wm + 4 * q + rl;        // (q = 8 t + k: the row quads of the wave's tile in order)
+        r = r < p.M ? r : p.M - 1;
+        return *reinterpret_cast<const gs_f32x4 *>(p.X + (size_t)r * p.Nc + colw);
     };
     if (EPI >= 2) {
 #pragma unroll
-        for (int a = 0; a < kAuxDepth; ++a) load_aux(a, xv[a]);
+        for (int q = 0; q < kAux; ++q) xa[q] = aux_of(q);
     }
 #pragma unroll
-    for (int ug = 0; ug < UB * 4; ++ug) {
-        const int u = ug >> 2, g = ug & 3, col = col0 + 32 * u + 8 * g;
-        if (EPI >= 2 && ug + kAuxDepth < UB * 4) load_aux(ug + kAuxDepth, xv[(ug + kAuxDepth) % (kAuxDepth + 1)]);
-        gs_i32x4 ec = {0, 0, 0, 0};
-        if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + col);
-        unsigned cmx[4] = {0u, 0u, 0u, 0u};
+    for (int t = 0; t < TA; ++t) {
+        // acc[t][u][r]: row 32 t + il of the wave's tile, column 32 u + 8 (r >> 2) + 4 h + (r & 3)
 #pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            gs_f32x4 v = {acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<gs_f32x4 *>(tb + il * kGsTS + 32 * u + 8 * g + 4 * h) =
+                    gs_f32x4{acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = 8 * t + k;
+            const int rloc = 32 * TA * wm + 32 * t + 4 * k + rl;     // row inside the workgroup's tile
+            const long long grow = m0 + rloc;
+            gs_f32x4 v = *reinterpret_cast<const gs_f32x4 *>(tb + (4 * k + rl) * kGsTS + 4 * cl);
             if (NP == 2) {   // undo the row and column scales (exact)
+                const int er = s_aexp[rloc];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er[t] + ec[j]);
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er + ec[j]);
+            }
+            gs_f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+            if (EPI >= 2) {
+                x4 = xa[q % kAux];
+                if (q + kAux < NQ) xa[q % kAux] = aux_of(q + kAux);
             }
             if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
                 v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
                 v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
             }
+            float sq = 0.0f;
             if (EPI == 2) {   // as csrc/recon_loss.hip: d = x_hat - x, loss += d d, gradient (2 d) row_scale
-                const gs_f32x4 x4 = xv[ug % (kAuxDepth + 1)][t];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float d = v[j] - x4[j];
-                    rowsq[t] = rowsq[t] + d * d;
+                    sq = sq + d * d;
                     v[j] = (2.0f * d) * p.row_scale;
                 }
             }
             if (EPI == 3) {   // threshold_backward(g, y, 0): 0 where y <= 0
-                const gs_f32x4 y4 = xv[ug % (kAuxDepth + 1)][t];
-                v.x = y4.x <= 0.0f ? 0.0f : v.x; v.y = y4.y <= 0.0f ? 0.0f : v.y;
-                v.z = y4.z <= 0.0f ? 0.0f : v.z; v.w = y4.w <= 0.0f ? 0.0f : v.w;
+                v.x = x4.x <= 0.0f ? 0.0f : v.x; v.y = x4.y <= 0.0f ? 0.0f : v.y;
+                v.z = x4.z <= 0.0f ? 0.0f : v.z; v.w = x4.w <= 0.0f ? 0.0f : v.w;
             }
-            if (rows[t] < p.M) {
+            unsigned rmx = 0u;
+            if (grow < p.M) {
                 if (want_rowmax | want_colmax) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const unsigned b = gs_abs_bits(v[j]);
-                        rowmx[t] = gs_umax(rowmx[t], b);
-                        cmx[j] = gs_umax(cmx[j], b);
+                        const unsigned bb = gs_abs_bits(v[j]);
+                        rmx = gs_umax(rmx, bb);
+                        cmx[j] = gs_umax(cmx[j], bb);
                     }
                 }
-                if (GS_PROBE & 128) *reinterpret_cast<gs_f32x4 *>(p.C + gs_probe_flat(p, m0, n0, ROWS, COLS, wave * TA * UB * 4 + t * UB * 4 + ug, lane)) = v;
-                else *reinterpret_cast<gs_f32x4 *>(p.C + (size_t)rows[t] * p.Nc + col) = v;   // (non-temporal stores: +2 ... +36 %)
+                *reinterpret_cast<gs_f32x4 *>(p.C + (size_t)grow * p.Nc + colw) = v;   // (4 rows x 256 contiguous bytes per instruction)
+            }
+            // the row's 64 columns of this wave lie in the 16 lanes of a DPP row: lane 15 of it ends up with the whole
+            if (EPI == 2) {
+                const float s16 = gs_row16_sum(sq);
+                if (cl == 15) red[wn * ROWS + rloc] = s16;
+            }
+            if (want_rowmax) {
+                const unsigned m16 = gs_row16_umax(rmx);
+                if (cl == 15) mred[wn * ROWS + rloc] = m16;
             }
         }
-        if (want_colmax) {   // the 32 rows of the half-wave (DPP: no LDS traffic), then one LDS (or memory) atomic per column
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();            // (the block is rewritten by the next t)
+    }
+    if (want_colmax) {   // a lane's four columns over all its rows; the four lanes that share them (rl = 0 .. 3), then one atomic per column
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned m = gs_half_wave_umax(cmx[j]);      // valid in lanes 31 and 63
-                if (il == 31 && m != 0u) {
-                    if (p.Nc <= kGsColmaxLds) atomicMax(&s_colmax[col + j], m);
-                    else atomicMax(p.c_colmax + col + j, m);
-                }
+        for (int j = 0; j < 4; ++j) {
+            unsigned m = gs_umax(cmx[j], (unsigned)__shfl_xor((int)cmx[j], 16, 64));
+            m = gs_umax(m, (unsigned)__shfl_xor((int)m, 32, 64));
+            if (rl == 0 && m != 0u) {
+                if (p.Nc <= kGsColmaxLds) atomicMax(&s_colmax[colw + j], m);
+                else atomicMax(p.c_colmax + colw + j, m);
             }
         }
     }
-    if (want_rowmax) {
-        // a row's maximum over this column tile: both lane halves, then the WN column waves through LDS (free: the loop's
-        // last barrier has been passed; EPI 2's `red` lies behind it) -- one part per column tile, one plain store per row
-        unsigned *mred = sbuf + WN * ROWS;                       // [WN][ROWS]
-#pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const unsigned mx = gs_umax(rowmx[t], (unsigned)__shfl_xor((int)rowmx[t], 32, 64));
-            if (h == 0) mred[wn * ROWS + 32 * TA * wm + 32 * t + il] = mx;
-        }
+    if (want_rowmax || EPI == 2) {
+        // the WN column waves of a row meet in LDS (red / mred lie behind the transposition blocks), in wave order
         __syncthreads();
-        unsigned *dst = p.c_rowmax + (size_t)(n0 / COLS) * p.M;
-        for (int r = tid; r < ROWS; r += kGsThreads) {
-            if (m0 + r >= p.M) continue;
-            unsigned mx = mred[r];
+        if (want_rowmax) {
+            unsigned *dst = p.c_rowmax + (size_t)(n0 / COLS) * p.M;
+            for (int r = tid; r < ROWS; r += kGsThreads) {
+                if (m0 + r >= p.M) continue;
+                unsigned mx = mred[r];
 #pragma unroll
-            for (int w = 1; w < WN; ++w) mx = gs_umax(mx, mred[w * ROWS + r]);
-            dst[m0 + r] = mx;
+                for (int w = 1; w < WN; ++w) mx = gs_umax(mx, mred[w * ROWS + r]);
+                dst[m0 + r] = mx;
+            }
         }
-    }
-    if (EPI == 2) {
-        // a row's squared error over this column tile: the lane's 32 columns (above, fixed order), + the other half-wave's,
-        // then the four column waves in order through LDS (free: the loop's last barrier has been passed)
-        float *red = reinterpret_cast<float *>(sbuf);          // [WN][ROWS]
+        if (EPI == 2) {
+            for (int r = tid; r < ROWS; r += kGsThreads) {
+                if (m0 + r >= p.M) continue;
+                float sum = red[r];
 #pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            const float both = rowsq[t] + __shfl_xor(rowsq[t], 32, 64);
-            if (h == 0) red[wn * ROWS + 32 * TA * wm + 32 * t + il] = both;
+                for (int w = 1; w < WN; ++w) sum = sum + red[w * ROWS + r];
+                p.rowsum[(size_t)(n0 / COLS) * p.M + m0 + r] = sum;
+            }
         }
-        __syncthreads();
-        for (int r = tid; r < ROWS; r += kGsThreads) {
-            if (m0 + r >= p.M) continue;
-            float sum = red[r];
-#pragma unroll
-            for (int w = 1; w < WN; ++w) sum = sum + red[w * ROWS + r];
-            p.rowsum[(size_t)(n0 / COLS) * p.M + m0 + r] = sum;
-        }
-        // (the persistent loop's barrier at its top keeps the next tile's staging off `red`)
+        // (the persistent loop's barrier at its top keeps the next tile's staging off these arrays)
     }
 }
 
@@ -1034,7 +1059,9 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
-    const size_t lds = tile2 ? (size_t)2 * 4 * (128 * 4 + 32) * 4 : (size_t)2 * (np * 2 * (big_rows + cols) * 16);
+    size_t lds = tile2 ? (size_t)2 * 4 * (128 * 4 + 32) * 4 : (size_t)2 * (np * 2 * (big_rows + cols) * 16);   // the stage buffers
+    const size_t lds_epi = gs_epilogue_lds(waves, big_rows, cols / 64);                                         // re-used by the epilogue
+    if (lds < lds_epi) lds = lds_epi;
     const long long tiles = (long long)p.n_tiles;
     const int grid = (int)(tiles < slots ? tiles : slots);
     auto go = [&](auto kern) -> int {

@@ -218,9 +218,18 @@ def _graph_worker(port, tmp):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import traceback
     import torch.distributed as dist
     from rqhip import dist as rqdist
     from train_rqvae import _GraphedStep
+    try:
+        _graph_body(tmp, dist, rqdist, _GraphedStep)
+    except Exception:     # (the parent shows it: a bare exit code says nothing)
+        torch.save({"error": traceback.format_exc()}, os.path.join(tmp, "graph.pt"))
+        raise
+
+
+def _graph_body(tmp, dist, rqdist, _GraphedStep):
     rqdist.init_from_env("cuda", force=True)                   # backend "nccl" == RCCL
     assert dist.is_initialized() and dist.get_backend() == "nccl"
     X = _items()[:640]
@@ -258,6 +267,8 @@ def test_hip_graph_step_with_rccl_group():
         p.join(timeout=170)
         if p.is_alive():
             p.kill()
-        assert p.exitcode == 0, p.exitcode
-        res = torch.load(os.path.join(tmp, "graph.pt"))
-    assert res["eager"] == res["eager"] and abs(res["eager"] - res["graph"]) <= 1e-4 * max(1.0, abs(res["eager"])), res
+        res = torch.load(os.path.join(tmp, "graph.pt")) if os.path.exists(os.path.join(tmp, "graph.pt")) else {}
+        assert p.exitcode == 0 and "error" not in res, (p.exitcode, res.get("error"))
+    # 25 AdamW steps from the same start: the two trajectories agree to rounding noise amplified by the optimiser (the bound of
+    # tests/test_gpu_train.py:test_hip_graph_step_matches_eager)
+    assert res["eager"] == res["eager"] and abs(res["eager"] - res["graph"]) <= 2e-3 * max(1.0, abs(res["eager"])), res

@@ -42,10 +42,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.exit(0)
 
 names = {1: "no barriers", 2: "no split/LDS writes", 4: "no A loads", 8: "no B loads", 16: "no MFMA", 32: "no LDS reads", 64: "A loads contiguous", 128: "epilogue contiguous"}
-libs = [("-", 0)] + sorted(((f, int(os.path.basename(f)[len("librqhip_p"):-3])) for f in glob.glob(os.path.join(ROOT, "tools", "_ab", "librqhip_p*.so"))
+extra = [(a, -1) for a in sys.argv[1:] if a.endswith(".so")]      # other builds to time next to the product (any name)
+libs = [("-", 0)] + extra + sorted(((f, int(os.path.basename(f)[len("librqhip_p"):-3])) for f in glob.glob(os.path.join(ROOT, "tools", "_ab", "librqhip_p*.so"))
                            if os.path.basename(f)[len("librqhip_p"):-3].isdigit()), key=lambda t: t[1])
 print(f"{'build':>44} | 768->512 relu  512->768 store  512->768 recon  512->256 relu   (us, 100 000 rows)")
 for path, bits in libs * 2:
-    what = "product" if bits == 0 else " + ".join(v for k, v in names.items() if bits & k)
+    what = "product" if bits == 0 else os.path.basename(path) if bits < 0 else " + ".join(v for k, v in names.items() if bits & k)
     r = subprocess.run([sys.executable, __file__, "--one", path], capture_output=True, text=True)
     print(f"{what:>44} | {r.stdout.strip() or r.stderr.strip()[-300:]}", flush=True)

@@ -118,6 +118,17 @@ def main():
     res["kmeans_20000x32_k256"] = {"s_per_iter": round(t, 4)}
     print(f"Kmeans.run 20000x32 k=256: {t * 1e3:.1f} ms/iteration", flush=True)
 
+    # the port bench.py's `cpu_baseline` times on the GPU host (oracle/torch_port.py; /root/reference does not exist there), on
+    # the same host, threads, rows and model shape as the reference's S-full numbers above: how far the port is from what it stands for
+    from oracle import torch_port
+    for B in (640, 8192):
+        r_port = torch_port.time_training_steps(X[:B].contiguous(), steps=20 if B == 640 else 5, warmup=3, hidden=[512, 256, 128],
+                                                embed_dim=32, n_levels=3, codebook_size=256, beta=0.25)
+        ref_ips = res[f"s_full_ste_B{B}"]["items_per_s"]
+        res[f"port_s_full_ste_B{B}"] = {"items_per_s": round(r_port["items_per_s"], 1),
+                                        "port_over_reference": round(r_port["items_per_s"] / ref_ips, 3)}
+        print(f"port S-full STE B={B}: {r_port['items_per_s']:,.0f} items/s = {r_port['items_per_s'] / ref_ips:.2f} x the reference's own modules", flush=True)
+
     with open(args.out, "w") as fh:
         json.dump(res, fh, indent=1)
     print("wrote", args.out)
