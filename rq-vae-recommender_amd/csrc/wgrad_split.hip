@@ -140,6 +140,12 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         for (int cc = 0; cc < 4; ++cc)
             ue[q][cc] = (mxp && ((UNITS % NT == 0) || u < UNITS)) ? ws_exp_of_bits(mxp[c0 + 4 * cq + cc]) : 0;
     }
+    // Loads of a row past the range: UNCONDITIONAL (the range's last row is re-read and a select zeroes it) for the 4-wave
+    // configurations -- a load under `if (ok)` is a basic block of its own, eight to twelve per stage, each with its own wait, and
+    // nothing is scheduled across them: 146 -> 137 us (dW [256, 512]), 70 -> 60 us ([128, 256]) at 100 000 rows -- but PREDICATED
+    // for the 256 x 256 configuration, which lost 7 % with the unconditional form (tools/wgrad_ab.py, profiles/r04_wgrad_ab.txt:
+    // 367 -> 387 us for dW [512, 768]; its out-of-phase wave pairs want the staging of a stage kept together).
+    constexpr bool kUncond = TA * TB < 8;
     auto fetch = [&](long long stage) {
         const long long row0 = r_begin + stage * kWsRows;
 #pragma unroll
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             const int u = tid + q * NT;
             const bool live = (UNITS % NT == 0) || u < UNITS;
             const bool isg = u < Nt;                          // (wave-uniform: Nt is a multiple of 64)
-            const int idx = isg ? u : u - Nt, W = isg ? Nt : Kt;
+            const int idx = live ? (isg ? u : u - Nt) : 0, W = isg ? Nt : Kt;
             const int cq = idx % (W / 4), rq = idx / (W / 4);
             const float *base = isg ? p.g : p.x;
             const int ld = isg ? p.N : p.K, c0 = isg ? n0 : k0;
@@ -155,9 +161,19 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             for (int j = 0; j < 4; ++j) {
                 const long long row = row0 + 4 * rq + j;
                 const bool ok = live && row < r_end;
-                const size_t off = (size_t)(ok ? row : 0) * ld + c0 + 4 * cq;
-                rv[q][j] = ok ? *reinterpret_cast<const ws_f32x4 *>(base + off) : ws_f32x4{0.f, 0.f, 0.f, 0.f};
-                if (MASK) ry[q][j] = (ok && isg) ? *reinterpret_cast<const ws_f32x4 *>(p.y + off) : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+                if constexpr (kUncond) {
+                    const size_t off = (size_t)(row < r_end ? row : r_end - 1) * ld + c0 + 4 * cq;
+                    const ws_f32x4 v = *reinterpret_cast<const ws_f32x4 *>(base + off);
+                    rv[q][j] = ok ? v : ws_f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (MASK) {
+                        const ws_f32x4 yv = *reinterpret_cast<const ws_f32x4 *>(p.y + (isg ? off : (size_t)0));
+                        ry[q][j] = (ok && isg) ? yv : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
+                } else {
+                    const size_t off = (size_t)(ok ? row : 0) * ld + c0 + 4 * cq;
+                    rv[q][j] = ok ? *reinterpret_cast<const ws_f32x4 *>(base + off) : ws_f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (MASK) ry[q][j] = (ok && isg) ? *reinterpret_cast<const ws_f32x4 *>(p.y + off) : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+                }
             }
         }
     };
@@ -274,22 +290,31 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 
     // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r]:
     // n = n0 + wave's base + 32 t + 8 (r >> 2) + 4 h + (r & 3),  k = k0 + wave's base + 32 u + il
+    // (NP == 2: the column exponents are fetched with two + TA * 4 vector loads up front -- one scalar load per stored element,
+    // each under its own null test, made 256 basic blocks of this epilogue, every one waiting for its own load)
     float *dst = p.out + (size_t)split * p.N * p.K;
+    int ek[TB];
 #pragma unroll
-    for (int t = 0; t < TA; ++t)
+    for (int u = 0; u < TB; ++u) ek[u] = (NP == 2 && p.x_max) ? ws_exp_of_bits(p.x_max[k0 + wb * 32 * TB + 32 * u + il]) : 0;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
+        ws_u32x4 gb[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            gb[g4] = (NP == 2 && p.g_max) ? *reinterpret_cast<const ws_u32x4 *>(p.g_max + n0 + wa * 32 * TA + 32 * t + 8 * g4 + 4 * h)
+                                          : ws_u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int u = 0; u < TB; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-                if constexpr (NP == 2) {   // undo the column scales (exact)
-                    const int k = k0 + wb * 32 * TB + 32 * u + il;
-                    const int e = (p.g_max ? ws_exp_of_bits(p.g_max[n]) : 0) + (p.x_max ? ws_exp_of_bits(p.x_max[k]) : 0);
-                    dst[(size_t)n * p.K + k] = ldexpf(acc[t][u][r], e);
-                    continue;
-                }
-                dst[(size_t)n * p.K + k0 + wb * 32 * TB + 32 * u + il] = acc[t][u][r];
+                const int k = k0 + wb * 32 * TB + 32 * u + il;
+                float v = acc[t][u][r];
+                if constexpr (NP == 2) v = ldexpf(v, ws_exp_of_bits(gb[r >> 2][r & 3]) + ek[u]);   // undo the column scales (exact)
+                dst[(size_t)n * p.K + k] = v;
             }
+    }
 }
 
 // shapes the split kernel tiles: both dimensions multiples of 128 (every large layer of the 768-512-256-128 MLPs)

@@ -242,14 +242,16 @@ def _graph_body(tmp, dist, rqdist, _GraphedStep):
         reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
         step = _GraphedStep(model, opt, reducer, 640, 768, torch.device("cuda", 0), 0.2)
         model.train()
+        step.x.copy_(X)
+        for _ in range(3):          # as train_rqvae.train: a few eager steps first (the optimizer's state must exist before a
+            step._step()            # capture -- its lazy initialisation inside one would be replayed with every step)
         if graphed:
             step.capture(X)
-            for _ in range(25):
+            for _ in range(22):
                 out = step.run(X)
             assert step.captures == 1
         else:
-            step.x.copy_(X)
-            for _ in range(25):
+            for _ in range(22):
                 out = step._step()
         torch.cuda.synchronize()
         losses.append(float(out.loss))
