@@ -125,6 +125,9 @@ class _GraphedStep:
         their optimizer updates are rolled back (parameters and optimizer state are snapshotted and restored), so a
         capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
         import copy
+        if not self._opt.state:
+            raise RuntimeError("_GraphedStep.capture: run a few eager steps first -- the optimizer creates its state lazily in its "
+                               "first step, and a creation recorded into the graph would reset the moments at every replay")
         self.x.copy_(x)
         self.captures += 1
         if self.captures in (2, 10, 100, 1000):     # every eager excursion (a short epoch-tail batch, eval, checkpoint) costs one
