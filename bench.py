@@ -90,6 +90,7 @@ def parse_args():
                          "under exact power-of-two scales, three piece products (csrc/gemm_split.hip, wgrad_split.hip); `split6`: "
                          "round 3's three bf16 pieces and six products; `library`: library fp32 GEMMs and the fp32-MFMA weight "
                          "gradients (round 2's step)")
+    ap.add_argument("--no-narrow", action="store_true", help="A/B: layers of 128 (mod 256) columns on the library instead of the split kernel's 128-column tile")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="if the K timed steps took less, also time a longer region and report it as `long_run`")
     return ap.parse_args()
@@ -302,6 +303,7 @@ def main():
     tuned = tuning.enable_tuned_gemms()   # fp32 library-GEMM selections for the MLP layers the split kernels do not tile
     from rqhip import linear as _lin
     _lin.use_arith({"split": "f16x2", "split6": "bf16x3", "library": "fp32"}[args.mlp])   # (A/B arms: tools/profile_mlp_ab.sh)
+    _lin.use_narrow_tiles(not args.no_narrow)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)
     for lo in range(0, B, 250_000):        # generated in host chunks: 1.25 M x 768 fp32 is 3.8 GB

@@ -42,6 +42,12 @@ typedef unsigned ws_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWsRows = 16;   // rows per LDS stage = one K step of the matrix instruction
 
+// developer-only phase-skipping probes (tools/ab_build.sh <name> wgrad_split.hip -DWS_PROBE=<bits>; results are WRONG with any bit
+// set): 1 no split / LDS writes, 2 no global loads, 4 no matrix instructions, 8 no LDS reads, 16 no stage barriers
+#ifndef WS_PROBE
+#define WS_PROBE 0
+#endif
+
 struct WgradSplitParams {
     const float *g, *y, *x;
     float *gm, *out;
@@ -140,13 +146,32 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         for (int cc = 0; cc < 4; ++cc)
             ue[q][cc] = (mxp && ((UNITS % NT == 0) || u < UNITS)) ? ws_exp_of_bits(mxp[c0 + 4 * cq + cc]) : 0;
     }
-    // Loads of a row past the range: UNCONDITIONAL (the range's last row is re-read and a select zeroes it) for the 4-wave
-    // configurations -- a load under `if (ok)` is a basic block of its own, eight to twelve per stage, each with its own wait, and
-    // nothing is scheduled across them: 146 -> 137 us (dW [256, 512]), 70 -> 60 us ([128, 256]) at 100 000 rows -- but PREDICATED
-    // for the 256 x 256 configuration, which lost 7 % with the unconditional form (tools/wgrad_ab.py, profiles/r04_wgrad_ab.txt:
-    // 367 -> 387 us for dW [512, 768]; its out-of-phase wave pairs want the staging of a stage kept together).
-    constexpr bool kUncond = TA * TB < 8;
-    auto fetch = [&](long long stage) {
+    // Staging loads.  A thread's unit (4 rows x 4 columns) sits at the same place of every stage, 16 rows further down: the
+    // four row pointers are formed ONCE and advanced by 16 rows per stage (one 64-bit add each) -- recomputing `(row0 + 4 rq + j)
+    // * ld + c0 + 4 cq` with its 64-bit multiplies, the row test and the predication for every load of every stage was ~100
+    // integer instructions per stage next to the 64 of the split itself.  Whole stages (every row inside the range) take this
+    // path with plain loads; only the range's last, partial stage takes `fetch_tail` (predicated, addresses from scratch).
+    const long long n_full = (r_end - r_begin) / kWsRows;           // stages whose 16 rows all lie inside [r_begin, r_end)
+    const float *cur[UQ][4];
+    const float *ycur[MASK ? UQ : 1][4];
+    size_t step16[UQ];
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) {
+        const int u = tid + q * NT;
+        const bool live = (UNITS % NT == 0) || u < UNITS;
+        const bool isg = u < Nt;
+        const int idx = live ? (isg ? u : u - Nt) : 0, W = isg ? Nt : Kt;
+        const int cq = idx % (W / 4), rq = idx / (W / 4);
+        const int ld = isg ? p.N : p.K, c0 = isg ? n0 : k0;
+        step16[q] = (size_t)kWsRows * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t off = (size_t)(r_begin + 4 * rq + j) * ld + c0 + 4 * cq;
+            cur[q][j] = (isg ? p.g : p.x) + off;
+            if (MASK) ycur[q][j] = p.y + (isg ? off : (size_t)0);
+        }
+    }
+    auto fetch_tail = [&](long long stage) {
         const long long row0 = r_begin + stage * kWsRows;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
@@ -161,25 +186,45 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             for (int j = 0; j < 4; ++j) {
                 const long long row = row0 + 4 * rq + j;
                 const bool ok = live && row < r_end;
-                if constexpr (kUncond) {
-                    const size_t off = (size_t)(row < r_end ? row : r_end - 1) * ld + c0 + 4 * cq;
-                    const ws_f32x4 v = *reinterpret_cast<const ws_f32x4 *>(base + off);
-                    rv[q][j] = ok ? v : ws_f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (MASK) {
-                        const ws_f32x4 yv = *reinterpret_cast<const ws_f32x4 *>(p.y + (isg ? off : (size_t)0));
-                        ry[q][j] = (ok && isg) ? yv : ws_f32x4{1.f, 1.f, 1.f, 1.f};
-                    }
+                const size_t off = (size_t)(ok ? row : 0) * ld + c0 + 4 * cq;
+                rv[q][j] = ok ? *reinterpret_cast<const ws_f32x4 *>(base + off) : ws_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (MASK) ry[q][j] = (ok && isg) ? *reinterpret_cast<const ws_f32x4 *>(p.y + off) : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+        }
+    };
+    // (stages are fetched in order 0, 1, 2, ...: `cur` always points at the next one)
+    auto fetch = [&](long long stage) {
+        if (stage >= n_full) {
+            fetch_tail(stage);
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int u = tid + q * NT;
+            const bool live = (UNITS % NT == 0) || u < UNITS;
+            const bool isg = u < Nt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr ((WS_PROBE & 2) != 0) {
+                    rv[q][j] = ws_f32x4{1.f + (float)stage, 2.f, 3.f, 4.f};
+                    if (MASK) ry[q][j] = ws_f32x4{1.f, 1.f, 1.f, 1.f};
                 } else {
-                    const size_t off = (size_t)(ok ? row : 0) * ld + c0 + 4 * cq;
-                    rv[q][j] = ok ? *reinterpret_cast<const ws_f32x4 *>(base + off) : ws_f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (MASK) ry[q][j] = (ok && isg) ? *reinterpret_cast<const ws_f32x4 *>(p.y + off) : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+                    const ws_f32x4 v = *reinterpret_cast<const ws_f32x4 *>(cur[q][j]);
+                    rv[q][j] = live ? v : ws_f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (MASK) {
+                        const ws_f32x4 yv = *reinterpret_cast<const ws_f32x4 *>(ycur[q][j]);
+                        ry[q][j] = (live && isg) ? yv : ws_f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
                 }
+                cur[q][j] += step16[q];
+                if (MASK && isg) ycur[q][j] += step16[q];
             }
         }
     };
     auto stash = [&](long long stage, int buf) {
         const long long row0 = r_begin + stage * kWsRows;
         unsigned *dst = sbuf + buf * (PART_G + PART_X);
+        if (WS_PROBE & 1) return;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
             const int u = tid + q * NT;
@@ -247,19 +292,23 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         for (int t = 0; t < TA; ++t)
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc)
-                a[t][pc] = gA[(pc * 2 + h) * (4 * SG) + (il & 3) * SG + ((wa * 32 * TA + 32 * t + il) >> 2)];
+                a[t][pc] = (WS_PROBE & 8) ? ws_bf16x8{(__bf16)(float)(t + buf), 1, 2, 3, 4, 5, 6, 7}
+                                          : gA[(pc * 2 + h) * (4 * SG) + (il & 3) * SG + ((wa * 32 * TA + 32 * t + il) >> 2)];
 #pragma unroll
         for (int u = 0; u < TB; ++u)
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc)
-                b[u][pc] = xB[(pc * 2 + h) * (4 * SX) + (il & 3) * SX + ((wb * 32 * TB + 32 * u + il) >> 2)];
+                b[u][pc] = (WS_PROBE & 8) ? ws_bf16x8{(__bf16)(float)(u + buf), 1, 2, 3, 4, 5, 6, 7}
+                                          : xB[(pc * 2 + h) * (4 * SX) + (il & 3) * SX + ((wb * 32 * TB + 32 * u + il) >> 2)];
         // smallest products first (their sum is formed before it meets the large ones)
 #pragma unroll
         for (int t = 0; t < TA; ++t)
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 ws_f32x16 c16 = acc[t][u];
-                if constexpr (NP == 2) {
+                if constexpr ((WS_PROBE & 4) != 0) {
+                    c16[0] += (float)a[t][0][0] + (float)b[u][0][1] + (float)a[t][NP - 1][2] + (float)b[u][NP - 1][3];
+                } else if constexpr (NP == 2) {
                     c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][1]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // m h
                     c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][1]), c16, 0, 0, 0);   // h m
                     c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a[t][0]), __builtin_bit_cast(ws_f16x8, b[u][0]), c16, 0, 0, 0);   // h h
@@ -285,7 +334,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             if (c + 1 < n_stage) stash(c + 1, buf ^ 1);
             if (c + 2 < n_stage) fetch(c + 2);
         }
-        __syncthreads();
+        if (!(WS_PROBE & 16)) __syncthreads();
     }
 
     // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r]:

@@ -83,11 +83,21 @@ def split_ok(x: Tensor, n_cols: int, n_red: int, forward_relu: bool = False) -> 
 
 
 def _wide(n_cols: int) -> bool:
-    """Layers of 256 (mod 256) output columns only.  The kernel also has a 256 x 128 tile for 128 (mod 256) columns
-    (csrc/gemm_split.hip, tested), but the layers that would take it are HBM-bound at these widths and the library is as
-    fast: 100 000 x 256 -> 128 forward 58 us vs 67, its data gradient 59 vs 56, 100 000 x 32 -> 128 24 vs 25 (round 3,
-    tools/bench_gemm_split.py)."""
-    return n_cols % 256 == 0
+    """Layers of 128 (mod 128) output columns: 256-column tiles (the product kernel) or, for 128 (mod 256) columns, the staged
+    loop's 128-column tile.  Round 3 left the latter to the library (HBM-bound shapes, measured level: 100 000 x 256 -> 128
+    forward 58 us vs 67, its data gradient 59 vs 56); with the f16x2 arithmetic, maxima from the epilogues and the transposing
+    epilogue the step is 2 % faster with them on the split kernel (3.06 -> 2.99 ms, bench.py --no-narrow for the A/B)."""
+    return n_cols % 256 == 0 or (_NARROW and n_cols % 128 == 0)
+
+
+_NARROW = True
+
+
+def use_narrow_tiles(on: bool = True) -> bool:
+    """A/B switch (bench.py --no-narrow): layers of 128 (mod 256) output columns through the split kernel's 128-column tile as well."""
+    global _NARROW
+    before, _NARROW = _NARROW, bool(on)
+    return before
 
 
 def split_shape_ok(rows: int, n_cols: int, n_red: int) -> bool:
