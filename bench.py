@@ -90,6 +90,7 @@ def parse_args():
                          "under exact power-of-two scales, three piece products (csrc/gemm_split.hip, wgrad_split.hip); `split6`: "
                          "round 3's three bf16 pieces and six products; `library`: library fp32 GEMMs and the fp32-MFMA weight "
                          "gradients (round 2's step)")
+    ap.add_argument("--lib", default=None, help="developer A/B: another build of librqhip.so (same ABI) instead of the in-tree one")
     ap.add_argument("--no-narrow", action="store_true", help="A/B: layers of 128 (mod 256) columns on the library instead of the split kernel's 128-column tile")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="if the K timed steps took less, also time a longer region and report it as `long_run`")
@@ -300,6 +301,9 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    if args.lib:
+        from rqhip import _lib as _rqlib
+        _rqlib.load(os.path.abspath(args.lib))
     tuned = tuning.enable_tuned_gemms()   # fp32 library-GEMM selections for the MLP layers the split kernels do not tile
     from rqhip import linear as _lin
     _lin.use_arith({"split": "f16x2", "split6": "bf16x3", "library": "fp32"}[args.mlp])   # (A/B arms: tools/profile_mlp_ab.sh)
@@ -457,7 +461,7 @@ def main():
         bytes_per_row = 8 * EMBED + 12 * LEVELS + 4                          # fwd: 296 B (c2), 308 B (c4)
         traffic, traffic_src = None, None
         from rqhip import _lib as _rqlib
-        lib_sha = _sha256_file(_rqlib.SO_PATH)
+        lib_sha = _sha256_file(os.path.abspath(args.lib) if args.lib else _rqlib.SO_PATH)
         pmc = args.pmc_file or os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{args.config}.json")
         if not os.path.exists(pmc):
             traffic_src = f"null: no PMC file {os.path.relpath(pmc, ROOT)}"

@@ -85,21 +85,7 @@ constexpr int kGsF16Top = 14;
 __device__ __forceinline__ int gs_exp_of_bits(unsigned b) {
     b &= 0x7fffffffu;
     const int e = (int)(b >> 23);
-    const int r = (e == 0 ? -126 : e - 127) - kGsF16Top;
-    return (b == 0u || e == 255) ? 0 : (r < -126 ? -126 : r);      // (>= -126: the scale 2^-e is then a normal float, gs_pow2)
-}
-// 2^-e as a float, e in [-126, 126] (gs_exp_of_bits stays inside): the rows are scaled by a MULTIPLICATION with it -- exact, as
-// v_ldexp_f32 is, but two values per instruction (v_pk_mul_f32), and the residual v - h likewise (v_pk_add_f32)
-__device__ __forceinline__ float gs_pow2_neg(int e) { return __builtin_bit_cast(float, (unsigned)(127 - e) << 23); }
-// four values of one row (scale sc = 2^-e): packed fp16 pieces of (v0, v1) and (v2, v3)
-__device__ __forceinline__ void gs_scale_split4(const gs_f32x4 v, float sc, unsigned &h01, unsigned &m01, unsigned &h23, unsigned &m23) {
-    const gs_f32x2 s2 = {sc, sc};
-    const gs_f32x2 a = gs_f32x2{v.x, v.y} * s2, b = gs_f32x2{v.z, v.w} * s2;
-    const gs_f16x2 ha = __builtin_convertvector(a, gs_f16x2), hb = __builtin_convertvector(b, gs_f16x2);
-    const gs_f32x2 ra = a - __builtin_convertvector(ha, gs_f32x2), rb = b - __builtin_convertvector(hb, gs_f32x2);
-    const gs_f16x2 ma = __builtin_convertvector(ra, gs_f16x2), mb = __builtin_convertvector(rb, gs_f16x2);
-    h01 = __builtin_bit_cast(unsigned, ha); h23 = __builtin_bit_cast(unsigned, hb);
-    m01 = __builtin_bit_cast(unsigned, ma); m23 = __builtin_bit_cast(unsigned, mb);
+    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127) - kGsF16Top;
 }
 __device__ __forceinline__ unsigned gs_abs_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
 // max of the bit patterns of |values| == bit pattern of the largest |value| for everything that is not a NaN; a NaN wins
@@ -550,7 +536,8 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
             if (!a_live[q]) continue;
             unsigned h01, m01, l01 = 0u, h23, m23, l23 = 0u;
             if (NP == 2) {
-                gs_scale_split4(ra[q], gs_pow2_neg(a_e[q]), h01, m01, h23, m23);
+                gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
+                gs_split2_f16(ldexpf(ra[q].z, -a_e[q]), ldexpf(ra[q].w, -a_e[q]), h23, m23);
             } else {
                 gs_split2(ra[q].x, ra[q].y, h01, m01, l01);
                 gs_split2(ra[q].z, ra[q].w, h23, m23, l23);
@@ -683,7 +670,6 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
     const int arow = tid >> 2, akq = tid & 3;
     const float *asrc[AQ];
     int a_e[AQ];
-    float a_sc[AQ];                                                  // 2^-a_e: the rows' scale
     bool a_live[AQ];
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
@@ -700,7 +686,6 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
             mx = gs_umax(gs_umax(mx, gs_umax(v[0], v[1])), gs_umax(v[2], v[3]));
         }
         a_e[q] = gs_exp_of_bits(mx);
-        a_sc[q] = gs_pow2_neg(a_e[q]);
         if (a_live[q] && akq == 0) s_aexp[arow + APASS * q] = a_e[q];   // (read by the epilogue, many barriers later)
     }
 
@@ -748,7 +733,8 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
         for (int q = 0; q < AQ; ++q) {
             if (!kAllLive && !a_live[q]) continue;
             unsigned h01, m01, h23, m23;
-            gs_scale_split4(ra[q], a_sc[q], h01, m01, h23, m23);
+            gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
+            gs_split2_f16(ldexpf(ra[q].z, -a_e[q]), ldexpf(ra[q].w, -a_e[q]), h23, m23);
             // region [piece][half = akq >> 1], element [row] = 16 bytes (r 8 half .. 8 half + 7); this thread fills its 8 bytes
             unsigned *d = dA + (akq >> 1) * kRegion + (arow + APASS * q) * 4 + 2 * (akq & 1);
             *reinterpret_cast<gs_u32x2 *>(d) = gs_u32x2{h01, h23};

@@ -84,17 +84,7 @@ __device__ __forceinline__ void ws_split2_f16(float a, float b, unsigned &h, uns
 __device__ __forceinline__ int ws_exp_of_bits(unsigned b) {
     b &= 0x7fffffffu;
     const int e = (int)(b >> 23);
-    const int r = (e == 0 ? -126 : e - 127) - 14;
-    return (b == 0u || e == 255) ? 0 : (r < -126 ? -126 : r);      // (>= -126: 2^-e is a normal float)
-}
-// (a, b) scaled by the power of two sc, then split: the scaling and the residual as packed fp32 instructions (csrc/gemm_split.hip)
-__device__ __forceinline__ void ws_scale_split2_f16(float a, float b, float sc, unsigned &h, unsigned &m) {
-    const ws_f32x2 v = ws_f32x2{a, b} * ws_f32x2{sc, sc};
-    const ws_f16x2 hh = __builtin_convertvector(v, ws_f16x2);
-    const ws_f32x2 r = v - __builtin_convertvector(hh, ws_f32x2);
-    const ws_f16x2 mm = __builtin_convertvector(r, ws_f16x2);
-    h = __builtin_bit_cast(unsigned, hh);
-    m = __builtin_bit_cast(unsigned, mm);
+    return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127) - 14;
 }
 
 // TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given; NP: pieces per operand (3 bf16 / 2 fp16 under column scales)
@@ -143,7 +133,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
     ws_f32x4 rv[UQ][4], ry[MASK ? UQ : 1][4];
-    float usc[NP == 2 ? UQ : 1][4];   // NP == 2: the scales 2^-e of the four columns of each of this thread's staging units
+    int ue[NP == 2 ? UQ : 1][4];   // NP == 2: exponents of the four columns of each of this thread's staging units
 #pragma unroll
     for (int q = 0; q < (NP == 2 ? UQ : 0); ++q) {
         const int u = tid + q * NT;
@@ -154,7 +144,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         const int c0 = isg ? n0 : k0;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
-            usc[q][cc] = __builtin_bit_cast(float, (unsigned)(127 - ((mxp && ((UNITS % NT == 0) || u < UNITS)) ? ws_exp_of_bits(mxp[c0 + 4 * cq + cc]) : 0)) << 23);
+            ue[q][cc] = (mxp && ((UNITS % NT == 0) || u < UNITS)) ? ws_exp_of_bits(mxp[c0 + 4 * cq + cc]) : 0;
     }
     // Staging loads.  A thread's unit (4 rows x 4 columns) sits at the same place of every stage, 16 rows further down: the
     // four row pointers are formed ONCE and advanced by 16 rows per stage (one 64-bit add each) -- recomputing `(row0 + 4 rq + j)
@@ -266,8 +256,8 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             for (int cc = 0; cc < 4; ++cc) {
                 unsigned h01, m01, l01 = 0u, h23, m23, l23 = 0u;
                 if constexpr (NP == 2) {
-                    ws_scale_split2_f16(rv[q][0][cc], rv[q][1][cc], usc[q][cc], h01, m01);
-                    ws_scale_split2_f16(rv[q][2][cc], rv[q][3][cc], usc[q][cc], h23, m23);
+                    ws_split2_f16(ldexpf(rv[q][0][cc], -ue[q][cc]), ldexpf(rv[q][1][cc], -ue[q][cc]), h01, m01);
+                    ws_split2_f16(ldexpf(rv[q][2][cc], -ue[q][cc]), ldexpf(rv[q][3][cc], -ue[q][cc]), h23, m23);
                 } else {
                     ws_split2(rv[q][0][cc], rv[q][1][cc], h01, m01, l01);
                     ws_split2(rv[q][2][cc], rv[q][3][cc], h23, m23, l23);
