@@ -95,6 +95,29 @@ def test_forward_all_equal_rows_and_zero_codebook():
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,D,K", [(64, 64, 256), (640, 32, 256), (20000, 32, 256), (5000, 64, 256), (300, 32, 1024)])
+def test_forward_zero_and_vanishing_rows(mode, B, D, K):
+    """Rows that are exactly zero (a dead encoder output; they stay on the filtered scan: their scores are the exact -|c|^2/2),
+    rows of denormal / vanishing magnitude (exact scan), signed zeros, and codebooks with equal norms (zero rows then tie:
+    first index) -- every output bit for bit against the oracle, plain and margin variants."""
+    rng = np.random.default_rng(B + D + K + mode)
+    x = (rng.standard_normal((B, D)) * 0.5).astype(np.float32)
+    kind = rng.integers(0, 6, B)
+    x[kind == 0] = 0.0
+    x[kind == 1] = -0.0
+    x[kind == 2] *= np.float32(1e-30)                     # squares underflow to 0, features are not zero
+    x[kind == 3] = np.float32(1e-42) * np.sign(x[kind == 3])   # denormal features
+    cbs = (rng.standard_normal((3, K, D)) * np.array([0.4, 0.2, 0.1])[:, None, None]).astype(np.float32)
+    cbs[1, 7] = cbs[1, 3]                                 # duplicate codes: first index wins
+    cbs[0, 5] = -cbs[0, 2]                                # equal norms, different codes: a zero row ties between them
+    cbs[0, 2] *= 0.01
+    cbs[0, 5] *= 0.01                                     # ... and they are the smallest norms of level 0
+    _check_forward(x, cbs, mode)
+    # a whole batch of zeros (what a collapsed encoder produces)
+    _check_forward(np.zeros((min(B, 700), D), np.float32), cbs, mode)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_forward_rows_not_16_byte_aligned(mode):
     """The full-width kernels move rows as float4s; a contiguous view that starts 4 bytes into its storage must
     take the element-wise path and give the same bits."""
