@@ -592,8 +592,10 @@ def main():
                           "tokenize_items_per_s": round(Bm / tok_ms * 1e3, 1), "tokenize_ms": round(tok_ms, 4),
                           "note": "per GPU; S-rq = HIP quantisation stack fwd+bwd on 32-d latents, tokenize = "
                                   "get_semantic_ids (encoder GEMMs + HIP RQ, eval)"},
-            "mlp_gemms": (f"--mlp {args.mlp} (see `arithmetic`); layers narrower than 256 columns: PyTorch-ROCm fp32 GEMMs (matmul "
-                          "precision highest), TunableOp selections " + ("loaded" if tuned else "off")),
+            "mlp_gemms": (f"--mlp {args.mlp} (see `arithmetic`); layers of 128 (mod 128) output columns on the split kernels"
+                          + (" (128 (mod 256) on the library: --no-narrow)" if args.no_narrow else "")
+                          + "; the 32-wide layers: PyTorch-ROCm fp32 GEMMs (matmul precision highest), TunableOp selections "
+                          + ("loaded" if tuned else "off")),
             "final_loss": round(final_loss, 6), "p_unique_ids": round(p_unique, 6),
             "librqhip_sha256": lib_sha,
         }
