@@ -267,6 +267,12 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
     const int slabs = pl.nslab_n * pl.nslab_k;
     long long ms = cu_count() / slabs;      // one workgroup per CU (the LDS stage is 40-128 KiB)
     if (ms < 1) ms = 1;
+    // A multiple of 8 row ranges whenever there are that many: the kernels then put the slabs of one row range on ONE XCD
+    // (`(msplit & 7) == 0` branch), where they share the range's rows in that L2.  With 6 slabs on 256 CUs (dW [512, 768]) the
+    // count was 42: the slabs of a range ran on six different XCDs and every one fetched its operand strips from beyond the L2 --
+    // PMC 2 * FETCH_SIZE + WRITE_SIZE = 1 266 MB per launch against 512 MB algorithmic (2.5 x), 5.1 TB/s: the kernel was running
+    // at the fabric's limit on re-reads (profiles/r04_pmc_traffic_c2.json).  40 ranges leave 16 of 256 CUs idle and win.
+    if (ms >= 8) ms &= ~7LL;
     if (ms > chunks) ms = chunks > 0 ? chunks : 1;
     pl.msplit = (int)ms;
     pl.pow2 = 1;
