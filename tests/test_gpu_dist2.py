@@ -20,7 +20,7 @@ import torch
 
 from conftest import PKG, ROOT
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]   # (spawned ranks import torch again: slow on a cold box)
 
 ROWS, WARM = 2048, 2048
 

@@ -7,7 +7,7 @@ import torch
 
 from conftest import PKG
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]   # (whole training loops)
 
 
 def _run(cfg_name, tmp_path, monkeypatch, **overrides):
