@@ -36,9 +36,18 @@ def sampler():
 
 x = torch.randn(100_000, 768, device="cuda")
 w = torch.randn(512, 768, device="cuda") / 768 ** 0.5
-p = ops.weight_planes(w)
+ARITH = ops.BF16X3 if os.environ.get("RQ_POWER_ARITH") == "bf16x3" else ops.F16X2     # (round 4: the product arithmetic by default)
+p = ops.weight_planes(w, arith=ARITH)
+_rm = ops.maxima(x, cols=False)[0] if ARITH == ops.F16X2 else None
+_c = torch.empty((100_000, 512), device="cuda")
+
+
+def _gemm():
+    ops.gemm_split_ex(x, p, 512, arith=ARITH, epilogue=_lib.EPI_RELU, a_row_max=_rm)
+
+
 for _ in range(5):
-    ops.gemm_split(x, p, 512, relu=True)
+    _gemm()
 torch.cuda.synchronize()
 hdr = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True).stdout.strip().splitlines()
 print("header:", hdr[0] if hdr else "?")
@@ -51,7 +60,7 @@ n = 0
 a.record()
 while time.time() - t0 < secs:
     for _ in range(50):
-        ops.gemm_split(x, p, 512, relu=True)
+        _gemm()
     n += 50
     torch.cuda.synchronize()
 b.record()
