@@ -83,6 +83,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="rows per rank per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip secondary.small_batch (a subprocess: batch 640 / batch 64 steps, eager and hipGraph)")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
     ap.add_argument("--mlp", choices=("split", "split6", "library"), default="split",
@@ -174,6 +175,27 @@ def cpu_baseline(batch_rows, levels, codes, budget_s=24.0):
             "note": "the reference's own modules on the 8-vCPU build container, and this port beside them on that host: "
                     "BASELINE.md section 2, profiles/r04_reference_vs_port_cpu.json (tools/time_reference_cpu.py); "
                     "cgroup_cpu_quota_cores / affinity_cpus: what the box lets this process use of its hardware threads"}
+
+
+def small_batch_secondary(cpu):
+    """The batch sizes the reference's gin files ship (amazon: 640, D = 32, STE; ml32m: 64, D = 64, rotation trick), eager and
+    replayed from a hipGraph: tools/bench_small_batch.py --json in a SUBPROCESS with a time limit."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_small_batch.py"), "--json"]
+    try:
+        pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+        out = json.loads(pr.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    c640 = (cpu or {}).get("batch640_items_per_s")
+    if c640:
+        a = out.get("batch640_amazon", {})
+        out["batch640_vs_cpu_port"] = {"cpu_port_items_per_s": c640,
+                                       "eager_ratio": round(a.get("eager_items_per_s", 0.0) / c640, 2),
+                                       "graph_ratio": round(a.get("graph_items_per_s", 0.0) / c640, 2) if "graph_items_per_s" in a else None}
+    out["note"] = ("one fwd+bwd+AdamW step at the reference's shipped batch sizes; `graph` = the same step captured once and replayed "
+                   "(train_rqvae.py does this by default for full batches below 4096 rows); cpu port at batch 640: cpu_baseline.batch640_items_per_s")
+    return out
 
 
 def parity_gate(device, tag):
@@ -335,8 +357,9 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    ops.profile_enable(steps * n_micro + 8)
-    ops.profile_select("rq_forward")      # the timed region records the scan kernel only (one event pair per micro-batch)
+    n_fam = steps * n_micro * 26 + 64
+    ops.profile_enable(n_fam)
+    ops.profile_select("gemm_split", "wgrad")   # the timed region records the kernels that ARE the step: the MLP GEMM / weight-gradient family
     rqdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -345,7 +368,7 @@ def main():
     torch.cuda.synchronize()
     rqdist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ops.profile_read(steps * n_micro + 8)
+    fam_records = ops.profile_read_tagged(n_fam)
     ops.profile_enable(0)
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -385,6 +408,7 @@ def main():
     torch.cuda.synchronize()
     prof_records = ops.profile_read_tagged(n_prof * n_micro * 48 + 64)
     ops.profile_enable(0)
+    kernel_ms = [ms for kind, ms, _fl, _by in prof_records if kind == "rq_forward"]   # the scan kernel (`roofline_rq`)
 
     def timed(fn):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -397,6 +421,28 @@ def main():
     def reps(fn, n=10):
         fn()
         return timed(lambda: [fn() for _ in range(n)])[1] / n
+
+    # the strict-fp32 arm of the same step (`--mlp library`: library fp32 GEMMs + oracle-ordered fp32-MFMA weight gradients),
+    # same process, same model: what the step costs without the f16x2 emulation
+    strict = None
+    if args.mlp == "split" and world == 1:
+        prev_arith = _lin.use_arith("fp32")
+        n_strict = max(50, min(steps, 100))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n_strict):
+            step()
+        torch.cuda.synchronize()
+        e_strict = time.perf_counter() - ts
+        _lin.use_arith(prev_arith)
+        step()
+        torch.cuda.synchronize()
+        strict = {"arith": "fp32: library fp32 GEMMs (PyTorch-ROCm, matmul precision highest, TunableOp selections) + fp32-MFMA "
+                           "weight gradients in the oracle's order (bench.py --mlp library)",
+                  "steps": n_strict, "ms_per_step": round(e_strict / n_strict * 1e3, 4),
+                  "items_per_s": round(B * n_strict / e_strict, 1)}
 
     Xm = batches[0].x
     Bm = Xm.shape[0]
@@ -462,7 +508,9 @@ def main():
         traffic, traffic_src = None, None
         from rqhip import _lib as _rqlib
         lib_sha = _sha256_file(os.path.abspath(args.lib) if args.lib else _rqlib.SO_PATH)
-        pmc = args.pmc_file or os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{args.config}.json")
+        pmc = args.pmc_file or next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_{args.config}.json") for r in ("r05", "r04"))
+                                     if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{args.config}.json"))
+        pmc_json = None
         if not os.path.exists(pmc):
             traffic_src = f"null: no PMC file {os.path.relpath(pmc, ROOT)}"
         elif B != cfg["rows"]:
@@ -474,6 +522,7 @@ def main():
                 traffic_src = (f"null: {os.path.relpath(pmc, ROOT)} was collected on librqhip.so "
                                f"{str(pj.get('librqhip_sha256'))[:16]}, this run loaded {lib_sha[:16]}")
             else:
+                pmc_json = pj
                 traffic = pj["rq_forward_kernel"]["hbm_bytes_per_launch_corrected"]
                 traffic_src = (os.path.relpath(pmc, ROOT) + " (2*FETCH_SIZE+WRITE_SIZE, bytes/launch; same librqhip.so "
                                f"sha256 {lib_sha[:16]} as this run)")
@@ -524,6 +573,49 @@ def main():
                                "frac_of_issued_dtype_peak": round(gemm_issued / issued_peak, 4)},
             "kernels": rk[:12],
         }
+        # ---- `roofline`: the dominant kernel FAMILY, from the HIP-event records of the TIMED region ----
+        fam = {}
+        for kind, ms, fl, by in fam_records:
+            if fl >= 2.0 * 4096 * 128 * 256:                  # the matrix kernels proper (the 32-wide layers' fp32 kernels are not)
+                fam.setdefault((kind, fl, by), []).append(ms)
+        fam_ms = sum(sum(v) for v in fam.values())
+        fam_fl = sum(k[1] * len(v) for k, v in fam.items())
+        fam_launches = sum(len(v) for v in fam.values())
+        fam_alg = fam_fl / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else float("nan")
+        dom_key = max(fam, key=lambda k: sum(fam[k])) if fam else None
+        dom = None
+        if dom_key is not None:
+            dk, dfl, dby = dom_key
+            dmean = float(np.mean(fam[dom_key]))
+            dom = {"kernel": {"gemm_split": "gemm_f16_kernel", "wgrad": "wgrad_split_kernel"}.get(dk, dk),
+                   "launches_per_step": round(len(fam[dom_key]) / steps, 2), "launch_ms_mean": round(dmean, 5),
+                   "algorithmic_gflop_per_launch": round(dfl / 1e9, 3), "algorithmic_mb_per_launch": round(dby / 1e6, 2),
+                   "issued_tflops": round(issued_mult * dfl / (dmean * 1e-3) / 1e12, 1),
+                   "frac": round(issued_mult * dfl / (dmean * 1e-3) / 1e12 / issued_peak, 4), "traffic": None, "traffic_ratio": None}
+            if pmc_json is not None:     # HBM bytes of that launch by the PMC counters (2 FETCH_SIZE + WRITE_SIZE, largest launch)
+                cand = [(2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024.0 for n, v in pmc_json.get("kernels", {}).items()
+                        if ("wgrad" in n if dk == "wgrad" else "gemm" in n) and "FETCH_SIZE_KB_max" in v and "WRITE_SIZE_KB_max" in v]
+                if cand:
+                    dom["traffic"] = max(cand)
+                    dom["traffic_ratio"] = round(max(cand) / dby, 3) if dby else None
+        roofline_family = {
+            "kernel": ("MLP matrix-kernel family: gemm_f16_kernel / gemm_split_kernel (activation GEMMs with ReLU / mask / reconstruction-"
+                       "loss epilogues) + wgrad_split_kernel (weight gradients), " f"{round(fam_launches / max(steps, 1), 1)} launches per step"
+                       if args.mlp != "library" else "library fp32 GEMMs are not recorded; fp32-MFMA weight gradients only"),
+            "bound": "mfma",
+            "achieved": round(issued_mult * fam_alg, 2), "peak": issued_peak, "unit": "TFLOP/s",
+            "frac": round(issued_mult * fam_alg / issued_peak, 4),
+            "frac_kind": f"ISSUED matrix-instruction FLOPs ({issued_mult:g} fp16 piece products per fp32 product) / time of the family's launches "
+                         "in the timed region (HIP events on the launch stream) / dense fp16 MFMA peak",
+            "algorithmic_tflops": round(fam_alg, 2), "algorithmic_frac_of_issued_peak": round(fam_alg / issued_peak, 4),
+            "algorithmic_frac_of_fp32_peak": round(fam_alg / PEAK_FP32_MFMA_TFLOPS, 4),
+            "family_ms_per_step": round(fam_ms / max(steps, 1), 4), "share_of_step": round(fam_ms / max(steps, 1) / ms_per_step, 3),
+            "launches": fam_launches,
+            "traffic": dom["traffic"] if dom else None,
+            "traffic_source": (traffic_src if (dom and dom["traffic"]) else "null: no PMC passes for this build (tools/profile_bench.sh)")
+                              + "; of the dominant member's largest launch",
+            "dominant_member": dom,
+        }
         workload = {
             "c2": "C2: synthetic 100000x768 unit-norm items per GPU -> RQ-VAE 768-[512,256,128]-32, 3x256 codebooks, "
                   "STE (Gumbel off), one fwd+bwd+allreduce+AdamW step per HBM-resident batch",
@@ -539,7 +631,9 @@ def main():
             "config": {"workload": workload, "name": args.config, "rows_per_gpu_per_step": B, "micro_batch_rows": micro,
                        "levels": LEVELS, "codebook_size": CODES, "embed_dim": EMBED,
                        "parallelism": f"row-shard x{world}, 1 flat grad all-reduce per step (RCCL)"},
-            "roofline": {"kernel": f"rq_forward_kernel<16,STE,filtered> ({LEVELS}x{CODES}, {Bm} rows/launch)", "bound": "mfma",
+            "roofline": roofline_family,
+            "roofline_rq": {"kernel": f"rq_forward_kernel<16,STE,filtered> ({LEVELS}x{CODES}, {Bm} rows/launch)", "bound": "mfma",
+                         "measured": f"HIP events over {n_prof} steps run after the timed region (the timed region's records are the GEMM family's)",
                          "binding_resource": "valu-epilogue: the (best, runner-up, index) tournament on the 16 scores a lane "
                                              "receives per 32 codes -- neither matrix pipe nor HBM limits the kernel; "
                                              "`bound` names the FLOP roofline the fraction is priced on (the contract's "
@@ -588,7 +682,8 @@ def main():
                              "first_forward_with_kmeans_init_s": round(kmeans_s, 3),
                              "kmeans_init_s": round(kmeans_only_s, 4)},
             "rccl_ranks": world,
-            "secondary": {"s_rq_items_per_s": round(Bm / srq_ms * 1e3, 1), "s_rq_ms_fwd_bwd": round(srq_ms, 4),
+            "secondary": {"strict_fp32": strict,
+                          "s_rq_items_per_s": round(Bm / srq_ms * 1e3, 1), "s_rq_ms_fwd_bwd": round(srq_ms, 4),
                           "tokenize_items_per_s": round(Bm / tok_ms * 1e3, 1), "tokenize_ms": round(tok_ms, 4),
                           "note": "per GPU; S-rq = HIP quantisation stack fwd+bwd on 32-d latents, tokenize = "
                                   "get_semantic_ids (encoder GEMMs + HIP RQ, eval)"},
@@ -605,8 +700,24 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_parity:
             line["parity"] = parity_gate(device, args.config)
+            if args.config != "c4":     # the C4-shaped fixture (4 x 1024 codebooks, 300 000 rows end to end) beside it
+                try:
+                    p4 = parity_gate(device, "c4")
+                    line["parity"]["c4"] = {
+                        "rows_total": p4["end_to_end"]["eval"]["rows_total"], "mismatches_eval": p4["end_to_end"]["eval"]["mismatches"],
+                        "mismatches_train": p4["end_to_end"]["train"]["mismatches"], "ids_exact_rate": p4["ids_exact_rate"],
+                        "mismatch_margins_eval": p4["end_to_end"]["eval"]["mismatch_margins"],
+                        "hard_rows_mismatches": p4["kernel_level_hard_rows"]["mismatches"],
+                        "kernel_level_mismatches": p4["kernel_level"]["mismatches"],
+                        "all_mismatches_flagged": p4["all_mismatches_flagged"], "loss_max_abs_err": p4["loss_max_abs_err"],
+                        "pass": p4["pass"]}
+                    line["parity"]["c4_mismatches"] = p4["mismatches"]
+                except Exception as e:  # noqa: BLE001  (a missing fixture must not cost the line)
+                    line["parity"]["c4"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_rows, LEVELS, CODES)
+        if world == 1 and not args.no_small_batch:
+            line["secondary"]["small_batch"] = small_batch_secondary(line.get("cpu_baseline"))
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     rqdist.barrier()

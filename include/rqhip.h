@@ -339,7 +339,7 @@ int rqhip_linear_wgrad_f16(const float *g, const float *y, const float *x, int64
  *       rqhip_weight_image_bytes(Nc, R, arith) bytes, caller-owned, 16-byte aligned.  `jobs` is a HOST array.
  *   rqhip_maxima        : row_max [M] and / or col_max [R] (bit patterns of the largest |value|; col_max is maxed into
  *       atomically: zero it first) of A [M, R] in one pass; with Y given, of A masked by Y > 0 (the ReLU backward), which is
- *       also written to masked_out when that is not NULL.  R % 4 == 0, R <= 1024.
+ *       also written to masked_out when that is not NULL.  R % 4 == 0, R <= 16384 (columns are taken in chunks of 1024).
  *   rqhip_gemm_split_ex : C [M, Nc] = epilogue(A [M, R] . image^T).  Needs Nc % 128 == 0 (256-column tiles when
  *       Nc % 256 == 0, else 128), R % 16 == 0 (rqhip_gemm_split_supported), 16-byte aligned pointers; one launch at a time
  *       per image (it holds the kernel's tile dispenser).

@@ -55,7 +55,8 @@ typedef int gs_i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGsUB = 2;                    // a wave's tile is (32 TA) x (32 UB)
 constexpr int kGsK = 16;                    // reduction depth of a stage = one K step of the matrix instruction
-constexpr int kGsColmaxLds = 1024;          // column maxima are pre-reduced in LDS for Nc up to this (else straight to memory)
+constexpr int kGsColmaxLds = 1024;
+constexpr int kGsTailWords = 32;             // words behind a weight image that hold the tile dispensers (zero between launches)          // column maxima are pre-reduced in LDS for Nc up to this (else straight to memory)
 
 // (a, b) -> packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
@@ -105,7 +106,7 @@ __device__ __forceinline__ unsigned gs_half_wave_umax(unsigned v) {
 // ---- weight images: every layer of an MLP in one launch -----------------------------------------------------------------------
 // image[s][piece][half][n] (16 bytes: r = 16 s + 8 half + j, j < 8) of src[n][r] (transpose == 0, src is [Nc, R]) or of
 // src[r][n] (transpose == 1, src is [R, Nc]: the data gradient multiplies by W, i.e. B = W^T).  Behind the image: the tile
-// dispenser (16 words), and for NP = 2 the exponents of the Nc rows of B.
+// dispensers (kGsTailWords words), and for NP = 2 the exponents of the Nc rows of B.
 constexpr int kImgCols = 4;         // rows of B per block (one per wave)
 constexpr int kImgMaxJobs = 16;
 struct ImageJob {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const ImageJobs jobs
     const int blk = (int)blockIdx.x - job.block0;
     const int Nc = job.Nc, R = job.R, np = job.np, n0 = blk * kImgCols;
     unsigned *tail = job.image + (size_t)(R / kGsK) * 2 * np * Nc * 4;
-    if (blk == 0 && threadIdx.x < 16) tail[threadIdx.x] = 0u;        // the tile dispenser
+    if (blk == 0 && threadIdx.x < kGsTailWords) tail[threadIdx.x] = 0u;   // the tile dispensers
     __shared__ unsigned s_max[kImgCols];
     if (threadIdx.x < kImgCols) s_max[threadIdx.x] = 0u;
     __syncthreads();
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const ImageJobs jobs
             if (lane == 0) s_max[nl] = m;
         }
         __syncthreads();
-        if (threadIdx.x < kImgCols) reinterpret_cast<int *>(tail + 16)[n0 + threadIdx.x] = gs_exp_of_bits(s_max[threadIdx.x]);
+        if (threadIdx.x < kImgCols) reinterpret_cast<int *>(tail + kGsTailWords)[n0 + threadIdx.x] = gs_exp_of_bits(s_max[threadIdx.x]);
     }
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         int nl, rp;
@@ -202,17 +203,20 @@ __global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ A
         for (int c = threadIdx.x; c < R; c += 256) mx_smem[c] = 0u;
         __syncthreads();
     }
-    const int R4 = R / 4;
-    constexpr int kQ = 4;                             // float4s per lane held for the column maxima (R <= 1024)
+    constexpr int kQ = 4;                             // float4s per lane held for the column maxima of one 1024-column chunk
+    // columns in chunks of 1024 (any R): the same wave takes the same rows in every chunk, so a row's maximum is carried from
+    // chunk to chunk through row_max itself (written by lane 0, read back by lane 0)
+    for (int c0 = 0; c0 < R; c0 += 256 * kQ) {
+    const int R4 = (R - c0 < 256 * kQ ? R - c0 : 256 * kQ) / 4;
     unsigned cm[kQ][4];
 #pragma unroll
     for (int q = 0; q < kQ; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) cm[q][j] = 0u;
     for (long long row = (long long)blockIdx.x * 4 + wave; row < M; row += (long long)gridDim.x * 4) {
-        const gs_f32x4 *src = reinterpret_cast<const gs_f32x4 *>(A + (size_t)row * R);
-        const gs_f32x4 *ys = Y ? reinterpret_cast<const gs_f32x4 *>(Y + (size_t)row * R) : nullptr;
-        gs_f32x4 *dst = out ? reinterpret_cast<gs_f32x4 *>(out + (size_t)row * R) : nullptr;
+        const gs_f32x4 *src = reinterpret_cast<const gs_f32x4 *>(A + (size_t)row * R + c0);
+        const gs_f32x4 *ys = Y ? reinterpret_cast<const gs_f32x4 *>(Y + (size_t)row * R + c0) : nullptr;
+        gs_f32x4 *dst = out ? reinterpret_cast<gs_f32x4 *>(out + (size_t)row * R + c0) : nullptr;
         unsigned rm = 0u;
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ A
         if (row_max) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) rm = gs_umax(rm, (unsigned)__shfl_xor((int)rm, o, 64));
-            if (lane == 0) row_max[row] = rm;
+            if (lane == 0) row_max[row] = c0 == 0 ? rm : gs_umax(rm, row_max[row]);
         }
     }
     if (col_max) {
@@ -244,8 +248,11 @@ __global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ A
             const int i = lane + 64 * q;
             if (i >= R4) break;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) atomicMax(&mx_smem[4 * i + j], cm[q][j]);
+            for (int j = 0; j < 4; ++j) atomicMax(&mx_smem[c0 + 4 * i + j], cm[q][j]);
         }
+    }
+    }   // column chunks
+    if (col_max) {
         __syncthreads();
         for (int c = threadIdx.x; c < R; c += 256)
             if (mx_smem[c]) atomicMax(col_max + c, mx_smem[c]);
@@ -849,10 +856,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSpl
 
 // The product kernel: gs_tile2 tiles of 128 rows (64-row tiles for what is left over after the whole rounds), 4 waves, TWO
 // persistent workgroups per CU: one's tile prologue, barriers and epilogue fall into the other's matrix instructions.
-// Two dispensers: counter[0] big tiles, counter[2] small tiles (taken when the big ones are gone); counter[1] counts the
-// workgroups that have left (the last one re-arms all three).  (Round 4 also tried starting the second workgroup of every CU
-// half a tile late so that epilogues and main loops of a CU interleave by construction: neutral to -7 %,
-// tools/experiments/gemm_split_r04_variants.hip.)
+// Tile dispensers, ONE PER XCD (round 5): workgroup b runs on XCD b % 8 (workgroups are dealt to the XCDs round robin), queue q
+// holds the row tiles rt = q (mod 8) with their column tiles back to back, so the column tiles of one row tile -- which read the
+// same strip of A -- run on ONE XCD and share it in that XCD's L2 (with a single dispenser they went to different XCDs and the
+// strip was fetched from HBM once per column tile: 1.40-1.55 x the algorithmic bytes by the PMC counters, profiles/r04_pmc_*).
+// A workgroup whose own queue is empty takes from the next XCD's.  counter[0..7] big-tile queues, [8..15] small-tile queues,
+// [16] workgroups that have left (the last one re-arms all of them).  (Round 4 also tried starting the second workgroup of
+// every CU half a tile late: neutral to -7 %, tools/experiments/gemm_split_r04_variants.hip.)
+constexpr int kGsQueues = 8;
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams p) {
     constexpr int kThreads = 256, kBigRows = 128, kSmallRows = 64, COLS = 256;
@@ -866,36 +877,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams 
     const bool lds_colmax = p.c_colmax != nullptr && p.Nc <= kGsColmaxLds;
     if (lds_colmax)
         for (int c = tid; c < p.Nc; c += kThreads) s_colmax[c] = 0u;
-    const unsigned n_small = p.n_tiles - p.n_big;
+    const unsigned nct = (unsigned)p.n_col_tiles;
+    const unsigned rt_big = p.n_big / nct, rt_small = (p.n_tiles - p.n_big) / nct;
+    const int xcd = (int)(blockIdx.x & (kGsQueues - 1));
+    int big_skip = 0, small_skip = 0;          // (thread 0) queues found empty so far, in this workgroup's visiting order
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
         if (tid == 0) {
             unsigned t = kNone;
-            const unsigned i = atomicAdd(p.counter, 1u);
-            if (i < p.n_big) t = i;
+            for (; big_skip < kGsQueues; ++big_skip) {
+                const unsigned q = (unsigned)((xcd + big_skip) & (kGsQueues - 1));
+                const unsigned j = atomicAdd(p.counter + q, 1u);
+                const unsigned rt = (j / nct) * kGsQueues + q;
+                if (rt < rt_big) { t = rt * nct + j % nct; break; }
+            }
             if (t == kNone) {
-                const unsigned j = atomicAdd(p.counter + 2, 1u);
-                if (j < n_small) t = j | kSmallBit;
+                for (; small_skip < kGsQueues; ++small_skip) {
+                    const unsigned q = (unsigned)((xcd + small_skip) & (kGsQueues - 1));
+                    const unsigned j = atomicAdd(p.counter + kGsQueues + q, 1u);
+                    const unsigned rt = (j / nct) * kGsQueues + q;
+                    if (rt < rt_small) { t = (rt * nct + j % nct) | kSmallBit; break; }
+                }
             }
             s_tile = t;
         }
         __syncthreads();
         const unsigned tile = s_tile;
         if (tile == kNone) {
-            if (tid == 0 && atomicAdd(p.counter + 1, 1u) == gridDim.x - 1) {
-                p.counter[0] = 0u;
-                p.counter[1] = 0u;
-                p.counter[2] = 0u;
+            if (tid == 0 && atomicAdd(p.counter + 2 * kGsQueues, 1u) == gridDim.x - 1) {
+                for (int i = 0; i <= 2 * kGsQueues; ++i) p.counter[i] = 0u;
             }
             break;
         }
-        // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2)
         if (!(tile & kSmallBit)) {
-            const int ct = (int)(tile % (unsigned)p.n_col_tiles), rt = (int)(tile / (unsigned)p.n_col_tiles);
+            const int ct = (int)(tile % nct), rt = (int)(tile / nct);
             gs_tile2<EPI, kBigRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
         } else {
             const unsigned st = tile & ~kSmallBit;
-            const int ct = (int)(st % (unsigned)p.n_col_tiles), rt = (int)(st / (unsigned)p.n_col_tiles);
+            const int ct = (int)(st % nct), rt = (int)(st / nct);
             gs_tile2<EPI, kSmallRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
         }
     }
@@ -926,7 +945,7 @@ extern "C" int rqhip_gemm_split_supported(int Nc, int R) { return (Nc > 0 && R >
 extern "C" size_t rqhip_weight_image_bytes(int Nc, int R, int arith) {
     const int np = gs_np(arith);
     if (!np || !rqhip_gemm_split_supported(Nc, R)) return 0;
-    return (size_t)(R / kGsK) * 2 * np * Nc * 16 + 64 + (np == 2 ? (size_t)Nc * sizeof(int) : 0);   // + the tile counter (+ exponents)
+    return (size_t)(R / kGsK) * 2 * np * Nc * 16 + kGsTailWords * 4 + (np == 2 ? (size_t)Nc * sizeof(int) : 0);   // + the tile counter (+ exponents)
 }
 extern "C" size_t rqhip_weight_planes_bytes(int Nc, int R) { return rqhip_weight_image_bytes(Nc, R, RQHIP_SPLIT_BF16X3); }
 
@@ -971,8 +990,8 @@ extern "C" int rqhip_weight_planes(const float *w, int rows, int cols, int trans
 extern "C" int rqhip_maxima(const float *A, const float *Y, float *masked_out, int64_t M, int R, unsigned *row_max, unsigned *col_max,
                             rqhip_stream_t stream) {
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (M < 0 || R <= 0 || (R % 4) != 0 || R > 1024 || (M > 0 && !A) || (masked_out && !Y) || !al16(A) || !al16(Y) || !al16(masked_out)) {
-        set_error("maxima: bad arguments (R = %d must be a multiple of 4, at most 1024; 16-byte aligned rows; masked_out needs Y)", R);
+    if (M < 0 || R <= 0 || (R % 4) != 0 || R > 16384 || (M > 0 && !A) || (masked_out && !Y) || !al16(A) || !al16(Y) || !al16(masked_out)) {
+        set_error("maxima: bad arguments (R = %d must be a multiple of 4, at most 16384; 16-byte aligned rows; masked_out needs Y)", R);
         return RQHIP_EARG;
     }
     if (M == 0 || (!row_max && !col_max && !masked_out)) return RQHIP_OK;
@@ -1034,7 +1053,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
-    p.b_exp = reinterpret_cast<const int *>(p.counter + 16);
+    p.b_exp = reinterpret_cast<const int *>(p.counter + kGsTailWords);
     const int cus = cu_count();
     // the product kernel (gemm_f16_kernel: 4 waves, two workgroups per CU, B operands straight from the image) takes the f16x2
     // arithmetic at 256-column tiles; the staged loop the rest: bf16x3 with 8 waves / one workgroup per CU, f16x2 at 128-column

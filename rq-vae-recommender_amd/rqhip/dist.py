@@ -194,6 +194,12 @@ class FlatGradReducer:
         slice taken and returns an ordinary tensor, which autograd accumulates."""
         self.epoch += 1
         self._armed = False
+        # early all-reduces of a step that never reached allreduce_mean() (its backward or the caller raised after the hook
+        # fired): every rank issued them, so they complete; wait and drop them -- left in place, the NEXT allreduce_mean()
+        # would take them for this step's and skip the early part of the buffer (ADVICE r4)
+        for work in self._pending:
+            work.wait()
+        self._pending = []
         for p in self.params:
             p.grad = None
 

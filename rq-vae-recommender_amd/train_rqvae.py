@@ -17,10 +17,11 @@ What is MI355X-native about it:
   * the progress-bar losses are read back every `log_every` steps instead of three `.cpu().item()` syncs
     per step (train_rqvae.py:197-199);
   * at the reference's batch sizes (640 / 64 rows) a step is ~45 kernel launches of a few microseconds each, i.e.
-    launch-bound: with `use_hip_graph=True` (off in the signature and in the reference-equivalent gin configs, on in
-    configs/*_graph.gin; single GPU) the whole step (forward, HIP quantisation kernels, backward, fused AdamW) is
-    captured into a hipGraph and replayed on full-size batches (0.99 -> 0.38 ms per step at batch 640 on MI355X in
-    tools/bench_small_batch.py).  The training schedule is the reference's either way: the short batch that ends an
+    launch-bound.  So, like the reference -- whose forward is graph-captured by default (`torch.compile(mode="reduce-overhead")`,
+    modules/rqvae.py:141) -- the whole step (forward, HIP quantisation kernels, backward, all-reduce, fused AdamW) is captured into a
+    hipGraph and replayed on full-size batches BY DEFAULT when the batch is below 4096 rows and there is no gradient accumulation
+    (`use_hip_graph=None`, the signature's default: auto; `True` / `False` force it; configs/*_graph.gin bind True explicitly):
+    1.24 -> 0.35 ms per step at batch 640 on MI355X (tools/bench_small_batch.py, `secondary.small_batch` of the bench line).  The training schedule is the reference's either way: the short batch that ends an
     epoch (drop_last=False, train_rqvae.py:82-88) is trained on eagerly, and the graph is re-captured after every eager
     excursion (epoch tail, eval, tokenisation, checkpoint).
 wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
@@ -205,7 +206,7 @@ def train(
     vae_n_layers=3,
     dataset_split="beauty",
     log_every=100,
-    use_hip_graph=False,
+    use_hip_graph=None,
 ):
     params = dict(locals())
     del split_batches  # every rank always draws its own full batch (reference behaviour with a bare dataloader)
@@ -238,7 +239,11 @@ def train(
         codebook_normalize=vae_codebook_normalize, codebook_sim_vq=vae_sim_vq, codebook_mode=vae_codebook_mode,
         n_layers=vae_n_layers, n_cat_features=vae_n_cat_feats, commitment_weight=commitment_weight,
     ).to(device)
-    graphable = bool(use_hip_graph) and gradient_accumulate_every == 1
+    # None = auto: launch-bound batches replay the step from a hipGraph (the reference's forward is graph-captured by default too)
+    # (auto only where the step's collectives can be captured: one rank, or RCCL -- a gloo group cannot be)
+    import torch.distributed as _dist
+    capturable_comm = world == 1 or (_dist.is_initialized() and _dist.get_backend() == "nccl")
+    graphable = ((batch_size < 4096 and capturable_comm) if use_hip_graph is None else bool(use_hip_graph)) and gradient_accumulate_every == 1
     optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay, fused=True,
                       capturable=graphable)  # same update as the reference's AdamW, one multi-tensor kernel
 

@@ -121,6 +121,17 @@ def _worker(rank, world, port, out):
     got = red.allreduce_mean()
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
 
+    # an aborted step (the hook fired, allreduce_mean() never ran) must not leak its early all-reduces into the next one
+    red.zero_()
+    red.arm()
+    toy(X[lo:hi]).pow(2).sum(dim=1).mean().backward()
+    assert red._pending
+    red.zero_()                                   # the step is abandoned here
+    assert not red._pending
+    toy(X[lo:hi]).pow(2).sum(dim=1).mean().backward()    # unarmed: one whole-buffer all-reduce
+    got = red.allreduce_mean()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (got - want).abs().max()
+
     # ragged all-gather of id rows
     local = torch.arange(3 + rank).unsqueeze(1).repeat(1, 2) + 100 * rank
     full = rqdist.allgather_rows(local)

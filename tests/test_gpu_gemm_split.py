@@ -191,6 +191,40 @@ def test_maxima_and_epilogue_emitted_scales():
         ops.gemm_split_ex(a, i1, 768)                                  # the fp16 arithmetic needs the row maxima of A
 
 
+@pytest.mark.parametrize("R", [1536, 2048, 1028])
+def test_maxima_wide_rows_and_wide_mlp_layer(R):
+    """rqhip_maxima took at most 1024 columns while the f16x2 layer selection has no width limit -- an MLP
+    with a 1536-wide input (text embeddings) raised at batch >= 4096.  The kernel takes the columns in chunks of 1024 now."""
+    from rqhip import linear as lin
+    from rqhip import ops
+    g = torch.Generator().manual_seed(R)
+    M = 4099
+    a = torch.randn(M, R, generator=g).cuda() * torch.pow(10.0, torch.randint(-3, 4, (M, 1), generator=g).float()).cuda()
+    y = torch.randn(M, R, generator=g).cuda()
+    r, c, _ = ops.maxima(a)
+    assert torch.equal(r[0].view(torch.float32), a.abs().amax(dim=1)) and torch.equal(c.view(torch.float32), a.abs().amax(dim=0))
+    r, c, am = ops.maxima(a, y, write_masked=True)
+    want = torch.where(y > 0, a, torch.zeros_like(a))
+    assert torch.equal(am, want) and torch.equal(r[0].view(torch.float32), want.abs().amax(dim=1))
+    assert torch.equal(c.view(torch.float32), want.abs().amax(dim=0))
+    if R % 16:
+        return
+    # a whole layer at that width through the product path (forward, data gradient, weight gradient)
+    x = torch.randn(M, R, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(256, R, generator=g) / R ** 0.5).cuda().requires_grad_(True)
+    from modules.encoder import _LinearReLU
+    assert lin.split_ok(x.detach(), 256, R)
+    out = _LinearReLU.apply(x, w, torch.zeros(256, device="cuda"))
+    gy = torch.randn(M, 256, generator=g).cuda()
+    out.backward(gy)
+    ref = torch.relu(x.detach().double() @ w.detach().double().t())
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    gm = torch.where(ref > 0, gy.double(), torch.zeros_like(ref))
+    gw, gx = gm.t() @ x.detach().double(), gm @ w.detach().double()
+    assert (w.grad.double() - gw).abs().max().item() <= 2e-6 * gw.abs().max().item()
+    assert (x.grad.double() - gx).abs().max().item() <= 2e-6 * gx.abs().max().item()
+
+
 @pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("M", [100_000, 5003, 77])
 def test_gemm_split_recon_equals_gemm_then_loss(M, arith):

@@ -60,7 +60,7 @@ def test_train_ml32m_hyperparameters_rotation_trick(tmp_path, monkeypatch):
 
 
 def test_hip_graph_step_matches_eager(tmp_path, monkeypatch):
-    """use_hip_graph=True (opt-in) replays the captured step, re-capturing after eval / tokenisation / checkpoint
+    """use_hip_graph=True (also the default below 4096 rows: `None` = auto) replays the captured step, re-capturing after eval / tokenisation / checkpoint
     excursions; the loss stays on the eager trajectory (graph mode skips epoch-tail batches, so not bit-equal)."""
     import numpy as np
     runs = []

@@ -37,7 +37,7 @@ rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(DST, f"{PRE}_bench_kernel_stats_summary.txt"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats of `python bench.py --config {CFG} --steps {20 if CFG == 'c2' else 3} --warmup 3 --no-cpu-baseline --no-parity` (MI355X, {TAG}; librqhip.so sha256 {str(lib_sha)[:16]})\n")
     f.write(f"# bench line of the same build: profiles/{PRE}_bench_n1.json ({bench['value'] / 1e6:.2f} M items/s, "
-            f"{bench['ms_per_step']:.2f} ms/step; roofline launch mean {bench['roofline']['launch_ms_mean'] * 1e3:.1f} us by HIP events)\n")
+            f"{bench['ms_per_step']:.2f} ms/step; roofline launch mean {bench['roofline_rq']['launch_ms_mean'] * 1e3:.1f} us by HIP events)\n")
     f.write(f"# top kernels by total time; names shortened; full CSV: {PRE}_bench_kernel_stats.csv\n\n")
     f.write(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}\n")
     for r in rows[:40]:
@@ -77,7 +77,7 @@ if fwk:
     v = pmc["kernels"][fwk[0]]
     rows = bench["config"]["micro_batch_rows"]
     corrected = (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024.0
-    algorithmic = bench["roofline"]["hbm_view"]["algorithmic_bytes_per_row"] * rows
+    algorithmic = bench["roofline_rq"]["hbm_view"]["algorithmic_bytes_per_row"] * rows
     pmc["rq_forward_kernel"] = {"rows_per_launch": rows, "hbm_bytes_per_launch_corrected": corrected,
                                 "algorithmic_bytes_per_launch": algorithmic, "ratio": corrected / algorithmic}
 with open(os.path.join(DST, f"{TAG}_pmc_traffic_{cfg_name}.json"), "w") as f:
@@ -103,7 +103,7 @@ if os.path.exists(disp):
            "hip_event_mean_us_on_the_bench_line_of_the_same_run": None}
     try:
         br = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
-        out["hip_event_mean_us_on_the_bench_line_of_the_same_run"] = br["roofline"]["launch_ms_mean"] * 1e3
+        out["hip_event_mean_us_on_the_bench_line_of_the_same_run"] = br["roofline_rq"]["launch_ms_mean"] * 1e3
     except Exception:  # noqa: BLE001
         pass
     with open(os.path.join(DST, f"{PRE}_rq_forward_dispatches.json"), "w") as f:
