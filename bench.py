@@ -77,6 +77,10 @@ def _relaunch_under_torchrun(n: int) -> None:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-ranks", type=int, default=0,
+                    help="rehearsal of the multi-GPU path on ONE GPU: N ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on "
+                         "one device) -- the same torchrun relaunch, init_from_env, armed early all-reduce, long_run and JSON assembly "
+                         "as `--gpus N`; the line says `dry_ranks` and its `value` is not a scaling number")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for c2, 16 for c4: > 1 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
@@ -293,8 +297,9 @@ def _sha256_file(path):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        _relaunch_under_torchrun(args.gpus)
+    n_ranks = args.dry_ranks if args.dry_ranks > 1 else args.gpus
+    if n_ranks > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch_under_torchrun(n_ranks)
 
     import numpy as np
     import torch
@@ -317,9 +322,11 @@ def main():
     micro = min(cfg["micro"], B)
     steps = args.steps if args.steps is not None else (200 if args.config == "c2" else 16)
 
-    rank, local_rank, world = rqdist.init_from_env("cuda")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dry = args.dry_ranks > 1
+    rank, local_rank, world = (rqdist.init_from_env("cuda", backend="gloo", device_index=0) if dry
+                               else rqdist.init_from_env("cuda"))
+    if world != n_ranks:
+        raise SystemExit(f"--gpus {args.gpus} / --dry-ranks {args.dry_ranks} but WORLD_SIZE={world}")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -360,6 +367,8 @@ def main():
     n_fam = steps * n_micro * 26 + 64
     ops.profile_enable(n_fam)
     ops.profile_select("gemm_split", "wgrad")   # the timed region records the kernels that ARE the step: the MLP GEMM / weight-gradient family
+    if world > 1:
+        reducer.enable_timing()
     rqdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -368,6 +377,15 @@ def main():
     torch.cuda.synchronize()
     rqdist.barrier()
     elapsed = time.perf_counter() - t0
+    exposed = reducer.exposed_ms() if world > 1 else []
+    reducer.enable_timing(False)
+    exposed_all = None
+    if world > 1:    # every rank's mean exposed all-reduce time (device events, host clock), gathered on all ranks
+        mine = torch.tensor([float(np.mean([d for d, _ in exposed])) if exposed else 0.0,
+                             float(np.mean([h for _, h in exposed])) if exposed else 0.0], device=device, dtype=torch.float64)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        exposed_all = [[round(float(p[0]), 4), round(float(p[1]), 4)] for p in parts]
     fam_records = ops.profile_read_tagged(n_fam)
     ops.profile_enable(0)
     if dist.is_initialized():
@@ -477,6 +495,7 @@ def main():
         tok_ms = reps(lambda: model.get_semantic_ids(Xm))
     model.train()
     final_loss, p_unique = float(out.loss.detach()), float(out.p_unique_ids)
+    reducer_overlaps = reducer.overlap_launches
 
     # the codebook initialisation alone, warm (the first forward above also pays library / module loading): k-means of
     # every level on its own residuals of the first 20 000 rows, as train_rqvae.py:178-183 triggers it
@@ -681,7 +700,14 @@ def main():
                              "allreduce_ms": round(allreduce_ms, 4), "adamw": round(opt_ms, 3),
                              "first_forward_with_kmeans_init_s": round(kmeans_s, 3),
                              "kmeans_init_s": round(kmeans_only_s, 4)},
-            "rccl_ranks": world,
+            "rccl_ranks": 0 if dry else world,
+            "dry_ranks": world if dry else 0,
+            "allreduce": {"exposed_ms_per_rank_device_host": exposed_all,
+                          "overlap_launches": reducer_overlaps,
+                          "what": "per rank, mean over the timed steps: the part of the step's gradient reduction that is NOT hidden under the "
+                                  "encoder's backward (wait for the early all-reduces + the late ones), by events on the compute stream and by the "
+                                  "host clock; DESIGN.md section 6 predicts >= 0.96 weak-scaling efficiency at 8 GPUs from it",
+                          "backend": ("gloo (dry run: ranks share cuda:0, tensors staged through the host)" if dry else "nccl (RCCL over xGMI)") if world > 1 else None},
             "secondary": {"strict_fp32": strict,
                           "s_rq_items_per_s": round(Bm / srq_ms * 1e3, 1), "s_rq_ms_fwd_bwd": round(srq_ms, 4),
                           "tokenize_items_per_s": round(Bm / tok_ms * 1e3, 1), "tokenize_ms": round(tok_ms, 4),
@@ -696,6 +722,9 @@ def main():
         }
         if long_run is not None:
             line["long_run"] = long_run
+        if dry:
+            line["config"]["parallelism"] = f"DRY RUN: {world} ranks on ONE GPU over gloo -- plumbing rehearsal, not a scaling number"
+            line["n_physical_gpus"] = 1
         del model, opt, reducer, batches, X
         torch.cuda.empty_cache()
         if not args.no_parity:

@@ -117,6 +117,7 @@ class FlatGradReducer:
         self._armed = False
         self._pending: list = []
         self.overlap_launches = 0               # (tests / logs) early launches so far
+        self._timing = None                     # enable_timing(): [(event before, event after, host seconds)] per allreduce_mean()
         offset = 0
         for p in self.params:
             n = p.numel()
@@ -214,6 +215,12 @@ class FlatGradReducer:
             elif p.grad.data_ptr() != v.data_ptr():   # produced by code that does not know the buffer: one small copy
                 v.copy_(p.grad)
             p.grad = v
+        timed = self._timing is not None and self.flat.is_cuda
+        if timed:
+            import time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t0 = time.perf_counter()
         if self._pending:          # the early part is on the wire (boundary_hook): wait for it, reduce the rest
             for work in self._pending:
                 work.wait()
@@ -222,8 +229,25 @@ class FlatGradReducer:
                 dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if timed:
+            e1.record()
+            self._timing.append((e0, e1, time.perf_counter() - t0))
         self.flat.mul_(1.0 / w)
         return self.flat
+
+    def enable_timing(self, on: bool = True) -> None:
+        """Bench only: bracket the EXPOSED part of every following reduction -- the wait for the early all-reduces plus the late
+        ones, i.e. what is not hidden under the encoder's backward -- with two events on the current stream (and the host clock)."""
+        self._timing = [] if on else None
+
+    def exposed_ms(self) -> List[tuple]:
+        """[(device ms, host ms)] per allreduce_mean() since enable_timing(); synchronises; clears the list."""
+        if not self._timing:
+            return []
+        torch.cuda.synchronize()
+        out = [(a.elapsed_time(b), 1e3 * h) for a, b, h in self._timing]
+        self._timing = []
+        return out
 
 
 def claim_grad_sink(w: Tensor):

@@ -274,3 +274,30 @@ def test_hip_graph_step_with_rccl_group():
     # 25 AdamW steps from the same start: the two trajectories agree to rounding noise amplified by the optimiser (the bound of
     # tests/test_gpu_train.py:test_hip_graph_step_matches_eager)
     assert res["eager"] == res["eager"] and abs(res["eager"] - res["graph"]) <= 2e-3 * max(1.0, abs(res["eager"])), res
+
+
+def test_bench_dry_ranks_line_is_consistent():
+    """`python bench.py --dry-ranks 2`: the whole multi-rank path of the bench -- self-relaunch under torch.distributed.run,
+    init_from_env, armed early all-reduce, long_run, per-rank exposed all-reduce times, JSON assembly on rank 0 -- with two
+    ranks on the one GPU over gloo.  The line must parse and be self-consistent."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dry-ranks", "2", "--batch", "8192", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--no-parity", "--no-small-batch", "--min-seconds", "0.3"]
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=540, env=env)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_ranks"] == 2 and j["rccl_ranks"] == 0 and j["n_physical_gpus"] == 1
+    assert j["steps"] == 4 and j["config"]["rows_per_gpu_per_step"] == 8192
+    # value = rows of all ranks / time of the K steps
+    assert abs(j["value"] - 2 * 8192 / (j["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
+    assert j["long_run"]["steps"] > 4 and abs(j["long_run"]["items_per_s"] - 2 * 8192 / (j["long_run"]["ms_per_step"] * 1e-3)) <= 1e-3 * j["value"]
+    ar = j["allreduce"]
+    assert len(ar["exposed_ms_per_rank_device_host"]) == 2 and all(h > 0 for _, h in ar["exposed_ms_per_rank_device_host"])
+    assert ar["overlap_launches"] > 0                      # the early half went on the wire under the encoder's backward
+    assert j["roofline"]["bound"] == "mfma" and j["roofline"]["launches"] > 0 and 0 < j["roofline"]["frac"] < 1
