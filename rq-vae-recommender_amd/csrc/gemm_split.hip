@@ -55,8 +55,8 @@ typedef int gs_i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGsUB = 2;                    // a wave's tile is (32 TA) x (32 UB)
 constexpr int kGsK = 16;                    // reduction depth of a stage = one K step of the matrix instruction
-constexpr int kGsColmaxLds = 1024;
-constexpr int kGsTailWords = 32;             // words behind a weight image that hold the tile dispensers (zero between launches)          // column maxima are pre-reduced in LDS for Nc up to this (else straight to memory)
+constexpr int kGsColmaxLds = 1024;          // column maxima are pre-reduced in LDS for Nc up to this (else straight to memory)
+constexpr int kGsTailWords = kWeightImageTailWords;   // words behind a weight image that hold the tile dispensers (zero between launches)
 
 // (a, b) -> packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
 __device__ __forceinline__ void gs_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
@@ -269,7 +269,8 @@ struct GemmSplitParams {
     // tiles 0 .. n_big - 1 are 256 rows high (rows [0, 256 rt_big)), the rest 64 rows high (from row 256 rt_big on)
     unsigned n_big, n_tiles;
     int rt_big;
-    unsigned *counter;       // [0] tile dispenser, [1] workgroups that have left; both zero between launches
+    unsigned *counter;       // the tile dispensers behind the weight image (kGsTailWords words, zero between launches)
+    int n_queues;            // gemm_f16_kernel: 1 (chip-wide dispenser) or 8 (one per XCD)
     // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
     // rowsum[ct][m] the squared error of row m over column tile ct.  EPI == 3: X is Y, the activation whose ReLU is undone
     const float *X;
@@ -856,11 +857,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSpl
 
 // The product kernel: gs_tile2 tiles of 128 rows (64-row tiles for what is left over after the whole rounds), 4 waves, TWO
 // persistent workgroups per CU: one's tile prologue, barriers and epilogue fall into the other's matrix instructions.
-// Tile dispensers, ONE PER XCD (round 5): workgroup b runs on XCD b % 8 (workgroups are dealt to the XCDs round robin), queue q
-// holds the row tiles rt = q (mod 8) with their column tiles back to back, so the column tiles of one row tile -- which read the
-// same strip of A -- run on ONE XCD and share it in that XCD's L2 (with a single dispenser they went to different XCDs and the
-// strip was fetched from HBM once per column tile: 1.40-1.55 x the algorithmic bytes by the PMC counters, profiles/r04_pmc_*).
-// A workgroup whose own queue is empty takes from the next XCD's.  counter[0..7] big-tile queues, [8..15] small-tile queues,
+// Tile dispensers: n_queues of them.  With 8 (round 5's experiment) workgroup b -- which runs on XCD b % 8,
+// workgroups are dealt to the XCDs round robin -- takes from queue b % 8, which holds the row tiles rt = q (mod 8) with their column
+// tiles back to back: the column tiles of one row tile, which read the same strip of A, then run on ONE XCD and share it in that
+// XCD's L2.  Measured (profiles/r05_gemm_xcd_dispenser_ab.txt): the HBM traffic falls from 1.40-1.55 x to 1.08-1.15 x the
+// algorithmic bytes, bits unchanged -- and the kernels get 35-40 % SLOWER (768 -> 512: 247 -> ~340 us in the step): the column
+// tiles of a row tile now stream the same lines of A in lockstep through one L2.  The kernels are not HBM-bound (2-3 TB/s), so the
+// product uses ONE queue (n_queues = 1: the chip-wide dispenser of round 4); the per-XCD form stays selectable (tile_rows = -8).
+// A workgroup whose own queue is empty takes from the next one.  counter[0..7] big-tile queues, [8..15] small-tile queues,
 // [16] workgroups that have left (the last one re-arms all of them).  (Round 4 also tried starting the second workgroup of
 // every CU half a tile late: neutral to -7 %, tools/experiments/gemm_split_r04_variants.hip.)
 constexpr int kGsQueues = 8;
@@ -879,23 +883,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams 
         for (int c = tid; c < p.Nc; c += kThreads) s_colmax[c] = 0u;
     const unsigned nct = (unsigned)p.n_col_tiles;
     const unsigned rt_big = p.n_big / nct, rt_small = (p.n_tiles - p.n_big) / nct;
-    const int xcd = (int)(blockIdx.x & (kGsQueues - 1));
+    // p.n_queues: 8 = one queue per XCD; 1 (the default, see rqhip_gemm_split_ex) = a single queue for the chip
+    const int nq = p.n_queues;
+    const int xcd = (int)(blockIdx.x % (unsigned)nq);
     int big_skip = 0, small_skip = 0;          // (thread 0) queues found empty so far, in this workgroup's visiting order
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
         if (tid == 0) {
             unsigned t = kNone;
-            for (; big_skip < kGsQueues; ++big_skip) {
-                const unsigned q = (unsigned)((xcd + big_skip) & (kGsQueues - 1));
+            for (; big_skip < nq; ++big_skip) {
+                const unsigned q = (unsigned)((xcd + big_skip) % nq);
                 const unsigned j = atomicAdd(p.counter + q, 1u);
-                const unsigned rt = (j / nct) * kGsQueues + q;
+                const unsigned rt = (j / nct) * (unsigned)nq + q;
                 if (rt < rt_big) { t = rt * nct + j % nct; break; }
             }
             if (t == kNone) {
-                for (; small_skip < kGsQueues; ++small_skip) {
-                    const unsigned q = (unsigned)((xcd + small_skip) & (kGsQueues - 1));
+                for (; small_skip < nq; ++small_skip) {
+                    const unsigned q = (unsigned)((xcd + small_skip) % nq);
                     const unsigned j = atomicAdd(p.counter + kGsQueues + q, 1u);
-                    const unsigned rt = (j / nct) * kGsQueues + q;
+                    const unsigned rt = (j / nct) * (unsigned)nq + q;
                     if (rt < rt_small) { t = (rt * nct + j % nct) | kSmallBit; break; }
                 }
             }
@@ -1050,6 +1056,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.X = a->aux; p.rowsum = reinterpret_cast<float *>(a->workspace); p.row_scale = a->row_scale;
     p.a_max = a->a_row_max; p.a_parts = a->a_row_parts;
     p.c_rowmax = a->c_row_max; p.c_colmax = a->c_col_max;
+    p.n_queues = a->tile_rows == -8 ? kGsQueues : 1;   // (tools: tile_rows = -8 selects the per-XCD dispensers, A/B)
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
