@@ -422,7 +422,7 @@ int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_
  *   rqhip_gemm_img    : C = epilogue(A . image^T): A an image (R, E), `image` a weight image (rqhip_weight_images, RQHIP_SPLIT_F16X2);
  *                       outputs, any of: fp32 C [M, Nc]; the image of C (`out`: the planes present; segment = the tile width);
  *                       RQHIP_EPI_RECON: loss_rows, and the gradient (2 (A.B^T - aux)) * row_scale (or * row_scales[m]) as C / out;
- *                       RQHIP_EPI_MASK: the result zeroed where Y's image holds no positive value (Y: R planes).
+ *                       RQHIP_EPI_MASK: the result zeroed where Y's image holds no positive value (Y: T or R planes).
  *                       Consumers of images with several segments rescale their accumulators at segment boundaries; segments of a
  *                       row more than 2^64 below the row's largest one are dropped.  Needs Nc % 128 == 0, R % 128 == 0, R <= 2048.
  *   rqhip_linear_wgrad_img : dW [N, K] = g^T x from the T planes of g [M, N] and x [M, K] (both with E); shapes, row ranges,
@@ -446,7 +446,7 @@ typedef struct {
     float *C;                /* fp32 [M, Nc] or NULL */
     rqhip_img out;           /* the image of C: planes to write (R / T may be NULL; E required with either); all NULL: none */
     const float *aux;        /* RQHIP_EPI_RECON: X [M, Nc] */
-    rqhip_img Y;             /* RQHIP_EPI_MASK: R planes of Y [M, Nc] */
+    rqhip_img Y;             /* RQHIP_EPI_MASK: the image of Y [M, Nc]: its T planes (preferred: coalesced) or its R planes */
     float row_scale;         /* RQHIP_EPI_RECON */
     const float *row_scales; /* RQHIP_EPI_RECON: [M], used instead of row_scale when not NULL */
     float *loss_rows;        /* RQHIP_EPI_RECON: [M] */

@@ -95,8 +95,14 @@ __device__ __forceinline__ size_t gi_r_index(long long row, int ks, int ph, int 
 }
 // 16-byte element index of (32-row block b, row residue rl = row % 4, piece, column) in a T image of N columns: the element holds
 // rows 32 b + 4 k + rl, k = 0 .. 7; it belongs to stage 2 b + (rl >> 1), octet rl & 1
+// ... at POSITION gi_t_pos(col) of its (stage, piece, octet) run: inside every 64-column group the columns are stored in the order
+// the producing lanes hold them (position 16 j + c <-> column 4 c + j), so that a store instruction's 16 lanes write 16 consecutive
+// elements (256 contiguous bytes) -- in column order they wrote every fourth element, four times the cache-line requests (measured:
+// + 50 us on a 100 000 x 512 result).  The weight gradient multiplies positions and maps its result back with gi_t_col.
+__device__ __forceinline__ int gi_t_pos(int col) { return (col & ~63) + 16 * (col & 3) + ((col & 63) >> 2); }
+__device__ __forceinline__ int gi_t_col(int pos) { return (pos & ~63) + 4 * (pos & 15) + ((pos & 63) >> 4); }
 __device__ __forceinline__ size_t gi_t_index(long long b, int rl, int piece, int col, int N) {
-    return ((((size_t)(2 * b + (rl >> 1)) * 2 + piece) * 2 + (rl & 1)) * N) + col;
+    return ((((size_t)(2 * b + (rl >> 1)) * 2 + piece) * 2 + (rl & 1)) * N) + gi_t_pos(col);
 }
 
 // where a lane's block of results goes
@@ -143,12 +149,12 @@ __device__ __forceinline__ void gi_emit_block(const GiOut &o, const gi_f32x4 (&v
     }
     if (o.T && row0 < ((o.M + 31) & ~31LL)) {
         const long long b = row0 >> 5;
-        gi_u32x4 *dh = reinterpret_cast<gi_u32x4 *>(o.T) + gi_t_index(b, rl, 0, colw, o.N);
+        gi_u32x4 *dh = reinterpret_cast<gi_u32x4 *>(o.T) + gi_t_index(b, rl, 0, colw, o.N);      // column colw + j: 16 j elements further
         gi_u32x4 *dm = reinterpret_cast<gi_u32x4 *>(o.T) + gi_t_index(b, rl, 1, colw, o.N);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            dh[j] = gi_u32x4{th[j][0], th[j][1], th[j][2], th[j][3]};
-            dm[j] = gi_u32x4{tm[j][0], tm[j][1], tm[j][2], tm[j][3]};
+            dh[16 * j] = gi_u32x4{th[j][0], th[j][1], th[j][2], th[j][3]};
+            dm[16 * j] = gi_u32x4{tm[j][0], tm[j][1], tm[j][2], tm[j][3]};
         }
     }
 }
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void img_unpack_t_kernel(const unsigned *__res
         const int col = (int)(i % N);
         const int rl = (int)((i / N) % 4);
         const long long b = (long long)(i / ((size_t)4 * N));
-        const gi_f16x8 h = __builtin_bit_cast(gi_f16x8, reinterpret_cast<const gi_u32x4 *>(T)[gi_t_index(b, rl, 0, col, N)]);
+        const gi_f16x8 h = __builtin_bit_cast(gi_f16x8, reinterpret_cast<const gi_u32x4 *>(T)[gi_t_index(b, rl, 0, col, N)]);   // (positions inside)
         const gi_f16x8 m = __builtin_bit_cast(gi_f16x8, reinterpret_cast<const gi_u32x4 *>(T)[gi_t_index(b, rl, 1, col, N)]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -257,7 +263,8 @@ struct GemmImgParams {
     int rt_big;
     GiOut o;                 // outputs: fp32 C and / or the image of C (o.N == Nc, segment = the tile width)
     const float *X;          // EPI 2: the target [M, Nc]
-    const unsigned *yR;      // EPI 3: R planes of Y [M, Nc] (C is zeroed where the high piece of Y is not positive)
+    const unsigned *yR;      // EPI 3: R planes of Y [M, Nc] (C is zeroed where the high piece of Y is not positive) ...
+    const unsigned *yT;      // ... or, preferred when present, its T planes (coalesced: four 16-byte loads per 32-row block and lane)
     float *rowsum;           // EPI 2: [column tiles][M]
     float row_scale;         // EPI 2: C = (2 (A.B^T - X)) * row_scale ...
     const float *row_scales; // ... or * row_scales[m] when given
@@ -468,6 +475,15 @@ __device__ __forceinline__ void gi_tile(const GemmImgParams &p, unsigned *sbuf, 
     gi_f32x4 vv[TA][8];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
+        gi_u32x4 ym[4];
+        if (EPI == 3 && p.yT) {   // (requested before the transposition: the block's whole mask in four coalesced loads)
+            long long yb32 = (m0 + 32 * TA * lwm + 32 * t) >> 5;
+            const long long last = (p.M - 1) >> 5;
+            yb32 = yb32 < last ? yb32 : last;                         // (a block past the matrix: any valid block, its rows are not stored)
+            const gi_u32x4 *ys = reinterpret_cast<const gi_u32x4 *>(p.yT) + gi_t_index(yb32, rl, 0, colw, p.Nc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ym[j] = ys[16 * j];
+        }
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
@@ -504,13 +520,18 @@ __device__ __forceinline__ void gi_tile(const GemmImgParams &p, unsigned *sbuf, 
                 if (cl == 15) s_red[lwn * ROWS + rloc] = s16;
             }
             if (EPI == 3) {   // threshold_backward(g, y, 0) from the high piece of y's image: y > 0 <=> its fp16 bits in 0x0001 .. 0x7fff
-                const long long yr = grow < p.M ? grow : p.M - 1;        // (and above: a NaN passes, as `y <= 0 ? 0 : g` lets it)
-                const gi_u32x2 yh = *reinterpret_cast<const gi_u32x2 *>(p.yR + gi_r_index(yr, colw >> 4, (colw >> 3) & 1, p.Nc / kGiK) * 4
-                                                                         + 2 * ((colw >> 2) & 1));
-                v.x = ((yh.x & 0xffffu) - 1u) < 0x7fffu || (yh.x & 0x7fffu) > 0x7c00u ? v.x : 0.0f;
-                v.y = ((yh.x >> 16) - 1u) < 0x7fffu || ((yh.x >> 16) & 0x7fffu) > 0x7c00u ? v.y : 0.0f;
-                v.z = ((yh.y & 0xffffu) - 1u) < 0x7fffu || (yh.y & 0x7fffu) > 0x7c00u ? v.z : 0.0f;
-                v.w = ((yh.y >> 16) - 1u) < 0x7fffu || ((yh.y >> 16) & 0x7fffu) > 0x7c00u ? v.w : 0.0f;
+                unsigned yb[4];                                           // (and above 0x7c00: a NaN passes, as `y <= 0 ? 0 : g` lets it)
+                if (p.yT) {   // the T planes: the lane's four columns x eight rows of this block are four 16-byte elements (ym)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yb[j] = (ym[j][k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                } else {
+                    const long long yr = grow < p.M ? grow : p.M - 1;
+                    const gi_u32x2 yh = *reinterpret_cast<const gi_u32x2 *>(p.yR + gi_r_index(yr, colw >> 4, (colw >> 3) & 1, p.Nc / kGiK) * 4
+                                                                             + 2 * ((colw >> 2) & 1));
+                    yb[0] = yh.x & 0xffffu; yb[1] = yh.x >> 16; yb[2] = yh.y & 0xffffu; yb[3] = yh.y >> 16;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ((yb[j] - 1u) < 0x7fffu || (yb[j] & 0x7fffu) > 0x7c00u) ? v[j] : 0.0f;
             }
             if (grow < p.M) {
                 if (p.o.C) *reinterpret_cast<gi_f32x4 *>(p.o.C + (size_t)grow * p.Nc + colw) = v;
@@ -828,8 +849,8 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_img_kernel(const WgradImgP
         __syncthreads();
     }
 
-    // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r]:
-    // n = n0 + wave's base + 32 t + 8 (r >> 2) + 4 h + (r & 3),  k = k0 + wave's base + 32 u + il
+    // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r] belongs to the T-image POSITIONS
+    // wave's base + 32 t + 8 (r >> 2) + 4 h + (r & 3) of g and wave's base + 32 u + il of x (the slab starts are multiples of 64)
     float *dst = p.out + (size_t)split * p.N * p.K;
 #pragma unroll
     for (int t = 0; t < TA; ++t)
@@ -837,8 +858,8 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_img_kernel(const WgradImgP
         for (int u = 0; u < TB; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-                const int k = k0 + wb * 32 * TB + 32 * u + il;
+                const int n = n0 + gi_t_col(wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3));      // positions -> columns
+                const int k = k0 + gi_t_col(wb * 32 * TB + 32 * u + il);
                 dst[(size_t)n * p.K + k] = eref > kGiEZero ? ldexpf(acc[t][u][r], eref) : 0.0f;
             }
 }
@@ -853,7 +874,7 @@ int launch_wgrad_img(int cfg, const unsigned *gT, const int *gE, int g_seg, cons
     auto go = [&](auto kern, int Nt, int Kt, int waves) -> int {
         static LdsGrant grant;
         const size_t lds = (size_t)2 * 4 * (Nt + Kt) * 16;
-        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)lds));      // (+ the kernel's static LDS)
         hipLaunchKernelGGL(kern, dim3(nslab_n * nslab_k * msplit), dim3(64 * waves), lds, s, p);
         RQ_CHECK_LAUNCH("wgrad_img_kernel");
         return 0;
@@ -967,7 +988,7 @@ extern "C" int rqhip_gemm_img(const rqhip_gemm_img_args *a, rqhip_stream_t strea
         return RQHIP_EARG;
     }
     if (M > 0 && epi == RQHIP_EPI_MASK) {
-        if (int rc = gi_check_img(&a->Y, "gemm_img (Y)", true, false)) return rc;
+        if (int rc = gi_check_img(&a->Y, "gemm_img (Y)", a->Y.T == nullptr, false)) return rc;      // R planes, or T planes
         if (a->Y.M != M || a->Y.N != Nc) {
             set_error("gemm_img: the mask image must be [M, Nc]");
             return RQHIP_EARG;
@@ -983,7 +1004,7 @@ extern "C" int rqhip_gemm_img(const rqhip_gemm_img_args *a, rqhip_stream_t strea
     p.b_exp = reinterpret_cast<const int *>(p.counter + kWeightImageTailWords);
     p.M = M; p.R = R; p.Nc = Nc; p.n_col_tiles = Nc / cols;
     p.o.C = a->C; p.o.R = reinterpret_cast<unsigned *>(a->out.R); p.o.T = reinterpret_cast<unsigned *>(a->out.T); p.o.E = a->out.E; p.o.M = M; p.o.N = Nc;
-    p.X = a->aux; p.yR = reinterpret_cast<const unsigned *>(a->Y.R); p.rowsum = reinterpret_cast<float *>(a->workspace);
+    p.X = a->aux; p.yR = reinterpret_cast<const unsigned *>(a->Y.R); p.yT = reinterpret_cast<const unsigned *>(a->Y.T); p.rowsum = reinterpret_cast<float *>(a->workspace);
     p.row_scale = a->row_scale; p.row_scales = a->row_scales; p.run_flag = a->run_flag;
     const int cus = cu_count();
     const long long slots = (long long)cus * 2, big_rows = 128, small_rows = 64;

@@ -34,7 +34,7 @@ for Nc, R, epi in ((512, 768, 1), (256, 512, 1), (128, 256, 1), (256, 128, 1), (
     img_w = ops.weight_planes(w, arith=ops.F16X2)
     rows = ops.maxima(a, cols=False)[0]
     ia = ops.img_pack(a, want_t=False)[0]
-    iy = ops.img_pack(torch.relu(x), want_t=False)[0]
+    iy = ops.img_pack(torch.relu(x))[0]
     kw4 = dict(epilogue=epi, a_row_max=rows, want_row_max=True, col_max_out=torch.zeros(Nc, dtype=torch.int32, device="cuda"))
     if epi >= 2:
         kw4["aux"] = x
