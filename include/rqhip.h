@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 500 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 410 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -368,7 +368,8 @@ typedef struct {
     int Nc;
     int arith;           /* RQHIP_SPLIT_* the image was built with */
     int epilogue;        /* RQHIP_EPI_* */
-    int tile_rows;       /* 0 (tools only, staged-B kernels: 256 / 128 force big tiles, 64 / 32 small ones) */
+    int tile_rows;       /* 0 (tools only: staged-B kernels 256 / 128 force big tiles, 64 / 32 small ones; -8: gemm_f16_kernel with one
+                            tile dispenser per XCD instead of one for the chip -- measured slower, profiles/r05_gemm_xcd_dispenser_ab.txt) */
     float *C;            /* [M, Nc] */
     const float *aux;    /* RQHIP_EPI_RECON: X [M, Nc]; RQHIP_EPI_MASK: Y [M, Nc]; else NULL */
     float row_scale;     /* RQHIP_EPI_RECON */
@@ -402,72 +403,6 @@ int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_sca
  * (the row's new maximum in part 0, the other parts cleared) and col_max [N] (maxed into); either may be NULL */
 int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_scale, float *g_spec, unsigned *row_max,
                                 int row_parts, unsigned *col_max, rqhip_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------
- * Round 5: the same GEMMs and weight gradients on OPERAND IMAGES (csrc/gemm_img.hip) -- the product path of the MLPs at batches of
- * 4096 rows and more.  Same arithmetic (RQHIP_SPLIT_F16X2: two fp16 pieces under exact power-of-two scales, products hh + hm + mh,
- * fp32 accumulation), but an activation or gradient is split ONCE, by the kernel that produces it, into the layouts its consumers
- * stream, instead of by every kernel that reads it (reference modules/encoder.py:25-38 and its autograd; modules/rqvae.py:146,152).
- * An image of X [M, N] (N % 128 == 0; columns in segments of seg = rqhip_img_seg(N) = 256, or 128 when N % 256 != 0):
- *   E  int32 [N / seg][M]  exponent of (segment, row): the stored values are X * 2^-E, the segment's largest |value| in [2^14, 2^15);
- *                          -200 for an all-zero segment, 0 for one holding inf / nan (stored unscaled)
- *   R  rqhip_img_r_bytes(M, N): [ceil(M/64)][N/16][piece][half][64 rows] x 16 bytes (8 consecutive columns of a row, one piece) --
- *                          the A operand of a GEMM
- *   T  rqhip_img_t_bytes(M, N): [ceil(M/32) * 2][piece][octet][N] x 16 bytes (8 rows of a column, one piece; inside a 32-row block
- *                          position 8 (r % 4) + r / 4 holds row r; rows >= M are zeros) -- the operands of the weight gradient
- * Buffers are caller-owned (torch tensors), 16-byte aligned; R or T may be NULL where a call does not need it.
- *   rqhip_img_pack    : fp32 A [M, N] (masked by Y > 0 when Y is given -- the ReLU backward --, the masked matrix also to masked_out
- *                       when that is not NULL) -> the image planes present in `out`.
- *   rqhip_img_unpack  : the values an image stands for, (h + m) 2^E, from its R planes (from_t = 0) or its T planes (from_t = 1).
- *   rqhip_gemm_img    : C = epilogue(A . image^T): A an image (R, E), `image` a weight image (rqhip_weight_images, RQHIP_SPLIT_F16X2);
- *                       outputs, any of: fp32 C [M, Nc]; the image of C (`out`: the planes present; segment = the tile width);
- *                       RQHIP_EPI_RECON: loss_rows, and the gradient (2 (A.B^T - aux)) * row_scale (or * row_scales[m]) as C / out;
- *                       RQHIP_EPI_MASK: the result zeroed where Y's image holds no positive value (Y: T or R planes).
- *                       Consumers of images with several segments rescale their accumulators at segment boundaries; segments of a
- *                       row more than 2^64 below the row's largest one are dropped.  Needs Nc % 128 == 0, R % 128 == 0, R <= 2048.
- *   rqhip_linear_wgrad_img : dW [N, K] = g^T x from the T planes of g [M, N] and x [M, K] (both with E); shapes, row ranges,
- *                       reduction tree and workspace as rqhip_linear_wgrad for the layers csrc/wgrad_split.hip tiles (N, K multiples
- *                       of 128, one of them of 256).  The ReLU mask is applied by whoever produced g's image.
- *   rqhip_rows_differ : *flag = 1 when some g_out[m] is not `announced` (bit compare), else 0 -- the device-side test behind the
- *                       speculative reconstruction gradient: calls given `run_flag` do nothing unless *run_flag != 0.
- */
-typedef struct {
-    void *R;        /* or NULL */
-    void *T;        /* or NULL */
-    int32_t *E;
-    int64_t M;
-    int N, seg;
-} rqhip_img;
-typedef struct {
-    rqhip_img A;             /* R and E */
-    const void *image;       /* of B [Nc, R] (rqhip_weight_images, RQHIP_SPLIT_F16X2) */
-    int Nc;
-    int epilogue;            /* RQHIP_EPI_* */
-    float *C;                /* fp32 [M, Nc] or NULL */
-    rqhip_img out;           /* the image of C: planes to write (R / T may be NULL; E required with either); all NULL: none */
-    const float *aux;        /* RQHIP_EPI_RECON: X [M, Nc] */
-    rqhip_img Y;             /* RQHIP_EPI_MASK: the image of Y [M, Nc]: its T planes (preferred: coalesced) or its R planes */
-    float row_scale;         /* RQHIP_EPI_RECON */
-    const float *row_scales; /* RQHIP_EPI_RECON: [M], used instead of row_scale when not NULL */
-    float *loss_rows;        /* RQHIP_EPI_RECON: [M] */
-    void *workspace;         /* RQHIP_EPI_RECON: rqhip_gemm_split_recon_workspace_bytes(M, Nc) */
-    size_t workspace_bytes;
-    const int *run_flag;     /* optional device flag: the call's kernels do nothing unless *run_flag != 0 */
-    int xcd_queues;          /* 0: one tile dispenser for the chip (product); 1: one per XCD (A/B) */
-} rqhip_gemm_img_args;
-int rqhip_img_supported(int N);
-int rqhip_img_seg(int N);
-size_t rqhip_img_r_bytes(int64_t M, int N);
-size_t rqhip_img_t_bytes(int64_t M, int N);
-size_t rqhip_img_e_bytes(int64_t M, int N);
-int rqhip_img_pack(const float *A, const float *Y, float *masked_out, int64_t M, int N, const rqhip_img *out, const int *run_flag,
-                   rqhip_stream_t stream);
-int rqhip_img_unpack(const rqhip_img *img, int from_t, float *out, rqhip_stream_t stream);
-int rqhip_rows_differ(const float *g_out, int64_t M, float announced, int *flag, rqhip_stream_t stream);
-int rqhip_gemm_img_supported(int Nc, int R);
-int rqhip_gemm_img(const rqhip_gemm_img_args *args, rqhip_stream_t stream);
-int rqhip_linear_wgrad_img(const rqhip_img *g, const rqhip_img *x, float *dW, void *workspace, size_t workspace_bytes,
-                           const int *run_flag, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline objects (no reference counterpart).  While enabled, the calls below bracket

@@ -220,8 +220,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
 // A workgroup owns kRedElems float4 elements of dW, stages all their partials in LDS and walks the tree there.
 constexpr int kRedElems = 4;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, int pow2,
-                                                           size_t nk4, float *__restrict__ dw, const int *__restrict__ run_flag) {
-    if (run_flag && *run_flag == 0) return;      // (rqhip_linear_wgrad_img under a clear flag: nothing was written, nothing is reduced)
+                                                           size_t nk4, float *__restrict__ dw) {
     extern __shared__ __attribute__((aligned(16))) char red_smem[];
     wg_f32x4 *a = reinterpret_cast<wg_f32x4 *>(red_smem);   // [pow2][kRedElems]
     const size_t base = (size_t)blockIdx.x * kRedElems;
@@ -343,57 +342,6 @@ extern "C" int rqhip_linear_wgrad_f16(const float *g, const float *y, const floa
     return linear_wgrad_impl(g, y, x, M, N, K, g_masked, dW, workspace, workspace_bytes, 0u, g_col_max, x_col_max, stream);
 }
 
-namespace rqhip {
-int launch_wgrad_img(int cfg, const unsigned *gT, const int *gE, int g_seg, const unsigned *xT, const int *xE, int x_seg, long long M, int N, int K,
-                     float *out, int nslab_n, int nslab_k, int msplit, const int *run_flag, hipStream_t s);   // gemm_img.hip
-}
-
-// dW = g^T x from operand images (csrc/gemm_img.hip): this file's plan (row ranges, workspace) and reduction tree
-extern "C" int rqhip_linear_wgrad_img(const rqhip_img *g, const rqhip_img *x, float *dW, void *workspace, size_t workspace_bytes,
-                                      const int *run_flag, rqhip_stream_t stream) {
-    if (!g || !x || !dW || g->M != x->M || g->M < 0 || (g->M > 0 && (!g->T || !g->E || !x->T || !x->E))) {
-        set_error("linear_wgrad_img: bad arguments (images of g [M, N] and x [M, K] with T and E planes, dW)");
-        return RQHIP_EARG;
-    }
-    const int64_t M = g->M;
-    const int N = g->N, K = x->N;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (M == 0) {
-        if (int rc = fill_words(dW, 0u, (size_t)N * K * sizeof(float), s)) return rc;
-        return RQHIP_OK;
-    }
-    const WgradPlan pl = wgrad_plan(M, N, K);
-    if (pl.cfg < 0 || pl.cfg > 2 || g->seg % pl.Nt != 0 || x->seg % pl.Kt != 0) {
-        set_error("linear_wgrad_img: unsupported layer shape N=%d K=%d (multiples of 128, one of them of 256; image segments %d / %d)", N, K,
-                  g->seg, x->seg);
-        return RQHIP_EUNSUPPORTED;
-    }
-    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (!al16(g->T) || !al16(x->T) || !al16(dW) || !al16(workspace)) {
-        set_error("linear_wgrad_img: pointers must be 16-byte aligned");
-        return RQHIP_EARG;
-    }
-    if (pl.msplit > 1 && (!workspace || workspace_bytes < rqhip_linear_wgrad_workspace_bytes(M, N, K))) {
-        set_error("linear_wgrad_img: workspace too small");
-        return RQHIP_EWORKSPACE;
-    }
-    float *out = pl.msplit > 1 ? reinterpret_cast<float *>(workspace) : dW;
-    profile_begin(s, RQHIP_PROF_WGRAD, 2.0 * (double)M * N * K, 4.0 * (double)M * (N + K));
-    int rc = launch_wgrad_img(pl.cfg, reinterpret_cast<const unsigned *>(g->T), g->E, g->seg, reinterpret_cast<const unsigned *>(x->T), x->E, x->seg,
-                              M, N, K, out, pl.nslab_n, pl.nslab_k, pl.msplit, run_flag, s);
-    if (rc) { profile_end(s); return rc; }
-    if (pl.msplit > 1) {
-        // (with a run flag that is clear the partial blocks were not written: the reduction must not run either -- the flag guards it)
-        const size_t nk4 = (size_t)N * K / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + kRedElems - 1) / kRedElems)), dim3(256),
-                           (size_t)pl.pow2 * kRedElems * sizeof(wg_f32x4), s, reinterpret_cast<const float *>(workspace),
-                           pl.msplit, pl.pow2, nk4, dW, run_flag);
-        RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
-    }
-    profile_end(s);
-    return RQHIP_OK;
-}
-
 static int linear_wgrad_impl(const float *g, const float *y, const float *x, int64_t M, int N, int K, float *g_masked, float *dW,
                              void *workspace, size_t workspace_bytes, unsigned flags, const unsigned *g_col_max,
                              const unsigned *x_col_max, rqhip_stream_t stream) {
@@ -453,7 +401,7 @@ static int linear_wgrad_impl(const float *g, const float *y, const float *x, int
         const size_t nk4 = (size_t)N * K / 4;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + kRedElems - 1) / kRedElems)), dim3(256),
                            (size_t)pl.pow2 * kRedElems * sizeof(wg_f32x4), s, reinterpret_cast<const float *>(workspace),
-                           pl.msplit, pl.pow2, nk4, dW, static_cast<const int *>(nullptr));
+                           pl.msplit, pl.pow2, nk4, dW);
         RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
     }
     profile_end(s);

@@ -38,16 +38,6 @@ class GemmArgs(C.Structure):          # rqhip_gemm_args
                 ("c_row_max", C.c_void_p), ("c_col_max", C.c_void_p)]
 
 
-class ImgC(C.Structure):              # rqhip_img
-    _fields_ = [("R", C.c_void_p), ("T", C.c_void_p), ("E", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("seg", C.c_int)]
-
-
-class GemmImgArgs(C.Structure):       # rqhip_gemm_img_args
-    _fields_ = [("A", ImgC), ("image", C.c_void_p), ("Nc", C.c_int), ("epilogue", C.c_int), ("C", C.c_void_p), ("out", ImgC),
-                ("aux", C.c_void_p), ("Y", ImgC), ("row_scale", C.c_float), ("row_scales", C.c_void_p), ("loss_rows", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("run_flag", C.c_void_p), ("xcd_queues", C.c_int)]
-
-
 class ProfileRecord(C.Structure):     # rqhip_profile_record
     _fields_ = [("tag", C.c_int), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -110,17 +100,6 @@ SIGNATURES = {
     "rqhip_gemm_split_recon": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_recon_rescale_rows": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
     "rqhip_recon_rescale_rows_ex": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _int, _vp, _vp]),
-    "rqhip_img_supported": (_int, [_int]),
-    "rqhip_img_seg": (_int, [_int]),
-    "rqhip_img_r_bytes": (_sz, [_i64, _int]),
-    "rqhip_img_t_bytes": (_sz, [_i64, _int]),
-    "rqhip_img_e_bytes": (_sz, [_i64, _int]),
-    "rqhip_img_pack": (_int, [_vp, _vp, _vp, _i64, _int, C.POINTER(ImgC), _vp, _vp]),
-    "rqhip_img_unpack": (_int, [C.POINTER(ImgC), _int, _vp, _vp]),
-    "rqhip_rows_differ": (_int, [_vp, _i64, _f32, _vp, _vp]),
-    "rqhip_gemm_img_supported": (_int, [_int, _int]),
-    "rqhip_gemm_img": (_int, [C.POINTER(GemmImgArgs), _vp]),
-    "rqhip_linear_wgrad_img": (_int, [C.POINTER(ImgC), C.POINTER(ImgC), _vp, _vp, _sz, _vp, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_select": (_int, [C.c_uint]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),

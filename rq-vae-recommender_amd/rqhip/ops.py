@@ -539,131 +539,6 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
     return dw, (g if y is None else gm)
 
 
-# ---- operand images (csrc/gemm_img.hip): an activation / gradient split once, by its producer, into its consumers' layouts ----------
-class Img:
-    """The image of a matrix [M, N]: `R` (uint8 tensor: the A-operand planes of a GEMM), `T` (uint8: the weight gradient's operand
-    planes), `E` (int32 [N / seg, M]: exponents per column segment and row); R or T may be None.  include/rqhip.h (rqhip_img)."""
-    __slots__ = ("R", "T", "E", "M", "N", "seg")
-
-    def __init__(self, M: int, N: int, device, want_r: bool = True, want_t: bool = True):
-        l = _lib.lib()
-        if not l.rqhip_img_supported(int(N)):
-            raise RqHipError(f"Img: {N} columns are not a multiple of 128")
-        self.M, self.N, self.seg = int(M), int(N), int(l.rqhip_img_seg(int(N)))
-        with torch.cuda.device(device):
-            self.R = torch.empty((max(l.rqhip_img_r_bytes(M, N), 16),), dtype=torch.uint8, device=device) if want_r else None
-            self.T = torch.empty((max(l.rqhip_img_t_bytes(M, N), 16),), dtype=torch.uint8, device=device) if want_t else None
-            self.E = torch.empty((N // self.seg, M), dtype=torch.int32, device=device)
-
-    def c(self) -> "_lib.ImgC":
-        return _lib.ImgC(_ptr(self.R), _ptr(self.T), _ptr(self.E), self.M, self.N, self.seg)
-
-    @property
-    def device(self):
-        return self.E.device
-
-
-def _img_none() -> "_lib.ImgC":
-    return _lib.ImgC(None, None, None, 0, 0, 0)
-
-
-def img_supported(n: int) -> bool:
-    return bool(_lib.lib().rqhip_img_supported(int(n)))
-
-
-def gemm_img_supported(n_cols: int, n_red: int) -> bool:
-    return bool(_lib.lib().rqhip_gemm_img_supported(int(n_cols), int(n_red))) and n_red <= 2048
-
-
-def img_pack(a: Tensor, y: Optional[Tensor] = None, *, want_r: bool = True, want_t: bool = True, write_masked: bool = False,
-             run_flag: Optional[Tensor] = None):
-    """(image of a [M, N], masked or None) (rqhip_img_pack).  With y: of `a` masked by y > 0 (the ReLU backward), returned as `masked`
-    when `write_masked`."""
-    _need_gpu(a, y, run_flag)
-    a, y = _f32c(a, "a"), _f32c(y, "y")
-    M, N = a.shape
-    if y is not None and y.shape != a.shape:
-        raise RqHipError(f"img_pack: y is {tuple(y.shape)}, expected {tuple(a.shape)}")
-    img = Img(M, N, a.device, want_r, want_t)
-    with torch.cuda.device(a.device):
-        out = torch.empty_like(a) if (write_masked and y is not None) else None
-        c = img.c()
-        check(_lib.lib().rqhip_img_pack(_ptr(a), _ptr(y), _ptr(out), M, N, c, _ptr(run_flag), _stream()), "rqhip_img_pack")
-    return img, out
-
-
-def img_unpack(img: Img, from_t: bool = False) -> Tensor:
-    """The fp32 values an image stands for, (h + m) 2^E (rqhip_img_unpack): from its R planes, or from its T planes."""
-    with torch.cuda.device(img.device):
-        out = torch.empty((img.M, img.N), dtype=torch.float32, device=img.device)
-        c = img.c()
-        check(_lib.lib().rqhip_img_unpack(c, int(bool(from_t)), _ptr(out), _stream()), "rqhip_img_unpack")
-    return out
-
-
-def rows_differ(g_out: Tensor, announced: float, flag: Optional[Tensor] = None) -> Tensor:
-    """int32 [1] device flag: 1 when some g_out[m] is not `announced` (bit compare), else 0 (rqhip_rows_differ)."""
-    _need_gpu(g_out)
-    g_out = _f32c(g_out, "g_out")
-    with torch.cuda.device(g_out.device):
-        flag = flag if flag is not None else torch.empty((1,), dtype=torch.int32, device=g_out.device)
-        check(_lib.lib().rqhip_rows_differ(_ptr(g_out), g_out.numel(), float(announced), _ptr(flag), _stream()), "rqhip_rows_differ")
-    return flag
-
-
-def gemm_img(a: Img, image: Tensor, n_cols: int, *, epilogue: int = _lib.EPI_STORE, want_c: bool = False, want_r: bool = False,
-             want_t: bool = False, aux: Optional[Tensor] = None, y: Optional[Img] = None, row_scale: float = 0.0,
-             row_scales: Optional[Tensor] = None, run_flag: Optional[Tensor] = None, out: Optional[Img] = None,
-             c_out: Optional[Tensor] = None, loss_out: Optional[Tensor] = None, xcd_queues: bool = False):
-    """epilogue(a . image^T) from the image `a` (rqhip_gemm_img).  Returns (C fp32 [M, n_cols] or None, image of C or None, loss_rows
-    or None).  `out` / `c_out` / `loss_out`: buffers of an earlier call to write into again (the conditional re-run of the
-    reconstruction epilogue under `run_flag`)."""
-    _need_gpu(image, aux, row_scales, run_flag)
-    M = a.M
-    dev = a.device
-    if aux is not None:
-        aux = _f32c(aux, "aux")
-        if tuple(aux.shape) != (M, n_cols):
-            raise RqHipError(f"gemm_img: aux is {tuple(aux.shape)}, expected {(M, n_cols)}")
-    with torch.cuda.device(dev):
-        l = _lib.lib()
-        c = c_out if c_out is not None else (torch.empty((M, n_cols), dtype=torch.float32, device=dev) if want_c else None)
-        o = out if out is not None else (Img(M, n_cols, dev, want_r, want_t) if (want_r or want_t) else None)
-        args = _lib.GemmImgArgs()
-        args.A, args.image, args.Nc, args.epilogue = a.c(), image.data_ptr(), int(n_cols), int(epilogue)
-        args.C = _ptr(c)
-        args.out = o.c() if o is not None else _img_none()
-        args.aux = _ptr(aux)
-        args.Y = y.c() if y is not None else _img_none()
-        args.row_scale, args.row_scales = float(row_scale), _ptr(row_scales)
-        loss_rows = ws = None
-        if epilogue == _lib.EPI_RECON:
-            loss_rows = loss_out if loss_out is not None else torch.empty((M,), dtype=torch.float32, device=dev)
-            wsb = l.rqhip_gemm_split_recon_workspace_bytes(M, int(n_cols))
-            ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-            args.loss_rows, args.workspace, args.workspace_bytes = loss_rows.data_ptr(), ws.data_ptr(), wsb
-        args.run_flag, args.xcd_queues = _ptr(run_flag), int(bool(xcd_queues))
-        check(l.rqhip_gemm_img(args, _stream()), "rqhip_gemm_img")
-    return c, o, loss_rows
-
-
-def linear_wgrad_img(g: Img, x: Img, *, out: Optional[Tensor] = None, run_flag: Optional[Tensor] = None) -> Tensor:
-    """dW [N, K] = g^T x from the T planes of the images of g [M, N] and x [M, K] (rqhip_linear_wgrad_img)."""
-    if g.M != x.M or g.T is None or x.T is None:
-        raise RqHipError("linear_wgrad_img: images of the same M with T planes")
-    M, N, K = g.M, g.N, x.N
-    dev = g.device
-    with torch.cuda.device(dev):
-        l = _lib.lib()
-        if out is not None and (tuple(out.shape) != (N, K) or out.dtype != torch.float32 or not out.is_contiguous()):
-            raise RqHipError("linear_wgrad_img: `out` must be a contiguous float32 [N,K] tensor")
-        dw = out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
-        wsb = l.rqhip_linear_wgrad_workspace_bytes(M, N, K)
-        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-        check(l.rqhip_linear_wgrad_img(g.c(), x.c(), _ptr(dw), _ptr(ws), wsb, _ptr(run_flag), _stream()), "rqhip_linear_wgrad_img")
-    return dw
-
-
 def gemm_split_supported(n_cols: int, n_red: int) -> bool:
     return bool(_lib.lib().rqhip_gemm_split_supported(int(n_cols), int(n_red)))
 

@@ -1,6 +1,7 @@
 """The error bound of the block-scaled two-piece fp16 arithmetic of the MLP GEMMs, as a test (CPU).
 
-csrc/gemm_img.hip (and csrc/gemm_split.hip's RQHIP_SPLIT_F16X2 path: the same arithmetic under whole-row scales) replaces an fp32
+csrc/gemm_split.hip's RQHIP_SPLIT_F16X2 path (the product: ONE block per row -- the whole row) and round 5's image experiment
+(tools/experiments/gemm_img_r05.hip: one block per 256-column segment, accumulators rescaled at block boundaries) replace an fp32
 product sum  sum_k a_k b_k  by
 
     sum_k (ah_k bh_k + ah_k bm_k + am_k bh_k) 2^(Ea(k) + Eb),     a_k 2^-Ea = ah_k + am_k + ra_k   (fp16 pieces, ra the remainder),
@@ -30,13 +31,13 @@ TOP = 14   # the block maximum is scaled into [2^TOP, 2^(TOP+1))
 
 
 def exp_of_max(mx):
-    """exponent E of a block whose largest |value| is mx > 0 (finite): mx 2^-E in [2^14, 2^15)  (csrc/gemm_img.hip:gi_exp_of_bits)"""
+    """exponent E of a block whose largest |value| is mx > 0 (finite): mx 2^-E in [2^14, 2^15)  (csrc/gemm_split.hip:gs_exp_of_bits)"""
     m, e = np.frexp(np.float32(mx))          # mx = m 2^e, m in [0.5, 1)
     return int(e) - 1 - TOP
 
 
 def split(v, E):
-    """(h, m) as float64 arrays: h = RN16(v 2^-E), m = RN16(v 2^-E - h)  (csrc/gemm_img.hip:gi_split2; v 2^-E is exact in fp32)"""
+    """(h, m) as float64 arrays: h = RN16(v 2^-E), m = RN16(v 2^-E - h)  (csrc/gemm_split.hip:gs_split2_f16; v 2^-E is exact in fp32)"""
     a = np.ldexp(np.asarray(v, np.float32), -E).astype(np.float32)
     h = a.astype(np.float16)
     m = (a - h.astype(np.float32)).astype(np.float16)          # a - h is exact in fp32
