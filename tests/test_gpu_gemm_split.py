@@ -219,7 +219,8 @@ def test_maxima_wide_rows_and_wide_mlp_layer(R):
     out.backward(gy)
     ref = torch.relu(x.detach().double() @ w.detach().double().t())
     assert (out.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
-    gm = torch.where(ref > 0, gy.double(), torch.zeros_like(ref))
+    # (the mask of the layer's OWN output: an output that is 1e-9 in fp64 and 0 in fp32 would flip a whole term of the references)
+    gm = torch.where(out.detach() > 0, gy.double(), torch.zeros_like(ref))
     gw, gx = gm.t() @ x.detach().double(), gm @ w.detach().double()
     assert (w.grad.double() - gw).abs().max().item() <= 2e-6 * gw.abs().max().item()
     assert (x.grad.double() - gx).abs().max().item() <= 2e-6 * gx.abs().max().item()
