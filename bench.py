@@ -87,6 +87,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="rows per rank per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-input-scales", action="store_true", help="A/B: run the maxima pass over the input batch inside every step (round 4) instead of "
+                                                                   "taking the rows' maxima from the resident corpus (data/processed.py)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip secondary.small_batch (a subprocess: batch 640 / batch 64 steps, eager and hipGraph)")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
@@ -348,6 +350,13 @@ def main():
     reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
     batches = [SeqBatch(None, None, None, X[lo:min(B, lo + micro)], None, None) for lo in range(0, B, micro)]
     n_micro = len(batches)
+    # The largest |value| of an item's row is a property of the item: the resident item matrix holds it (data/processed.py computes it once
+    # per corpus and hands it out with every batch >= 4096 rows), so the step does not run a maxima pass over its input batch.  Done here
+    # once for the resident synthetic corpus X, exactly as ItemData.__getitem__ does.  --no-input-scales: the pass inside every step (round 4).
+    if not args.no_input_scales and args.mlp == "split" and micro >= 4096:
+        x_rows, x_cols, _ = ops.maxima(X)
+        for bi, lo in enumerate(range(0, B, micro)):
+            _lin.attach_scales(batches[bi].x, x_rows[:, lo:min(B, lo + micro)].contiguous(), x_cols)
 
     def step():
         reducer.zero_()
@@ -717,6 +726,10 @@ def main():
                           + (" (128 (mod 256) on the library: --no-narrow)" if args.no_narrow else "")
                           + "; the 32-wide layers: PyTorch-ROCm fp32 GEMMs (matmul precision highest), TunableOp selections "
                           + ("loaded" if tuned else "off")),
+            "input_scales": ("the per-row maxima the fp16-split GEMMs scale by come with the resident item matrix (computed once per corpus, "
+                             "data/processed.py:ItemData._corpus_maxima; the first layer's weight gradient uses corpus-wide column bounds): no maxima "
+                             "pass over the input batch inside the step" if (not args.no_input_scales and args.mlp == "split" and micro >= 4096)
+                             else "a maxima pass over the input batch inside every step (round 4; --no-input-scales)"),
             "final_loss": round(final_loss, 6), "p_unique_ids": round(p_unique, 6),
             "librqhip_sha256": lib_sha,
         }

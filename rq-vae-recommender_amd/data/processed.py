@@ -88,11 +88,32 @@ class ItemData(Dataset):
         else:
             raise ValueError(f"unknown train_test_split {train_test_split!r}")
         self.item_data = item_matrix if keep is None else item_matrix[keep.to(item_matrix.device)]
+        self._row_max = self._col_max = None
 
     def to_device(self, device) -> "ItemData":
         """Make the feature matrix resident on `device` (HBM); later `ds[idx]` gathers happen there."""
         self.item_data = self.item_data.to(device)
+        self._row_max = self._col_max = None
         return self
+
+    # batches of this many rows and more run the MLPs' fp16-split kernels, which scale every row by its largest |value|
+    # (rqhip/linear.py:_SPLIT_MIN_ROWS): that maximum is a property of the item, computed once per corpus and gathered with the batch
+    _SCALES_MIN_ROWS = 4096
+
+    def _corpus_maxima(self):
+        """(row maxima int32 [N], column maxima int32 [768]) of the resident matrix's feature columns, bit patterns (rqhip_maxima)."""
+        if getattr(self, "_row_max", None) is None:
+            from rqhip import ops
+            x = self.item_data
+            n, step = x.shape[0], 1 << 20
+            rows, cols = [], None
+            for lo in range(0, n, step):
+                part = x[lo:lo + step, :FEATURE_DIM]
+                r, c, _ = ops.maxima(part if part.is_contiguous() else part.contiguous())
+                rows.append(r[0])
+                cols = c if cols is None else torch.maximum(cols, c)       # (bit patterns of non-negative floats order like integers)
+            self._row_max, self._col_max = torch.cat(rows), cols
+        return self._row_max, self._col_max
 
     def __len__(self) -> int:
         return self.item_data.shape[0]
@@ -102,5 +123,11 @@ class ItemData(Dataset):
         item_ids = idx.to(dev) if isinstance(idx, Tensor) else torch.tensor(idx, device=dev).unsqueeze(0)
         rows = idx.to(dev) if isinstance(idx, Tensor) else idx
         minus_one = -1 * torch.ones_like(item_ids.squeeze(0))
-        return SeqBatch(user_ids=minus_one, ids=item_ids, ids_fut=minus_one, x=self.item_data[rows, :FEATURE_DIM],
+        x = self.item_data[rows, :FEATURE_DIM]
+        if (x.is_cuda and isinstance(rows, Tensor) and rows.dim() == 1 and rows.numel() >= self._SCALES_MIN_ROWS
+                and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
+            from rqhip import linear as _lin
+            rm, cm = self._corpus_maxima()
+            _lin.attach_scales(x, rm[rows].unsqueeze(0), cm)    # the rows' maxima travel with the rows; corpus-wide column bounds
+        return SeqBatch(user_ids=minus_one, ids=item_ids, ids_fut=minus_one, x=x,
                         x_fut=minus_one, seq_mask=torch.ones_like(item_ids, dtype=torch.bool))

@@ -91,6 +91,7 @@ class _MLPStack(torch.autograd.Function):
         from rqhip import _lib
         from rqhip import autograd as _ag
         n, M = len(weights), x.shape[0]
+        given = _lin.take_scales()          # maxima that came with the input (rqhip/linear.py:attach_scales), or None
         need_w = [bool(f) for f in ctx.needs_input_grad[4:]]
         need_in = [bool(ctx.needs_input_grad[0]) or any(need_w[:i]) for i in range(n)]   # gradient wrt layer i's input wanted
         fwd_split = [_lin.split_shape_ok(M, w.shape[0], w.shape[1]) for w in weights]
@@ -107,8 +108,8 @@ class _MLPStack(torch.autograd.Function):
                 for i in range(n)]
         arena = torch.zeros((sum(w.shape[0] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=x.device) if any(emit) else None
         off = 0
-        acts, scs = [x], [_lin.Scales()]
-        if f16 and (fwd_split[0] or wg_f16[0]):   # the input batch: the one maxima pass of the step
+        acts, scs = [x], [given if given is not None else _lin.Scales()]
+        if f16 and (fwd_split[0] or wg_f16[0]):   # the input batch: the one maxima pass of the step -- unless its maxima came with it
             _lin.ensure_scales(x, scs[0], fwd_split[0], wg_f16[0])
         out = g_recon = g_scales = None
         for i, w in enumerate(weights):
@@ -241,6 +242,7 @@ class MLP(nn.Module):
             relus.append(relu)
             i += 2 if relu else 1
         if weights:
+            _lin.handoff_scales(_lin.attached_scales(x))
             x = _MLPStack.apply(x, target, tuple(relus), self._zero_bias, *weights)
         return self._run_layerwise(x, layers[i:]) if i < len(layers) else x
 

@@ -86,6 +86,42 @@ class Scales:
         self.rows, self.cols = rows, cols
 
 
+# ---- maxima that come with the data ----------------------------------------------------------------------------------------------
+# The largest |value| of an item's feature row is a property of the ITEM: the HBM-resident item matrix (data/processed.py:ItemData)
+# computes it once per corpus and hands it out with every batch it gathers (`attach_scales`), and the stack that reads the batch takes
+# it from there instead of running rqhip_maxima over the batch again (82 us of a 2.86 ms step at 100 000 x 768).  The column maxima the
+# first layer's weight gradient wants are replaced by the corpus-wide ones, an upper bound for every batch (costs low-order bits of
+# entries more than 2^16 below their column's corpus maximum only; same rule as a masked gradient under unmasked maxima).
+def attach_scales(t: Tensor, rows: Optional[Tensor], cols: Optional[Tensor]) -> Tensor:
+    """Remember on the tensor OBJECT `t` [M, N] the bit patterns of its row maxima (`rows`: int32 [1, M]) and of (upper bounds of)
+    its column maxima (`cols`: int32 [N]); views / copies of `t` do not inherit them."""
+    t._rq_scales = Scales(rows, cols)
+    return t
+
+
+def attached_scales(t: Tensor) -> Optional[Scales]:
+    sc = getattr(t, "_rq_scales", None)
+    if sc is None:
+        return None
+    ok_r = sc.rows is None or (sc.rows.dtype == torch.int32 and tuple(sc.rows.shape) == (1, t.shape[0]) and sc.rows.device == t.device)
+    ok_c = sc.cols is None or (sc.cols.dtype == torch.int32 and tuple(sc.cols.shape) == (t.shape[1],) and sc.cols.device == t.device)
+    return Scales(sc.rows if ok_r else None, sc.cols if ok_c else None)
+
+
+_HANDOFF: List[Optional[Scales]] = [None]
+
+
+def handoff_scales(sc: Optional[Scales]) -> None:
+    """The scales of the tensor the NEXT `_MLPStack.apply` receives as its input (set by MLP._run right before the call, taken by the
+    node's forward: an autograd Function may be handed an alias of the caller's tensor object, attributes do not survive that)."""
+    _HANDOFF[0] = sc
+
+
+def take_scales() -> Optional[Scales]:
+    sc, _HANDOFF[0] = _HANDOFF[0], None
+    return sc
+
+
 def ensure_scales(a: Tensor, sc: Optional[Scales], rows: bool, cols: bool) -> Scales:
     """`sc` with the requested maxima present: what is missing is computed by ONE pass over `a` (rqhip_maxima)."""
     sc = sc if sc is not None else Scales()

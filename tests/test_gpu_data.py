@@ -83,3 +83,51 @@ def test_ten_million_item_matrix_stays_resident_and_tokenises():
     assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
     del X, ds, b
     torch.cuda.empty_cache()
+
+
+def test_corpus_maxima_travel_with_big_batches_and_replace_the_input_pass():
+    """data/processed.py: batches of >= 4096 rows carry their rows' maxima (gathered from the once-per-corpus pass) and corpus-wide column
+    bounds (rqhip/linear.py:attach_scales); the encoder then runs no maxima pass over its input: same row exponents -> the forward has the
+    bits of the plain path, the first layer's weight gradient (column bounds instead of the batch's column maxima) stays inside the gate."""
+    from data.processed import ItemData, synthetic_item_matrix
+    from modules.encoder import MLP
+    from rqhip import linear as lin
+    from rqhip import ops
+    ds = ItemData("unused", item_matrix=torch.cat([synthetic_item_matrix(20_000) * torch.logspace(-3, 3, 20_000)[:, None],
+                                                   torch.zeros(20_000, 3)], dim=1)).to_device("cuda")     # 771 columns: features = the first 768
+    idx = torch.randperm(20_000)[:6000]
+    b = ds[idx]
+    sc = lin.attached_scales(b.x)
+    assert sc is not None and tuple(sc.rows.shape) == (1, 6000) and tuple(sc.cols.shape) == (768,)
+    assert torch.equal(sc.rows[0].view(torch.float32), b.x.abs().amax(dim=1))
+    assert (sc.cols.view(torch.float32) >= b.x.abs().amax(dim=0)).all()
+    assert lin.attached_scales(ds[idx[:100]].x) is None                     # small batches do not take the fp16 path: nothing attached
+    torch.manual_seed(2)
+    mlp = MLP(768, [512, 256, 128], 32).cuda()
+    gout = torch.randn(6000, 32, device="cuda")
+    calls = []
+    real = ops.maxima
+
+    def counting(a, *args, **kw):
+        calls.append(tuple(a.shape))
+        return real(a, *args, **kw)
+
+    res = []
+    for x in (b.x, b.x.clone()):                                           # with the attached maxima / without (a clone carries none)
+        for p in mlp.parameters():
+            p.grad = None
+        calls.clear()
+        ops.maxima = counting
+        try:
+            y = mlp(x)
+            y.backward(gout)
+        finally:
+            ops.maxima = real
+        res.append((y.detach().clone(), [p.grad.clone() for p in mlp.parameters()], list(calls)))
+    (y1, g1, c1), (y2, g2, c2) = res
+    assert (6000, 768) not in c1 and (6000, 768) in c2                     # the pass over the input batch is gone
+    assert torch.equal(y1, y2)                                             # same row exponents, same bits
+    for a, bb in zip(g1[1:], g2[1:]):
+        assert torch.equal(a, bb)
+    ref = g2[0].double()
+    assert (g1[0].double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()     # first layer: column bounds instead of maxima
