@@ -89,6 +89,7 @@ def parse_args():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-input-scales", action="store_true", help="A/B: run the maxima pass over the input batch inside every step (round 4) instead of "
                                                                    "taking the rows' maxima from the resident corpus (data/processed.py)")
+    ap.add_argument("--torch-adamw", action="store_true", help="A/B: torch.optim.AdamW(fused=True) instead of rqhip.optim.FlatAdamW")
     ap.add_argument("--no-small-batch", action="store_true", help="skip secondary.small_batch (a subprocess: batch 640 / batch 64 steps, eager and hipGraph)")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
@@ -346,7 +347,9 @@ def main():
         X[lo:hi] = torch.nn.functional.normalize(torch.randn(hi - lo, INPUT_DIM, generator=g), dim=-1).to(device)
     model, kmeans_s = build_model(device, X[: min(20000, B)], LEVELS, CODES)
     rqdist.broadcast_module(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)  # one multi-tensor kernel
+    from rqhip.optim import FlatAdamW
+    opt = (torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True) if args.torch_adamw     # (A/B: torch's fused kernel)
+           else FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4))     # the same update, one launch over all parameters (csrc/adamw.hip)
     reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
     batches = [SeqBatch(None, None, None, X[lo:min(B, lo + micro)], None, None) for lo in range(0, B, micro)]
     n_micro = len(batches)

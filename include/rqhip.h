@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 410 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 420 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -403,6 +403,15 @@ int rqhip_recon_rescale_rows(const float *g_out, int64_t B, int N, float row_sca
  * (the row's new maximum in part 0, the other parts cleared) and col_max [N] (maxed into); either may be NULL */
 int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_scale, float *g_spec, unsigned *row_max,
                                 int row_parts, unsigned *col_max, rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The AdamW update of all parameters in one launch (reference train_rqvae.py:136-138: AdamW with decoupled weight decay on every
+ * parameter, codebooks included).  Arithmetic of torch's `_fused_adamw_` in fp32 (no amsgrad, no maximize); tensors p / g / m / v of
+ * numel[i] contiguous fp32 elements, 16-byte aligned, caller-owned; `step`: device float scalar = steps taken so far, incremented by
+ * the call (on the device, so a captured hipGraph advances it on replay); `scratch`: one device word, zero between calls. */
+int rqhip_adamw_step(float *const *p, const float *const *g, float *const *m, float *const *v, const int64_t *numel, int n,
+                     float *step, unsigned *scratch, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline objects (no reference counterpart).  While enabled, the calls below bracket

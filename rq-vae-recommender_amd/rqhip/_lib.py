@@ -100,6 +100,7 @@ SIGNATURES = {
     "rqhip_gemm_split_recon": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_recon_rescale_rows": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
     "rqhip_recon_rescale_rows_ex": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _int, _vp, _vp]),
+    "rqhip_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_select": (_int, [C.c_uint]),
     "rqhip_profile_read": (_int, [C.POINTER(_f32), _int, C.POINTER(_int)]),

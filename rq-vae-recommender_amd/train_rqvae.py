@@ -32,7 +32,7 @@ from typing import List
 
 import numpy as np
 import torch
-from torch.optim import AdamW
+from rqhip.optim import FlatAdamW
 
 from data.processed import ItemData, RecDataset
 from modules.quantize import QuantizeForwardMode
@@ -244,8 +244,9 @@ def train(
     import torch.distributed as _dist
     capturable_comm = world == 1 or (_dist.is_initialized() and _dist.get_backend() == "nccl")
     graphable = ((batch_size < 4096 and capturable_comm) if use_hip_graph is None else bool(use_hip_graph)) and gradient_accumulate_every == 1
-    optimizer = AdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay, fused=True,
-                      capturable=graphable)  # same update as the reference's AdamW, one multi-tensor kernel
+    # the reference's AdamW update (train_rqvae.py:136-138) as ONE kernel over all parameters (rqhip/optim.py, csrc/adamw.hip; the state
+    # dict is torch.optim.AdamW's, so checkpoints interchange); graph-safe by construction
+    optimizer = FlatAdamW(params=model.parameters(), lr=learning_rate, weight_decay=weight_decay)
 
     use_wandb = wandb_logging and is_main and _HAVE_WANDB
     if wandb_logging and is_main and not _HAVE_WANDB:

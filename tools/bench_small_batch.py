@@ -43,8 +43,8 @@ def run(c3: bool, B: int, say=print):
     with torch.no_grad():
         for l, layer in enumerate(m.layers):
             layer.embedding.weight.copy_(torch.randn_like(layer.embedding.weight) * (0.05 / (l + 1)))
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4 if c3 else 1e-3, weight_decay=0.01 if c3 else 1e-4, fused=True,
-                            capturable=True)
+    from rqhip.optim import FlatAdamW
+    opt = FlatAdamW(m.parameters(), lr=1e-4 if c3 else 1e-3, weight_decay=0.01 if c3 else 1e-4)     # as train_rqvae.py
     x = torch.nn.functional.normalize(torch.randn(B, 768, device="cuda"), dim=-1)
     batch = SeqBatch(None, None, None, x, None, None)
 
