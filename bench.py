@@ -376,15 +376,20 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    n_fam = steps * n_micro * 26 + 64
+    # the timed region records the kernels that ARE the step -- the MLP GEMM / weight-gradient family -- in its FIRST n_rec steps only:
+    # ~21 event pairs per step cost 5 % of a 2.8 ms step (K-step 2.90 ms vs 2.76 ms unrecorded, profiles/r05_bench_n1.json's long_run)
+    n_rec = min(steps, 4)
+    n_fam = n_rec * n_micro * 26 + 64
     ops.profile_enable(n_fam)
-    ops.profile_select("gemm_split", "wgrad")   # the timed region records the kernels that ARE the step: the MLP GEMM / weight-gradient family
+    ops.profile_select("gemm_split", "wgrad")
     if world > 1:
         reducer.enable_timing()
     rqdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for si in range(steps):
+        if si == n_rec:
+            ops.profile_select("none")      # (a host-side flag: no further records, no synchronisation)
         out = step()
     torch.cuda.synchronize()
     rqdist.barrier()
@@ -619,7 +624,7 @@ def main():
             dk, dfl, dby = dom_key
             dmean = float(np.mean(fam[dom_key]))
             dom = {"kernel": {"gemm_split": "gemm_f16_kernel", "wgrad": "wgrad_split_kernel"}.get(dk, dk),
-                   "launches_per_step": round(len(fam[dom_key]) / steps, 2), "launch_ms_mean": round(dmean, 5),
+                   "launches_per_step": round(len(fam[dom_key]) / n_rec, 2), "launch_ms_mean": round(dmean, 5),
                    "algorithmic_gflop_per_launch": round(dfl / 1e9, 3), "algorithmic_mb_per_launch": round(dby / 1e6, 2),
                    "issued_tflops": round(issued_mult * dfl / (dmean * 1e-3) / 1e12, 1),
                    "frac": round(issued_mult * dfl / (dmean * 1e-3) / 1e12 / issued_peak, 4), "traffic": None, "traffic_ratio": None}
@@ -631,16 +636,17 @@ def main():
                     dom["traffic_ratio"] = round(max(cand) / dby, 3) if dby else None
         roofline_family = {
             "kernel": ("MLP matrix-kernel family: gemm_f16_kernel / gemm_split_kernel (activation GEMMs with ReLU / mask / reconstruction-"
-                       "loss epilogues) + wgrad_split_kernel (weight gradients), " f"{round(fam_launches / max(steps, 1), 1)} launches per step"
+                       "loss epilogues) + wgrad_split_kernel (weight gradients), " f"{round(fam_launches / max(n_rec, 1), 1)} launches per step"
                        if args.mlp != "library" else "library fp32 GEMMs are not recorded; fp32-MFMA weight gradients only"),
             "bound": "mfma",
             "achieved": round(issued_mult * fam_alg, 2), "peak": issued_peak, "unit": "TFLOP/s",
             "frac": round(issued_mult * fam_alg / issued_peak, 4),
             "frac_kind": f"ISSUED matrix-instruction FLOPs ({issued_mult:g} fp16 piece products per fp32 product) / time of the family's launches "
-                         "in the timed region (HIP events on the launch stream) / dense fp16 MFMA peak",
+                         f"in the first {n_rec} steps of the timed region (HIP events on the launch stream) / dense fp16 MFMA peak",
             "algorithmic_tflops": round(fam_alg, 2), "algorithmic_frac_of_issued_peak": round(fam_alg / issued_peak, 4),
             "algorithmic_frac_of_fp32_peak": round(fam_alg / PEAK_FP32_MFMA_TFLOPS, 4),
-            "family_ms_per_step": round(fam_ms / max(steps, 1), 4), "share_of_step": round(fam_ms / max(steps, 1) / ms_per_step, 3),
+            "family_ms_per_step": round(fam_ms / max(n_rec, 1), 4), "share_of_step": round(fam_ms / max(n_rec, 1) / ms_per_step, 3),
+            "recorded_steps": n_rec,
             "launches": fam_launches,
             "traffic": dom["traffic"] if dom else None,
             "traffic_source": (traffic_src if (dom and dom["traffic"]) else "null: no PMC passes for this build (tools/profile_bench.sh)")

@@ -273,6 +273,9 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
     // PMC 2 * FETCH_SIZE + WRITE_SIZE = 1 266 MB per launch against 512 MB algorithmic (2.5 x), 5.1 TB/s: the kernel was running
     // at the fabric's limit on re-reads (profiles/r04_pmc_traffic_c2.json).  40 ranges leave 16 of 256 CUs idle and win.
     if (ms >= 8) ms &= ~7LL;
+    // at least four 32-row granules per range: at batch 640 twenty 32-row ranges made the reduction of their partial blocks (31 MB for a
+    // 512 x 768 layer, 19.6 us) cost more than the weight-gradient kernel itself (16 us); five 128-row ranges: 8 MB
+    if (ms > chunks / 4) ms = chunks / 4 > 0 ? chunks / 4 : 1;
     if (ms > chunks) ms = chunks > 0 ? chunks : 1;
     pl.msplit = (int)ms;
     pl.pow2 = 1;

@@ -384,6 +384,9 @@ def profile_select(*kinds: str) -> None:
     """Record only launches of these kinds (names of _lib.PROF_TAGS); no argument = every kind."""
     mask = 0
     for k in kinds:
+        if k == "none":          # record nothing until the next select
+            check(_lib.lib().rqhip_profile_select(0), "rqhip_profile_select")
+            return
         mask |= 1 << next(t for t, n in _lib.PROF_TAGS.items() if n == k)
     check(_lib.lib().rqhip_profile_select(mask if kinds else 0xFFFFFFFF), "rqhip_profile_select")
 

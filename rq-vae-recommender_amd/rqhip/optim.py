@@ -91,6 +91,15 @@ class FlatAdamW(torch.optim.Optimizer):
                                          torch.cuda.current_stream().cuda_stream), "rqhip_adamw_step")
         return loss
 
+    def state_dict(self):
+        """torch.optim.AdamW's format.  Every parameter gets its OWN copy of the step counter: the live one is shared by the group, and a
+        torch AdamW that loaded aliased counters would advance the shared tensor once per parameter."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone()
+        return sd
+
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
         self._steps, self._cache = {}, {}
