@@ -408,7 +408,7 @@ int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_
  * The AdamW update of all parameters in one launch (reference train_rqvae.py:136-138: AdamW with decoupled weight decay on every
  * parameter, codebooks included).  Arithmetic of torch's `_fused_adamw_` in fp32 (no amsgrad, no maximize); tensors p / g / m / v of
  * numel[i] contiguous fp32 elements, 16-byte aligned, caller-owned; `step`: device float scalar = steps taken so far, incremented by
- * the call (on the device, so a captured hipGraph advances it on replay); `scratch`: one device word, zero between calls. */
+ * the call (on the device, so a captured hipGraph advances it on replay); `scratch`: 8 device bytes (8-byte aligned) the call may overwrite. */
 int rqhip_adamw_step(float *const *p, const float *const *g, float *const *m, float *const *v, const int64_t *numel, int n,
                      float *step, unsigned *scratch, float lr, float beta1, float beta2, float eps, float weight_decay,
                      rqhip_stream_t stream);

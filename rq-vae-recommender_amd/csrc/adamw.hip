@@ -4,8 +4,8 @@
 //
 // Why not torch's fused AdamW: its multi-tensor kernel hands 64 K-element chunks to workgroups -- 1.15 M parameters are 18 chunks, 18 of
 // 256 CUs work, 40-46 us per step at every batch size (11 % of the 0.35 ms hipGraph step at batch 640, 1.6 % at 100 000 rows), plus a
-// second launch that increments the per-parameter step counters.  Here: 1024 elements per workgroup (1 100 workgroups), the step counter
-// (a device scalar, so a captured hipGraph advances it on replay) read by everyone and incremented by the LAST workgroup to finish.
+// second launch that increments the per-parameter step counters.  Here: 1024 elements per workgroup (1 100 workgroups); the step counter is a
+// device scalar (so a captured hipGraph advances it on replay), bumped by a one-thread kernel that also forms the bias corrections.
 // The arithmetic is torch's `_fused_adamw_` (aten/src/ATen/native/cuda/fused_adam_utils.cuh, ADAMW mode, no amsgrad, no maximize), in fp32:
 //     p  -= lr wd p
 //     m   = lerp(m, g, 1 - b1)              (= m + (1 - b1) (g - m) for 1 - b1 < 0.5)
@@ -34,15 +34,28 @@ struct AdamwJobs {
     int n;
 };
 
-__global__ __launch_bounds__(256) void adamw_kernel(const AdamwJobs jobs, float *__restrict__ step, unsigned *__restrict__ departed, int last_launch,
-                                                    float lr, float beta1, float beta2, float eps, float wd) {
+// step += 1 and the scalars every element needs, once per step, by one thread -- so that the update kernel only READS them (a first version
+// let every workgroup read the counter and the last one to finish bump it: 1 100 returning atomics on one word are 13 us by themselves, and
+// every thread evaluated two powf)
+struct AdamwScalars {
+    float step_size, bc2_sqrt;
+};
+__global__ void adamw_bump_kernel(float *__restrict__ step, AdamwScalars *__restrict__ sc, float lr, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float t = step[0] + 1.0f;
+    step[0] = t;
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+    sc->step_size = lr / bc1;
+    sc->bc2_sqrt = sqrtf(bc2);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamwJobs jobs, const AdamwScalars *__restrict__ sc, float lr, float beta1, float beta2,
+                                                    float eps, float wd) {
     AdamwJob job = jobs.j[0];
 #pragma unroll
     for (int i = 1; i < kAwMaxJobs; ++i)
         if (i < jobs.n && (int)blockIdx.x >= jobs.j[i].block0) job = jobs.j[i];
-    const float t = step[0] + 1.0f;
-    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    const float step_size = sc->step_size, bc2_sqrt = sc->bc2_sqrt;
     const long long i0 = ((long long)((int)blockIdx.x - job.block0) * 256 + threadIdx.x) * 4;
     auto one = [&](float &p, float &m, float &v, float g) {
         p = p - (lr * wd) * p;
@@ -67,19 +80,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamwJobs jobs, float 
     } else {
         for (long long i = i0; i < job.n; ++i) one(job.p[i], job.m[i], job.v[i], job.g[i]);
     }
-    // the last workgroup of the LAST launch of this step advances the counter (every workgroup has read it by then) and re-arms
-    if (last_launch) {
-        __shared__ unsigned s_last;
-        __syncthreads();
-        // (no fence: the count only says "this workgroup has READ the counter" -- it did so before its first arithmetic instruction; a
-        // __threadfence() here, an L2 write-back + invalidate per workgroup, made the first version of this kernel take 49 us instead of ~8)
-        if (threadIdx.x == 0) s_last = atomicAdd(departed, 1u);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_last == gridDim.x - 1) {
-            *departed = 0u;
-            step[0] = t;
-        }
-    }
 }
 
 }  // namespace rqhip
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamwJobs jobs, float 
 using namespace rqhip;
 
 // One AdamW step over n tensors: p[i] (updated in place), g[i], m[i], v[i] of numel[i] fp32 elements each (16-byte aligned, contiguous).
-// `step`: device float scalar, the number of steps taken so far (incremented by the call); `scratch`: a device word, zero between calls.
+// `step`: device float scalar, the number of steps taken so far (incremented by the call); `scratch`: 8 device bytes the call may overwrite.
 extern "C" int rqhip_adamw_step(float *const *p, const float *const *g, float *const *m, float *const *v, const int64_t *numel, int n,
                                 float *step, unsigned *scratch, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 rqhip_stream_t stream) {
@@ -97,10 +97,11 @@ extern "C" int rqhip_adamw_step(float *const *p, const float *const *g, float *c
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    // launches of at most kAwMaxJobs tensors; every launch but the last leaves the counter alone (they all must read the same step)
+    AdamwScalars *sc = reinterpret_cast<AdamwScalars *>(scratch);
+    hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(64), 0, s, step, sc, lr, beta1, beta2);
+    RQ_CHECK_LAUNCH("adamw_bump_kernel");
     int first = 0;
-    // (skip empty tensors)
-    while (first < n) {
+    while (first < n) {      // launches of at most kAwMaxJobs tensors (empty tensors are skipped)
         AdamwJobs jobs;
         jobs.n = 0;
         int blocks = 0, i = first;
@@ -114,11 +115,8 @@ extern "C" int rqhip_adamw_step(float *const *p, const float *const *g, float *c
             j.p = p[i]; j.g = g[i]; j.m = m[i]; j.v = v[i]; j.n = numel[i]; j.block0 = blocks;
             blocks += (int)((numel[i] + kAwBlockElems - 1) / kAwBlockElems);
         }
-        bool more = false;
-        for (int k = i; k < n; ++k) more = more || numel[k] > 0;
         if (jobs.n > 0) {
-            hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, jobs, step, scratch, more ? 0 : 1, lr, beta1, beta2, eps,
-                               weight_decay);
+            hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, jobs, sc, lr, beta1, beta2, eps, weight_decay);
             RQ_CHECK_LAUNCH("adamw_kernel");
         }
         first = i;

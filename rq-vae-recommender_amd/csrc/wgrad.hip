@@ -273,9 +273,10 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
     // PMC 2 * FETCH_SIZE + WRITE_SIZE = 1 266 MB per launch against 512 MB algorithmic (2.5 x), 5.1 TB/s: the kernel was running
     // at the fabric's limit on re-reads (profiles/r04_pmc_traffic_c2.json).  40 ranges leave 16 of 256 CUs idle and win.
     if (ms >= 8) ms &= ~7LL;
-    // at least four 32-row granules per range: at batch 640 twenty 32-row ranges made the reduction of their partial blocks (31 MB for a
-    // 512 x 768 layer, 19.6 us) cost more than the weight-gradient kernel itself (16 us); five 128-row ranges: 8 MB
-    if (ms > chunks / 4) ms = chunks / 4 > 0 ? chunks / 4 : 1;
+    // up to 128 rows: ONE range (no partial blocks, no reduction launch -- at batch 64 the eight reductions were a fifth of the step's
+    // launches).  (Capping larger batches at >= 128 rows per range was measured slower: batch 640, hipGraph step 0.358 -> 0.406 ms --
+    // the kernel is latency-bound per 16-row stage there and the longer ranges cost more than the smaller reduction saves.)
+    if (chunks <= 4) ms = 1;
     if (ms > chunks) ms = chunks > 0 ? chunks : 1;
     pl.msplit = (int)ms;
     pl.pow2 = 1;

@@ -84,7 +84,7 @@ class Kmeans:
     def run(self, x: torch.Tensor, sharded: bool = False) -> KmeansOutput:
         if sharded:
             if not wide.kmeans_covers(x.shape[1]):
-                raise ops.RqHipError(f"row-sharded k-means needs the HIP kernels (latent width {x.shape[1]} > 128)")
+                return self._run_gathered(x)
             return self._run_sharded(x)
         x = x.detach().to(torch.float32).contiguous()
         self._init_centroids(x)
@@ -147,6 +147,33 @@ class Kmeans:
             buf[torch.as_tensor(j, device=x.device)] = x[torch.as_tensor(r, device=x.device)]
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         return buf
+
+    def _run_gathered(self, x: torch.Tensor) -> KmeansOutput:
+        """Row-sharded call on latent widths the HIP k-means kernels do not take (D > 128; rqhip/wide.py): the warm-up rows (at most
+        20 000) are all-gathered and every rank runs the same stepwise loop on the whole matrix under ONE seed drawn by rank 0 -- same
+        data, same draws, same operators: identical codebooks on every rank (this configuration trained on one GPU and
+        raised on several)."""
+        from rqhip.dist import allgather_rows
+        x = x.detach().to(torch.float32).contiguous()
+        rank = dist.get_rank()
+        sizes = torch.zeros((dist.get_world_size(),), dtype=torch.int64, device=x.device)
+        sizes[rank] = x.shape[0]
+        dist.all_reduce(sizes)
+        lo = int(sizes[:rank].sum())
+        box = [int(torch.randint(0, 2 ** 31 - 1, (1,))) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        full = allgather_rows(x)
+        np_state = np.random.get_state()
+        with torch.random.fork_rng(devices=[x.device] if x.is_cuda else []):
+            torch.manual_seed(box[0])
+            np.random.seed(box[0] % (2 ** 32))
+            try:
+                self._init_centroids(full)
+                out = self._run_stepwise(full)
+            finally:
+                np.random.set_state(np_state)
+        self.assignment = out.assignment[lo:lo + x.shape[0]]
+        return KmeansOutput(centroids=self.centroids, assignment=self.assignment)
 
     def _run_sharded(self, x: torch.Tensor) -> KmeansOutput:
         """`x` is this rank's block of rows (blocks in rank order form the global matrix).  Rank 0 owns both RNG

@@ -5,7 +5,7 @@ A `torch.optim.Optimizer` with AdamW's constructor, `param_groups` and per-param
 `optimizer.state_dict()` / `load_state_dict()` -- the `"optimizer"` entry of the reference's checkpoints (train_rqvae.py:260-265) -- are
 interchangeable with `torch.optim.AdamW`'s in both directions.  What differs is the launch: torch's fused kernel works on 64 K-element chunks
 (18 workgroups for this model's 1.15 M parameters: 40-46 us per step, plus a launch that bumps the step counters); here 1 100 workgroups
-update everything in ~5 us and the last one to finish bumps the one device-side step counter -- which also makes the step replayable from a
+update everything in a few microseconds behind a one-thread kernel that bumps the one device-side step counter -- which also makes the step replayable from a
 captured hipGraph without torch's `capturable` machinery.  The hyper-parameters are kernel arguments: a captured graph replays the values
 it was captured with (train_rqvae.py re-captures after every eager excursion; it has no scheduler)."""
 import ctypes as C
@@ -83,7 +83,7 @@ class FlatAdamW(torch.optim.Optimizer):
                         (C.c_int64 * n)(*[p.numel() for p in ps]), n)
                 self._cache[gi] = arrs
             if self._scratch is None or self._scratch.device != dev:
-                self._scratch = torch.zeros((1,), dtype=torch.int32, device=dev)
+                self._scratch = torch.zeros((2,), dtype=torch.float32, device=dev)
             b1, b2 = group["betas"]
             with torch.cuda.device(dev):
                 check(l.rqhip_adamw_step(arrs[1], arrs[2], arrs[3], arrs[4], arrs[5], arrs[6], step.data_ptr(), self._scratch.data_ptr(),

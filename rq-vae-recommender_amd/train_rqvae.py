@@ -207,6 +207,7 @@ def train(
     dataset_split="beauty",
     log_every=100,
     use_hip_graph=None,
+    mlp_arith=None,
 ):
     params = dict(locals())
     del split_batches  # every rank always draws its own full batch (reference behaviour with a bare dataloader)
@@ -218,6 +219,11 @@ def train(
         raise RuntimeError("train_rqvae needs a ROCm GPU: the quantisation path has no CPU implementation")
 
     tuning.enable_tuned_gemms()  # fp32 library-GEMM selections for the encoder/decoder
+    if mlp_arith is not None:
+        # the arithmetic of the encoder / decoder GEMMs at batches of 4096 rows and more: "f16x2" (default), "fp32" (library GEMMs at every
+        # batch size: results independent of the batching), "bf16x3" (round 3, A/B)
+        from rqhip import linear as _lin
+        _lin.use_arith(mlp_arith)
     rank, local_rank, world = rqdist.init_from_env("cuda")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)

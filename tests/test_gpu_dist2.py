@@ -105,6 +105,20 @@ def _worker(rank, world, port, tmp):
     both = [torch.empty_like(shard_km) for _ in range(world)]
     dist.all_gather(both, shard_km.contiguous())
     assert torch.equal(both[0], both[1]), "ranks disagree on the centroids"
+    # (a2) latent widths the HIP k-means kernels do not take (D > 128): the sharded call gathers the warm-up rows and every rank runs the
+    # same seeded loop (this raised with several ranks) -- identical centroids everywhere, this rank's block of assignments
+    import warnings
+    gw = torch.Generator().manual_seed(21)
+    wide_rows = (torch.randn(8, 160, generator=gw)[torch.randint(0, 8, (600,), generator=gw)] + 0.1 * torch.randn(600, 160, generator=gw)).cuda()
+    wlo, whi = rqdist.shard_bounds(600)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wk = Kmeans(k=8, max_iters=5).run(wide_rows[wlo:whi].contiguous(), sharded=True)
+    wboth = [torch.empty_like(wk.centroids) for _ in range(world)]
+    dist.all_gather(wboth, wk.centroids.contiguous())
+    assert torch.equal(wboth[0], wboth[1]) and tuple(wk.assignment.shape) == (whi - wlo,)
+    d2 = ((wide_rows[wlo:whi, None, :] - wk.centroids[None]) ** 2).sum(-1)
+    assert (d2.argmin(dim=1) == wk.assignment).float().mean().item() > 0.99      # assignments belong to the returned centroids
 
     # (b) the lazy in-model warm-up, row-sharded: every rank takes its block of the warm rows through the model
     model = _make_model(kmeans_init=True)
@@ -238,7 +252,8 @@ def _graph_body(tmp, dist, rqdist, _GraphedStep):
         model = _make_model(kmeans_init=False)
         for layer in model.layers:
             layer.kmeans_initted = True
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True, capturable=True)
+        from rqhip.optim import FlatAdamW
+        opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)          # as train_rqvae.train
         reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
         step = _GraphedStep(model, opt, reducer, 640, 768, torch.device("cuda", 0), 0.2)
         model.train()
