@@ -90,6 +90,7 @@ def parse_args():
     ap.add_argument("--no-input-scales", action="store_true", help="A/B: run the maxima pass over the input batch inside every step (round 4) instead of "
                                                                    "taking the rows' maxima from the resident corpus (data/processed.py)")
     ap.add_argument("--torch-adamw", action="store_true", help="A/B: torch.optim.AdamW(fused=True) instead of rqhip.optim.FlatAdamW")
+    ap.add_argument("--no-strict", action="store_true", help="skip secondary.strict_fp32 (the same step on library fp32 GEMMs, ~100 steps): profiling runs")
     ap.add_argument("--no-small-batch", action="store_true", help="skip secondary.small_batch (a subprocess: batch 640 / batch 64 steps, eager and hipGraph)")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
@@ -460,7 +461,7 @@ def main():
     # the strict-fp32 arm of the same step (`--mlp library`: library fp32 GEMMs + oracle-ordered fp32-MFMA weight gradients),
     # same process, same model: what the step costs without the f16x2 emulation
     strict = None
-    if args.mlp == "split" and world == 1:
+    if args.mlp == "split" and world == 1 and not args.no_strict:
         prev_arith = _lin.use_arith("fp32")
         n_strict = max(50, min(steps, 100))
         for _ in range(3):
@@ -497,7 +498,7 @@ def main():
 
     def rq_fwd_bwd():
         o = ops.rq_forward(lat, cbs, 1, BETA, want_embs=False, want_residuals=False)
-        ops.rq_backward(lat, cbs, 1, BETA, o.ids, g_embsum=g_sum, g_loss=g_l)
+        ops.rq_backward(lat, cbs, 1, BETA, o.ids, g_embsum=g_sum, g_loss=g_l, cbgrad=ops.cbgrad_default())   # (the training path's form)
 
     rq_ms = reps(lambda: ops.rq_forward(lat, cbs, 1, BETA, want_embs=False, want_residuals=False))
     # the same launch on the all-fp32 matrix scan, main kernel only (HIP events on the launch stream, as `roofline`)

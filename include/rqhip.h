@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 420 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 430 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -140,6 +140,17 @@ int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebook
                       const float *g_embsum, const float *g_resid, const float *g_loss,
                       float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
                       rqhip_stream_t stream);
+/* The same call with a kernel-selection flag (rqhip_rq_backward passes 0).  RQHIP_BWD_CBGRAD_MATRIX: where rqhip_rq_backward_matrix_form(D,
+ * K, L, mode) says so (D = 32, STE, the training step's upstream gradients g_embsum + g_loss only; 3 x <= 256 or 3-4 x 1024 codes) the
+ * codebook gradient is accumulated as a one-hot matrix product on the bf16 matrix cores (three exact bf16 pieces of every staged fp32
+ * value; the sum's order is the matrix pipe's: reproducible run to run, not restatable by the oracle -- held to "no further from fp64
+ * than the ordered kernel"); g_res0 has the same bits either way.  Other shapes ignore the flag. */
+#define RQHIP_BWD_CBGRAD_MATRIX 0x1u
+int rqhip_rq_backward_matrix_form(int D, int K, int L, int mode);
+int rqhip_rq_backward_ex(const float *res0, int64_t B, int D, const float *codebooks, int L, int K, int mode, float beta,
+                         const int64_t *ids, const float *g_embs, const float *g_embsum, const float *g_resid, const float *g_loss,
+                         float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes, unsigned flags,
+                         rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * One Gumbel-softmax level, training mode.  Replaces quantize.py:112-117,128,131-136,157 and

@@ -382,19 +382,62 @@ constexpr size_t kFlatListBytes = 2 * kFlatOwnerWaves * kListStride * sizeof(uns
 // step's -- g_embsum and g_loss given, g_embs and g_resid absent -- so their loads and tests are compiled out.  (The rows
 // role is bound by instruction issue, not by HBM: ~400 VALU instructions per lane and step in the first version, 64-bit
 // address chains, per-load predication, tests of L and of four optional pointers.)
-template <int MODE, bool PAIR, int NL, bool TRAIN>
+// MMP / MMB (round 5; 0 = the ordered owners above): the codebook gradient as a ONE-HOT MATRIX PRODUCT.  dE_l[k] = sum over the rows
+// with id_l = k of their staged vector is One_l^T . V_l; the owner waves form it on the bf16 matrix cores instead of walking an LDS
+// table: per staged step every 16 rows x level ("pair") are transposed ONCE into the matrix instruction's B operand as three EXACT
+// bf16 pieces of the fp32 values (v = h + m + l, 24 bits), owner wave w holds the accumulators of code blocks 32 (w + 8 b), b < MMB,
+// of the launch's MMP levels in registers (16 per block and level), builds its one-hot A operand from the 16 keys in registers and
+// issues 3 matrix instructions per pair and block.  No LDS read-modify-write, no per-CU table in LDS (its 96 KB hold the operand
+// images instead), the per-workgroup partial tables are flushed from registers; the products 1.0 x piece are exact, the sum's ORDER is
+// the matrix pipe's: not restatable by the oracle, so rqhip_rq_backward keeps the ordered form and rqhip_rq_backward_ex selects this
+// one (RQHIP_BWD_CBGRAD_MATRIX; tests/test_gpu_parity.py: g_res0 identical bits, codebook gradient no further from fp64 than the
+// ordered kernel's).  D = 32 only (R = 64 rows per step, 4 pairs per level).
+typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bw_f32x2 __attribute__((ext_vector_type(2)));
+typedef float bw_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned bw_u32x4 __attribute__((ext_vector_type(4)));
+typedef int bw_i32x4 __attribute__((ext_vector_type(4)));
+// (a, b) -> three dwords, each the packed bf16 pieces {piece(a), piece(b)}; a = h + m + l exactly (likewise b)
+__device__ __forceinline__ void bw_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    const bw_bf16x2 hh = __builtin_convertvector(bw_f32x2{a, b}, bw_bf16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const bw_bf16x2 mm = __builtin_convertvector(bw_f32x2{ra, rb}, bw_bf16x2);
+    m = __builtin_bit_cast(unsigned, mm);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    const bw_bf16x2 ll = __builtin_convertvector(bw_f32x2{sa, sb}, bw_bf16x2);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+constexpr int kMmPairOps = 3 * 2 * 32;      // 16-byte elements of a pair's B operand: [piece][octet][feature]
+
+template <int MODE, bool PAIR, int NL, bool TRAIN, int MMP = 0, int MMB = 0>
 __global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const RqBwdParams p, float *__restrict__ partial,
                                                                        int LKD_total, int R, int LPR) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float acc[];
     constexpr int LM = NL ? NL : kFusedMaxL;
+    constexpr bool MM = MMP > 0;
     const int D = p.D, L = NL ? NL : p.L, K = p.K;
     const int nl = p.l_end - p.l_begin;
-    const int tbl = p.g_cb ? nl * K * D : 0;                 // [levels of this launch][K][D]
+    const int tbl = (p.g_cb && !MM) ? nl * K * D : 0;        // [levels of this launch][K][D]
     const int items = nl * R;                               // staged rows x levels per step
     float *stage0 = acc + tbl;                              // [2][nl][R][D]
     int *keys0 = reinterpret_cast<int *>(stage0 + 2 * (size_t)items * D);   // [2][nl][R]
     unsigned *lists = reinterpret_cast<unsigned *>(keys0 + 2 * items);
+    // MM: instead of the lists, [2][pairs] B-operand images and [2][pairs][16] keys (pairs = MMP levels x 4 groups of 16 rows)
+    constexpr int kPairs = MM ? MMP * 4 : 1;
+    bw_u32x4 *bops = reinterpret_cast<bw_u32x4 *>(lists);
+    int *bkeys = reinterpret_cast<int *>(bops + 2 * kPairs * kMmPairOps);
+    bw_f32x16 cacc[MM ? MMP : 1][MM ? MMB : 1];
+    if constexpr (MM) {
+#pragma unroll
+        for (int a = 0; a < MMP; ++a)
+#pragma unroll
+            for (int b = 0; b < MMB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cacc[a][b][r] = 0.0f;
+    }
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int e = threadIdx.x * 4; e < tbl; e += kFlatThreads * 4) *reinterpret_cast<f32x4 *>(acc + e) = zero4;
 
@@ -453,9 +496,14 @@ __global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const Rq
     const int own0 = PAIR ? 2 * ow : ow;                                    // this wave's first (or only) owner
 
     // step h: the rows waves stage block h, the owner waves add block h-1; the last step only drains
-    const long long last = p.g_cb ? n_steps : n_steps - 1;
-    for (long long h = 0; h <= last; ++h) {
-        if (row_role) {
+    // (MM: a staged block is converted in the step after it was staged and multiplied in the step after that)
+    const long long last = p.g_cb ? (MM ? n_steps + 1 : n_steps) : n_steps - 1;
+    // The two roles run SEPARATE loops with the same number of barriers (a workgroup barrier counts arriving waves, whatever code path
+    // they come from): written as one loop with an if / else inside, every loop-carried value of one role is live through the other role's
+    // branch and the register allocator adds the two roles' needs -- with the matrix form's 48 accumulator registers that spilled.
+    if (row_role) {
+      for (long long h = 0; h <= last; ++h) {
+        {
             if (h < n_steps) {
                 const bool ok = ok_c;
                 float *stage = stage0 + (size_t)(h & 1) * items * D;
@@ -513,6 +561,75 @@ __global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const Rq
                 r0_c = r0_n; gs_c = gs_n; gl_c = gl_n;
 #pragma unroll
                 for (int l = 0; l < LM; ++l) { id_c[l] = id_n[l]; id_n[l] = id_nn[l]; e_c[l] = e_n[l]; }
+            }
+        }
+        if (p.g_cb) __syncthreads();
+      }
+    } else {
+      for (long long h = 0; h <= last; ++h) {
+        if (MM) {
+            if constexpr (MM) {
+                if (p.g_cb && ow >= 0) {
+                    // ---- convert the block staged in step h - 1 into B-operand images (each owner wave: pairs ow, ow + 8, ...)
+                    if (h >= 1 && h - 1 < n_steps) {
+                        const float *stage = stage0 + (size_t)((h - 1) & 1) * items * D;
+                        const int *keys = keys0 + ((h - 1) & 1) * items;
+                        const int cbuf = (int)((h - 1) & 1);
+                        const int n = lane & 31, o = lane >> 5;
+                        for (int pr = ow; pr < kPairs; pr += kFlatOwnerWaves) {
+                            const int li = pr >> 2, grp = pr & 3;
+                            const float *src = stage + ((size_t)li * 64 + 16 * grp + 8 * o) * 32 + n;
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = src[j * 32];
+                            bw_u32x4 ph, pm, pl;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                unsigned hh, mm, ll;
+                                bw_split2(v[2 * j], v[2 * j + 1], hh, mm, ll);
+                                ph[j] = hh; pm[j] = mm; pl[j] = ll;
+                            }
+                            bw_u32x4 *dst = bops + (size_t)(cbuf * kPairs + pr) * kMmPairOps + o * 32 + n;
+                            dst[0 * 64] = ph;
+                            dst[1 * 64] = pm;
+                            dst[2 * 64] = pl;
+                            if (lane < 16) bkeys[(cbuf * kPairs + pr) * 16 + lane] = keys[li * 64 + 16 * grp + lane];
+                        }
+                    }
+                    // ---- multiply the images converted in step h - 1 (the block staged in step h - 2)
+                    if (h >= 2 && h - 2 < n_steps) {
+                        const int mbuf = (int)(h & 1);
+                        const int il = lane & 31, o = lane >> 5;
+#pragma unroll
+                        for (int li = 0; li < MMP; ++li) {
+#pragma unroll
+                            for (int grp = 0; grp < 4; ++grp) {
+                                const int pr = li * 4 + grp;
+                                const bw_i32x4 *kp = reinterpret_cast<const bw_i32x4 *>(bkeys + (mbuf * kPairs + pr) * 16 + 8 * o);
+                                const bw_i32x4 k0 = kp[0], k1 = kp[1];
+                                const bw_u32x4 *src = bops + (size_t)(mbuf * kPairs + pr) * kMmPairOps + o * 32 + il;
+                                const bw_bf16x8 bh = __builtin_bit_cast(bw_bf16x8, src[0 * 64]);
+                                const bw_bf16x8 bm = __builtin_bit_cast(bw_bf16x8, src[1 * 64]);
+                                const bw_bf16x8 bl = __builtin_bit_cast(bw_bf16x8, src[2 * 64]);
+#pragma unroll
+                                for (int nb = 0; nb < MMB; ++nb) {
+                                    const int code = li * K + 32 * (ow + kFlatOwnerWaves * nb) + il;     // keys are level * K + id
+                                    bw_u32x4 a;     // bf16 1.0 = 0x3f80
+                                    a[0] = (k0[0] == code ? 0x3f80u : 0u) | (k0[1] == code ? 0x3f800000u : 0u);
+                                    a[1] = (k0[2] == code ? 0x3f80u : 0u) | (k0[3] == code ? 0x3f800000u : 0u);
+                                    a[2] = (k1[0] == code ? 0x3f80u : 0u) | (k1[1] == code ? 0x3f800000u : 0u);
+                                    a[3] = (k1[2] == code ? 0x3f80u : 0u) | (k1[3] == code ? 0x3f800000u : 0u);
+                                    const bw_bf16x8 av = __builtin_bit_cast(bw_bf16x8, a);
+                                    bw_f32x16 c16 = cacc[li][nb];
+                                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bl, c16, 0, 0, 0);   // smallest pieces first
+                                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bm, c16, 0, 0, 0);
+                                    c16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, c16, 0, 0, 0);
+                                    cacc[li][nb] = c16;
+                                }
+                            }
+                        }
+                    }
+                }
             }
         } else if (h >= 1 && p.g_cb && !RQ_PROBE(4) && ow >= 0 && (PAIR || ow < nown)) {
             // A first version picked the rows with scalar ballot / readlane logic and was bound by the CU's one scalar
@@ -572,12 +689,29 @@ __global__ __launch_bounds__(kFlatThreads) void rq_backward_flat_kernel(const Rq
             }
         }
         if (p.g_cb) __syncthreads();
+      }
     }
 
     if (p.g_cb) {
         float *out = partial + (size_t)blockIdx.x * LKD_total;
-        for (int e = threadIdx.x * 4; e < (RQ_PROBE(8) ? 0 : tbl); e += kFlatThreads * 4)
-            *reinterpret_cast<f32x4 *>(out + e) = *reinterpret_cast<const f32x4 *>(acc + e);
+        if constexpr (MM) {
+            // cacc[li][nb][r]: code 32 (ow + 8 nb) + 8 (r >> 2) + 4 (lane >> 5) + (r & 3), feature lane & 31
+            if (ow >= 0) {
+                const int il = lane & 31, o = lane >> 5;
+#pragma unroll
+                for (int li = 0; li < MMP; ++li)
+#pragma unroll
+                    for (int nb = 0; nb < MMB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int code = 32 * (ow + kFlatOwnerWaves * nb) + 8 * (r >> 2) + 4 * o + (r & 3);
+                            if (code < K) out[((size_t)li * K + code) * 32 + il] = cacc[li][nb][r];
+                        }
+            }
+        } else {
+            for (int e = threadIdx.x * 4; e < (RQ_PROBE(8) ? 0 : tbl); e += kFlatThreads * 4)
+                *reinterpret_cast<f32x4 *>(out + e) = *reinterpret_cast<const f32x4 *>(acc + e);
+        }
     }
 }
 
@@ -750,7 +884,7 @@ static int rq_backward_impl(const float *res0, int64_t B, int D, const float *co
                             int mode, float beta, const int64_t *ids, const float *g_embs,
                             const float *g_embsum, const float *g_resid, const float *g_loss,
                             float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
-                            rqhip_stream_t stream);
+                            unsigned flags, rqhip_stream_t stream);
 
 extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
                                  int mode, float beta, const int64_t *ids, const float *g_embs,
@@ -761,7 +895,33 @@ extern "C" int rqhip_rq_backward(const float *res0, int64_t B, int D, const floa
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     profile_begin(s, RQHIP_PROF_RQ_BACKWARD, (double)B * L * 3.0 * D, (double)B * (12.0 * D + 8.0 * L));
     const int rc = rq_backward_impl(res0, B, D, codebooks, L, K, mode, beta, ids, g_embs, g_embsum, g_resid, g_loss, g_res0,
-                                    g_codebooks, workspace, workspace_bytes, stream);
+                                    g_codebooks, workspace, workspace_bytes, 0u, stream);
+    profile_end(s);
+    return rc;
+}
+
+// which (levels per launch, code blocks per owner wave) the matrix-form codebook gradient runs a shape with; 0: not at all
+static int mm_levels_per_pass(int D, int K, int L, int mode, bool train) {
+    if (D != 32 || mode != RQHIP_MODE_STE || !train || K % 32 != 0) return 0;
+    if (K <= 256 && L == 3) return 3;                 // 3 x 256: all levels in one launch
+    if (K == 1024 && (L == 3 || L == 4)) return 1;    // 1024 codes: four blocks per owner wave, one level per launch
+    return 0;
+}
+extern "C" int rqhip_rq_backward_matrix_form(int D, int K, int L, int mode) { return mm_levels_per_pass(D, K, L, mode, true) ? 1 : 0; }
+
+extern "C" int rqhip_rq_backward_ex(const float *res0, int64_t B, int D, const float *codebooks, int L, int K,
+                                    int mode, float beta, const int64_t *ids, const float *g_embs,
+                                    const float *g_embsum, const float *g_resid, const float *g_loss,
+                                    float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
+                                    unsigned flags, rqhip_stream_t stream) {
+    if (flags & ~RQHIP_BWD_CBGRAD_MATRIX) {
+        set_error("rq_backward_ex: unknown flags 0x%x", flags);
+        return RQHIP_EARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    profile_begin(s, RQHIP_PROF_RQ_BACKWARD, (double)B * L * 3.0 * D, (double)B * (12.0 * D + 8.0 * L));
+    const int rc = rq_backward_impl(res0, B, D, codebooks, L, K, mode, beta, ids, g_embs, g_embsum, g_resid, g_loss, g_res0,
+                                    g_codebooks, workspace, workspace_bytes, flags, stream);
     profile_end(s);
     return rc;
 }
@@ -770,7 +930,7 @@ static int rq_backward_impl(const float *res0, int64_t B, int D, const float *co
                             int mode, float beta, const int64_t *ids, const float *g_embs,
                             const float *g_embsum, const float *g_resid, const float *g_loss,
                             float *g_res0, float *g_codebooks, void *workspace, size_t workspace_bytes,
-                            rqhip_stream_t stream) {
+                            unsigned flags, rqhip_stream_t stream) {
     if (B < 0 || !codebooks || (B > 0 && (!res0 || !ids))) {
         set_error("rq_backward: null pointer or negative B");
         return RQHIP_EARG;
@@ -807,14 +967,19 @@ static int rq_backward_impl(const float *res0, int64_t B, int D, const float *co
         const int R = flat_rows(D), LPR = D / 4;
         const int G = flat_wgs(B, D);
         float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
-        const int per_pass = g_codebooks ? flat_levels_per_pass(D, K, L) : L;
+        const bool train_shape = g_embsum && g_loss && !g_embs && !g_resid;
+        // the matrix form of the codebook gradient (RQHIP_BWD_CBGRAD_MATRIX; see the kernel): levels per launch, 0 = the ordered form
+        const int mmp = (g_codebooks && (flags & RQHIP_BWD_CBGRAD_MATRIX)) ? mm_levels_per_pass(D, K, L, mode, train_shape) : 0;
+        const int per_pass = mmp ? mmp : (g_codebooks ? flat_levels_per_pass(D, K, L) : L);
         for (int l0 = 0; l0 < L; l0 += per_pass) {
             p.l_begin = l0;
             p.l_end = (l0 + per_pass < L) ? l0 + per_pass : L;
             p.write_rows = (l0 == 0);
             const int nl = p.l_end - p.l_begin;
             const int LKD = nl * K * D;
-            const size_t lds = g_codebooks ? (size_t)nl * flat_level_bytes(D, K) + kFlatListBytes : 0;
+            size_t lds = g_codebooks ? (size_t)nl * flat_level_bytes(D, K) + kFlatListBytes : 0;
+            if (mmp)   // two stage buffers + keys, two sets of B-operand images + keys (no table)
+                lds = (size_t)2 * nl * (R * D * sizeof(float) + R * sizeof(int)) + (size_t)2 * nl * 4 * (kMmPairOps * 16 + 16 * sizeof(int));
             auto go = [&](auto kern) -> int {
                 static LdsGrant grant;
                 RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kFusedLdsBudget));
@@ -824,9 +989,14 @@ static int rq_backward_impl(const float *res0, int64_t B, int D, const float *co
             };
             // the training step's shape of upstream gradients and the two level counts of the named configurations get
             // their own instantiations; everything else runs the generic one
-            const bool train = g_embsum && g_loss && !g_embs && !g_resid;
+            const bool train = train_shape;
             const int nlv = (train && (L == 3 || L == 4)) ? L : 0;
             int rcf;
+            if (mmp) {
+                rcf = (mmp == 3) ? go(rq_backward_flat_kernel<RQHIP_MODE_STE, true, 3, true, 3, 1>)
+                    : (L == 4)   ? go(rq_backward_flat_kernel<RQHIP_MODE_STE, true, 4, true, 1, 4>)
+                                 : go(rq_backward_flat_kernel<RQHIP_MODE_STE, true, 3, true, 1, 4>);
+            } else
 #define RQ_FLAT_GO(M, P)                                                                                              \
     (nlv == 3 ? go(rq_backward_flat_kernel<M, P, 3, true>)                                                            \
               : nlv == 4 ? go(rq_backward_flat_kernel<M, P, 4, true>) : go(rq_backward_flat_kernel<M, P, 0, false>))

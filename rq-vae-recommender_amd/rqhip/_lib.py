@@ -20,6 +20,7 @@ MODE_EVAL, MODE_STE, MODE_ROTATION, MODE_GUMBEL = 0, 1, 2, 3
 # rqhip_rq_forward_ex flags (include/rqhip.h)
 FWD_SCAN_FP32, FWD_SCAN_VALU, FWD_NO_COOP_TAIL = 0x1, 0x2, 0x10
 WGRAD_FP32 = 0x1   # rqhip_linear_wgrad_ex
+BWD_CBGRAD_MATRIX = 0x1   # rqhip_rq_backward_ex
 SPLIT_F16X2, SPLIT_BF16X3 = 0, 1                       # arithmetic of the split GEMM kernels (include/rqhip.h)
 EPI_STORE, EPI_RELU, EPI_RECON, EPI_MASK = 0, 1, 2, 3  # rqhip_gemm_split_ex epilogues
 PROF_TAGS = {1: "rq_forward", 2: "rq_backward", 3: "gemm_split", 4: "wgrad", 5: "maxima", 6: "weight_images"}
@@ -60,6 +61,9 @@ SIGNATURES = {
     "rqhip_rq_backward_plan": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "rqhip_rq_backward": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
+    "rqhip_rq_backward_matrix_form": (_int, [_int, _int, _int, _int]),
+    "rqhip_rq_backward_ex": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _sz, C.c_uint, _vp]),
     "rqhip_gumbel_forward": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rqhip_gumbel_backward_workspace_bytes": (_sz, [_i64, _int, _int]),
     "rqhip_gumbel_matrix_path_min_rows": (_i64, [_i64]),

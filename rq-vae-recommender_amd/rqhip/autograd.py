@@ -64,7 +64,8 @@ class RqStackFunction(torch.autograd.Function):
                 p._rq_sink_epoch = sink.owner.epoch
         g_res0, g_cb = ops.rq_backward(res0, codebooks, ctx.mode, ctx.beta, ids, g_embs=_dense(g_embs),
                                        g_embsum=_dense(g_embsum), g_resid=_dense(g_resid), g_loss=_dense(g_loss),
-                                       need_res0=need_res0, need_codebooks=need_cb, out_g_codebooks=out_cb)
+                                       need_res0=need_res0, need_codebooks=need_cb, out_g_codebooks=out_cb,
+                                       cbgrad=ops.cbgrad_default())
         return g_res0, (g_cb.view_as(g_cb) if out_cb is not None else g_cb), None, None, None, None
 
 

@@ -123,11 +123,32 @@ def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_
     return RqForwardOut(ids, embs, residuals, emb_sum, loss, norm, margin)
 
 
+_CBGRAD = "matrix"
+
+
+def use_cbgrad(form: str) -> str:
+    """How the TRAINING path (rqhip/autograd.py, rqhip/torch_ops.py) accumulates the codebook gradient where both forms exist (D = 32, STE,
+    3 x <= 256 or 3-4 x 1024 codes): "matrix" (default: a one-hot matrix product on the bf16 matrix cores, three exact pieces per value; the
+    sum's order is the matrix pipe's) or "ordered" (row order, bit-exact against oracle/rq_oracle.c:rqo_rq_backward_ordered).  g_res0 has the
+    same bits either way.  Returns the previous setting."""
+    global _CBGRAD
+    if form not in ("matrix", "ordered"):
+        raise ValueError(form)
+    before, _CBGRAD = _CBGRAD, form
+    return before
+
+
+def cbgrad_default() -> str:
+    return _CBGRAD
+
+
 def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Tensor, *,
                 g_embs: Optional[Tensor] = None, g_embsum: Optional[Tensor] = None,
                 g_resid: Optional[Tensor] = None, g_loss: Optional[Tensor] = None,
-                need_res0: bool = True, need_codebooks: bool = True, out_g_codebooks: Optional[Tensor] = None):
-    """Closed-form backward of rq_forward (rqhip_rq_backward) -> (g_res0 [B,D] | None, g_codebooks [L,K,D] | None)."""
+                need_res0: bool = True, need_codebooks: bool = True, out_g_codebooks: Optional[Tensor] = None,
+                cbgrad: str = "ordered"):
+    """Closed-form backward of rq_forward (rqhip_rq_backward_ex) -> (g_res0 [B,D] | None, g_codebooks [L,K,D] | None).
+    cbgrad: "ordered" (this function's default: the form the oracle restates bit for bit) or "matrix" (see `use_cbgrad`)."""
     _need_gpu(res0, codebooks, ids, g_embs, g_embsum, g_resid, g_loss)
     res0, codebooks = _f32c(res0, "res0"), _f32c(codebooks, "codebooks")
     g_embs, g_embsum = _f32c(g_embs, "g_embs"), _f32c(g_embsum, "g_embsum")
@@ -150,10 +171,10 @@ def rq_backward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, ids: Te
                 raise RqHipError("rq_backward: out_g_codebooks must be a contiguous float32 [L,K,D] tensor")
         wsb = l.rqhip_rq_backward_workspace_bytes(B, D, L, K)
         ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-        rc = l.rqhip_rq_backward(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(g_embs),
-                                 _ptr(g_embsum), _ptr(g_resid), _ptr(g_loss), _ptr(g_res0), _ptr(g_cb), _ptr(ws),
-                                 wsb, _stream())
-        check(rc, "rqhip_rq_backward")
+        rc = l.rqhip_rq_backward_ex(_ptr(res0), B, D, _ptr(codebooks), L, K, mode, beta, _ptr(ids), _ptr(g_embs),
+                                    _ptr(g_embsum), _ptr(g_resid), _ptr(g_loss), _ptr(g_res0), _ptr(g_cb), _ptr(ws),
+                                    wsb, _lib.BWD_CBGRAD_MATRIX if cbgrad == "matrix" else 0, _stream())
+        check(rc, "rqhip_rq_backward_ex")
     return g_res0, g_cb
 
 

@@ -62,7 +62,7 @@ def rq_stack_backward(res0: Tensor, codebooks: Tensor, ids: Tensor, mode: int, b
                       g_embsum: Optional[Tensor]) -> List[Tensor]:
     c = lambda t: None if t is None else t.contiguous()  # noqa: E731
     g_res0, g_cb = ops.rq_backward(res0, codebooks, mode, beta, ids, g_embs=c(g_embs), g_embsum=c(g_embsum),
-                                   g_resid=c(g_resid), g_loss=c(g_loss))
+                                   g_resid=c(g_resid), g_loss=c(g_loss), cbgrad=ops.cbgrad_default())
     return [g_res0, g_cb]
 
 

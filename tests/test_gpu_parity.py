@@ -371,6 +371,57 @@ def test_backward_vs_oracle(mode, B, D, K, L, which):
         _assert_bitexact(g_cb_b, g_cb, "g_codebooks run-to-run")
 
 
+@pytest.mark.parametrize("pattern", ["argmin", "one_code", "two_codes", "runs", "ragged"])
+@pytest.mark.parametrize("B,K,L", [(100_000, 256, 3), (3000, 256, 3), (60_000, 1024, 4), (7, 256, 3), (5000, 1024, 3), (4000, 96, 3)])
+def test_backward_matrix_form_of_the_codebook_gradient(B, K, L, pattern):
+    """RQHIP_BWD_CBGRAD_MATRIX (round 5): the codebook gradient as a one-hot matrix product on the bf16 matrix cores -- what the training
+    path runs at D = 32 / STE.  g_res0 keeps the bits of the ordered kernel (== the oracle's); the codebook gradient is the exact sum of the
+    same fp32 terms in another order: no further from the fp64 sum than the ordered kernel is (both are fp32 accumulations), run-to-run
+    identical, collapsed codebooks and ragged tails included.  Shapes the matrix form does not cover fall back to the ordered kernel."""
+    from rqhip import _lib, ops
+    D, mode = 32, 1
+    rng = np.random.default_rng(B + K + L)
+    if pattern == "ragged" and B > 5000:
+        B = B - 37
+    x = (rng.standard_normal((B, D)) * 0.7).astype(np.float32)
+    cbs = (rng.standard_normal((L, K, D)) * np.array([0.6 / (l + 1) for l in range(L)])[:, None, None]).astype(np.float32)
+    if pattern in ("argmin", "ragged"):
+        ids = o.rq_forward(x, cbs, mode, 0.25)["ids"]
+    elif pattern == "one_code":
+        ids = np.full((L, B), 5, np.int64)
+    elif pattern == "two_codes":
+        ids = rng.choice([3, K - 1], size=(L, B)).astype(np.int64)
+    else:
+        ids = np.repeat(rng.integers(0, K, size=(L, B // 3 + 1)), 3, axis=1)[:, :B].astype(np.int64)
+    g_sum = (rng.standard_normal((B, D)) / B).astype(np.float32)
+    g_loss = np.full((B,), 1.0 / B, np.float32) if pattern != "runs" else (rng.random(B) / B).astype(np.float32)
+    kw = dict(g_embsum=_gpu(g_sum), g_loss=_gpu(g_loss))
+    r0_o, cb_o = ops.rq_backward(_gpu(x), _gpu(cbs), mode, 0.25, _gpu(ids), **kw)
+    r0_m, cb_m = ops.rq_backward(_gpu(x), _gpu(cbs), mode, 0.25, _gpu(ids), cbgrad="matrix", **kw)
+    r0_m2, cb_m2 = ops.rq_backward(_gpu(x), _gpu(cbs), mode, 0.25, _gpu(ids), cbgrad="matrix", **kw)
+    assert torch.equal(r0_m, r0_o) and torch.equal(cb_m, cb_m2) and torch.equal(r0_m, r0_m2)
+    covered = bool(_lib.lib().rqhip_rq_backward_matrix_form(D, K, L, mode))
+    assert covered == ((K <= 256 and K % 32 == 0 and L == 3) or K == 1024)
+    if not covered:
+        assert torch.equal(cb_m, cb_o)              # the flag is ignored: same kernel
+        return
+    # the fp64 sum of the terms the kernels add: 2 g_loss (e_l - r_l) per row into code id_l (STE: r_{l+1} = r_l - (r_l + (e_l - r_l)))
+    xt, ct, it = _gpu(x), _gpu(cbs), _gpu(ids)
+    gl = _gpu(g_loss)
+    ref = torch.zeros((L, K, D), dtype=torch.float64, device="cuda")
+    r = xt.clone()
+    for l in range(L):
+        e = ct[l][it[l]]
+        term = (2.0 * (e - r)) * gl[:, None]                       # fp32, as the kernels form it
+        ref[l].index_add_(0, it[l], term.double())
+        r = r - (r + (e - r))
+    scale = ref.abs().max().item()
+    err_m = (cb_m.double() - ref).abs().max().item() / scale
+    err_o = (cb_o.double() - ref).abs().max().item() / scale
+    print(f"B={B} K={K} L={L} {pattern}: codebook-gradient error vs fp64: matrix {err_m:.3e}, ordered {err_o:.3e}")
+    assert err_m <= max(2.0 * err_o, 2e-7), (err_m, err_o)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("pattern", ["one_code", "two_codes", "same_owner", "runs"])
 def test_backward_skewed_ids(mode, pattern):

@@ -58,6 +58,8 @@ def bwd(reps, shapes=None):
         ge = torch.randn(B, D, generator=g).cuda()
         gl = torch.full((B,), 1.0 / B).cuda()
         ms = timeit(lambda: ops.rq_backward(x, cb, 1, 0.25, out.ids, g_embsum=ge, g_loss=gl), reps)
+        ms_m = timeit(lambda: ops.rq_backward(x, cb, 1, 0.25, out.ids, g_embsum=ge, g_loss=gl, cbgrad="matrix"), reps)
+        print(f"    (codebook gradient as a one-hot matrix product: {ms_m * 1e3:.1f} us)")
         by = B * (12 * D + 8 * L)
         print(f"bwd ste  B={B:8d} D={D:3d} K={K:5d} L={L}: call {ms*1e3:9.1f} us  {by/ms/1e6:7.1f} GB/s algorithmic", flush=True)
 
