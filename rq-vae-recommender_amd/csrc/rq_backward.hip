@@ -392,6 +392,12 @@ constexpr size_t kFlatListBytes = 2 * kFlatOwnerWaves * kListStride * sizeof(uns
 // the matrix pipe's: not restatable by the oracle, so rqhip_rq_backward keeps the ordered form and rqhip_rq_backward_ex selects this
 // one (RQHIP_BWD_CBGRAD_MATRIX; tests/test_gpu_parity.py: g_res0 identical bits, codebook gradient no further from fp64 than the
 // ordered kernel's).  D = 32 only (R = 64 rows per step, 4 pairs per level).
+// MEASURED (profiles/r05_cbgrad_matrix_ab.txt): correct on the first GPU run and SLOWER than the ordered owners -- 38.2 vs 31.7 us at
+// 100 000 x 3 x 256, 242 vs 184 us at 1 M rows, 247 vs 149 us at 262 144 x 4 x 1024: every owner wave re-reads all B-operand images of a
+// step (8 x 36 KB of LDS reads) and builds 12 one-hot operands (20 VALU instructions each) beside the rows role on the same SIMDs, 3.9 us
+// per 64-row step against the ordered form's 2.8; and at 100 000 rows 13 us of the call are the per-CU table flush + reduce either way.
+// The product (rqhip/ops.py:use_cbgrad) therefore keeps the ordered form; what meets the <= 15 us target is a design WITHOUT per-CU tables
+// (rows pre-sorted by code once per batch: DESIGN.md section 8).
 typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float bw_f32x2 __attribute__((ext_vector_type(2)));

@@ -123,14 +123,15 @@ def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_
     return RqForwardOut(ids, embs, residuals, emb_sum, loss, norm, margin)
 
 
-_CBGRAD = "matrix"
+_CBGRAD = "ordered"
 
 
 def use_cbgrad(form: str) -> str:
     """How the TRAINING path (rqhip/autograd.py, rqhip/torch_ops.py) accumulates the codebook gradient where both forms exist (D = 32, STE,
-    3 x <= 256 or 3-4 x 1024 codes): "matrix" (default: a one-hot matrix product on the bf16 matrix cores, three exact pieces per value; the
-    sum's order is the matrix pipe's) or "ordered" (row order, bit-exact against oracle/rq_oracle.c:rqo_rq_backward_ordered).  g_res0 has the
-    same bits either way.  Returns the previous setting."""
+    3 x <= 256 or 3-4 x 1024 codes): "ordered" (default: row order, bit-exact against oracle/rq_oracle.c:rqo_rq_backward_ordered) or
+    "matrix" (round 5's experiment, kept selectable: a one-hot matrix product on the bf16 matrix cores, three exact pieces per value, the
+    sum's order is the matrix pipe's -- correct to the ordered kernel's own error level and MEASURED SLOWER: 38 vs 32 us at 100 000 rows,
+    242 vs 184 us at 1 M, profiles/r05_cbgrad_matrix_ab.txt).  g_res0 has the same bits either way.  Returns the previous setting."""
     global _CBGRAD
     if form not in ("matrix", "ordered"):
         raise ValueError(form)
