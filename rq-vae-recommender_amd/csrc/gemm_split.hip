@@ -271,6 +271,7 @@ struct GemmSplitParams {
     int rt_big;
     unsigned *counter;       // the tile dispensers behind the weight image (kGsTailWords words, zero between launches)
     int n_queues;            // gemm_f16_kernel: 1 (chip-wide dispenser) or 8 (one per XCD)
+    int rt_fastest;          // gemm_f16_kernel, one queue: tiles in row-tile-fastest order (A/B)
     // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
     // rowsum[ct][m] the squared error of row m over column tile ct.  EPI == 3: X is Y, the activation whose ReLU is undone
     const float *X;
@@ -915,12 +916,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams 
             }
             break;
         }
+        // p.rt_fastest (tools, tile_rows = -2): row tile fastest -- all workgroups work through ONE column tile of the weight at a time
+        // (the two workgroups of a CU read the same B stages), at the price of fetching every A strip once per column tile
         if (!(tile & kSmallBit)) {
-            const int ct = (int)(tile % nct), rt = (int)(tile / nct);
+            const int ct = p.rt_fastest ? (int)(tile / rt_big) : (int)(tile % nct), rt = p.rt_fastest ? (int)(tile % rt_big) : (int)(tile / nct);
             gs_tile2<EPI, kBigRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
         } else {
             const unsigned st = tile & ~kSmallBit;
-            const int ct = (int)(st % nct), rt = (int)(st / nct);
+            const int ct = p.rt_fastest ? (int)(st / rt_small) : (int)(st % nct), rt = p.rt_fastest ? (int)(st % rt_small) : (int)(st / nct);
             gs_tile2<EPI, kSmallRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
         }
     }
@@ -1057,6 +1060,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.a_max = a->a_row_max; p.a_parts = a->a_row_parts;
     p.c_rowmax = a->c_row_max; p.c_colmax = a->c_col_max;
     p.n_queues = a->tile_rows == -8 ? kGsQueues : 1;   // (tools: tile_rows = -8 selects the per-XCD dispensers, A/B)
+    p.rt_fastest = a->tile_rows == -2 ? 1 : 0;         // (tools: tile_rows = -2: row tile fastest, A/B)
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
