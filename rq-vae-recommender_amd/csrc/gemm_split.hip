@@ -294,6 +294,10 @@ struct GemmSplitParams {
 #ifndef GS_PROBE
 #define GS_PROBE 0
 #endif
+// pad between the (piece, half) regions of gs_tile2's A stage, dwords (developer A/B: tools/ab_build.sh pad16 gemm_split.hip -DGS_REGION_PAD=16)
+#ifndef GS_REGION_PAD
+#define GS_REGION_PAD 32
+#endif
 
 // DPP row (16 lanes) reductions: after four row_shr steps lane 15 of every 16-lane row holds the row's result (zeros shifted in)
 __device__ __forceinline__ unsigned gs_row16_umax(unsigned v) {
@@ -669,8 +673,8 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
     constexpr int ROWS = 32 * TA;
     constexpr int AQ = (ROWS * 4 + kThreads - 1) / kThreads;         // float4s of A per thread and stage (2 for 128 rows, 1 for 32)
     constexpr bool kAllLive = (ROWS * 4) % kThreads == 0;
-    constexpr int kRegion = ROWS * 4 + 32;                           // dwords per [piece][half] region of the A stage (+ 128 bytes:
-                                                                     // the two halves a ds_write pair of lanes fills land in different banks)
+    constexpr int kRegion = ROWS * 4 + GS_REGION_PAD;                // dwords per [piece][half] region of the A stage (+ a pad so that
+                                                                     // the two regions a 16-lane ds_write group fills land in different banks)
     constexpr int PA = 4 * kRegion;                                  // dwords per A stage
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const int il = lane & 31, h = lane >> 5;
