@@ -4,8 +4,8 @@ The kernels behind `Quantize` / `RqVae` / `Kmeans` hold a latent row in register
 D <= 128 (csrc/rq_forward.hip, rq_backward.hip, kmeans.hip), and for the Gumbel-softmax level K <= 1024 codes with the
 LDS carve of csrc/gumbel.hip below 160 KiB.  The reference has no such limits (modules/quantize.py:54-81 takes any
 `embed_dim`, `n_embed`), and it also combines COSINE distance with GUMBEL_SOFTMAX (quantize.py:118-136), for which there is
-no kernel.  Instead of raising, those calls run the reference's EXPRESSIONS (quantize.py:110-161, init/kmeans.py:39-70) with
-torch operators on the ROCm tensors they were given, differentiated by autograd.  This is not a CPU path and not the
+no kernel.  Instead of raising, those calls run on the ROCm tensors they were given as torch operators in ROW TILES (a level's work is
+row-local: no [B, K] matrix is ever formed; the reference's formulas per row, quantize.py:110-161, init/kmeans.py:39-70), differentiated by autograd.  This is not a CPU path and not the
 oracle: the tensors stay on the device and nothing here imports `oracle/`.  Ties in the argmin are broken as torch breaks
 them on the GPU; losses follow the reference's summation expression, in the device's reduction order.
 
@@ -49,40 +49,72 @@ def kmeans_covers(D: int) -> bool:
     return 1 <= D <= 128
 
 
-# ---- reference modules/quantize.py:110-161 ---------------------------------------------------------------------------------
+# ---- one quantisation level on shapes the kernels do not take, in ROW TILES -----------------------------------------------------
+# What the reference computes per level (modules/quantize.py:110-161) is row-local: a row's distances to the K codes, its argmin, its
+# output and loss depend on that row and the codebook only.  The reference forms them for all B rows at once -- a [B, K] distance matrix
+# (and, for Gumbel-softmax, [B, K] noise, weights and their autograd copies: ~5 B K floats).  Here a tile of at most _TILE_ROWS rows goes
+# through `_level_tile` at a time, so the temporaries are [tile, K] whatever B is (10 M rows x 2048 codes would be 82 GB per matrix), and
+# autograd sees one small graph per tile.  Per row the arithmetic is the reference's (same operators in the same order: its goldens,
+# tests/golden/wide_*.npz, are reproduced to the ids), and `torch.rand` is drawn per tile in row order.
+_TILE_ROWS = 16384
+
+
+def _scores_l2(rows: Tensor, codes: Tensor) -> Tensor:
+    """[tile, K] squared distances, (|x|^2 + |c|^2) - 2 x.c in the reference's operator order (quantize.py:113-117)."""
+    return (rows ** 2).sum(dim=1, keepdim=True) + (codes.T ** 2).sum(dim=0, keepdim=True) - 2 * rows @ codes.T
+
+
+def _scores_cosine(rows: Tensor, codes: Tensor) -> Tensor:
+    """[tile, K] negative cosine similarities (quantize.py:118-124)."""
+    return -(rows / rows.norm(dim=1, keepdim=True) @ codes.T / codes.T.norm(dim=0, keepdim=True))
+
+
+def _level_tile(layer, rows: Tensor, codes: Tensor, temperature: float, modes):
+    """(emb_out, ids, emb) of one row tile; `emb` is what the commitment loss compares the rows with."""
+    QuantizeDistance, QuantizeForwardMode, rotate = modes
+    if layer.distance_mode == QuantizeDistance.L2:
+        scores = _scores_l2(rows, codes)
+    elif layer.distance_mode == QuantizeDistance.COSINE:
+        scores = _scores_cosine(rows, codes)
+    else:
+        raise Exception("Unsupported Quantize distance mode.")
+    ids = scores.detach().min(dim=1).indices
+    if not layer.training:
+        picked = layer.get_item_embeddings(ids)
+        return picked, ids, picked
+    mode = layer.forward_mode
+    if mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
+        noise = torch.rand(scores.shape, device=layer.device)                 # distributions/gumbel.py:10-11
+        soft = torch.softmax((-scores + -torch.log(-torch.log(noise + 1e-20) + 1e-20)) / temperature, dim=-1)
+        mix = soft @ codes
+        return mix, ids, mix
+    picked = layer.get_item_embeddings(ids)
+    if mode == QuantizeForwardMode.STE:
+        return rows + (picked - rows).detach(), ids, picked
+    if mode == QuantizeForwardMode.ROTATION_TRICK:
+        unit = lambda t: t / (t.norm(dim=-1, keepdim=True) + 1e-8)            # noqa: E731
+        turned = rotate(unit(rows), unit(picked), rows)
+        return turned * (picked.norm(dim=1, keepdim=True) / (rows.norm(dim=1, keepdim=True) + 1e-6)).detach(), ids, picked
+    raise Exception("Unsupported Quantize forward mode.")
+
+
 def quantize_forward(layer, x: Tensor, temperature: float):
-    """`Quantize.forward` after the lazy k-means init, as torch operators.  Returns (emb_out, ids, loss)."""
+    """`Quantize.forward` after the lazy k-means init for a level the kernels do not cover.  Returns (emb_out [B, D], ids [B], loss [B])."""
     from modules.quantize import QuantizeDistance, QuantizeForwardMode, efficient_rotation_trick_transform
     _need_gpu(x, "Quantize.forward")
     _note(f"Quantize(embed_dim={layer.embed_dim}, n_embed={layer.n_embed}, {layer.forward_mode.name}, {layer.distance_mode.name})")
-    codebook = layer.codebook()
-    if layer.distance_mode == QuantizeDistance.L2:
-        dist = (x ** 2).sum(dim=1, keepdim=True) + (codebook.T ** 2).sum(dim=0, keepdim=True) - 2 * x @ codebook.T
-    elif layer.distance_mode == QuantizeDistance.COSINE:
-        dist = -(x / x.norm(dim=1, keepdim=True) @ codebook.T / codebook.T.norm(dim=0, keepdim=True))
-    else:
-        raise Exception("Unsupported Quantize distance mode.")
-    ids = dist.detach().min(dim=1).indices
-    if not layer.training:
-        emb_out = layer.get_item_embeddings(ids)
-        return emb_out, ids, layer.quantize_loss(query=x, value=emb_out)
-    if layer.forward_mode == QuantizeForwardMode.GUMBEL_SOFTMAX:
-        u = torch.rand(dist.shape, device=layer.device)                      # distributions/gumbel.py:10-11
-        gumbel = -torch.log(-torch.log(u + 1e-20) + 1e-20)
-        weights = torch.softmax((-dist + gumbel) / temperature, dim=-1)
-        emb = weights @ codebook
-        emb_out = emb
-    elif layer.forward_mode == QuantizeForwardMode.STE:
-        emb = layer.get_item_embeddings(ids)
-        emb_out = x + (emb - x).detach()
-    elif layer.forward_mode == QuantizeForwardMode.ROTATION_TRICK:
-        emb = layer.get_item_embeddings(ids)
-        rot = efficient_rotation_trick_transform(x / (x.norm(dim=-1, keepdim=True) + 1e-8),
-                                                 emb / (emb.norm(dim=-1, keepdim=True) + 1e-8), x)
-        emb_out = rot * (emb.norm(dim=1, keepdim=True) / (x.norm(dim=1, keepdim=True) + 1e-6)).detach()
-    else:
-        raise Exception("Unsupported Quantize forward mode.")
-    return emb_out, ids, layer.quantize_loss(query=x, value=emb)
+    codes = layer.codebook()
+    modes = (QuantizeDistance, QuantizeForwardMode, efficient_rotation_trick_transform)
+    outs, ids, losses = [], [], []
+    for r0 in range(0, max(x.shape[0], 1), _TILE_ROWS):
+        rows = x[r0:r0 + _TILE_ROWS]
+        out_t, ids_t, emb_t = _level_tile(layer, rows, codes, temperature, modes)
+        outs.append(out_t)
+        ids.append(ids_t)
+        losses.append(layer.quantize_loss(query=rows, value=emb_t))
+    if len(outs) == 1:
+        return outs[0], ids[0], losses[0]
+    return torch.cat(outs, dim=0), torch.cat(ids, dim=0), torch.cat(losses, dim=0)
 
 
 # ---- reference init/kmeans.py:39-59 ----------------------------------------------------------------------------------------

@@ -624,6 +624,32 @@ def test_shapes_outside_the_kernels_match_reference(name, monkeypatch):
     np.testing.assert_allclose(q.embedding.weight.grad.cpu().numpy(), g["grad_codebook"], rtol=1e-4, atol=2e-5)
 
 
+def test_wide_level_runs_in_row_tiles(monkeypatch):
+    """rqhip/wide.py processes a level in tiles of 16 384 rows (no [B, K] matrix): a 40 000-row call equals the same call in one tile."""
+    import warnings
+    from modules.quantize import Quantize, QuantizeForwardMode
+    from rqhip import wide
+    torch.manual_seed(4)
+    x = torch.randn(40_000, 160, device="cuda")
+    for mode, training in ((QuantizeForwardMode.STE, True), (QuantizeForwardMode.ROTATION_TRICK, True), (QuantizeForwardMode.STE, False)):
+        q = Quantize(embed_dim=160, n_embed=48, do_kmeans_init=False, forward_mode=mode).cuda().train(training)
+        res = []
+        for tile in (16384, 1 << 30):
+            monkeypatch.setattr(wide, "_TILE_ROWS", tile)
+            xi = x.clone().requires_grad_(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                out = q(xi, temperature=0.2)
+            (out.embeddings.sum() + out.loss.sum()).backward()
+            res.append((out.ids.clone(), out.embeddings.detach().clone(), out.loss.detach().clone(), xi.grad.clone(), q.embedding.weight.grad.clone()))
+            q.embedding.weight.grad = None
+        (i1, e1, l1, g1, w1), (i2, e2, l2, g2, w2) = res
+        assert tuple(i1.shape) == (40_000,) and (i1 != i2).sum().item() <= 2           # (a GEMM of another height may round a near-tie differently)
+        same = i1 == i2
+        assert torch.allclose(e1[same], e2[same], rtol=1e-5, atol=1e-6) and torch.allclose(l1[same], l2[same], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(g1[same], g2[same], rtol=1e-4, atol=1e-5) and torch.allclose(w1, w2, rtol=1e-3, atol=1e-3)
+
+
 def test_wide_latents_through_rqvae_and_kmeans():
     """embed_dim = 160: k-means init (reference seeds -> reference centroids), then RqVae forward + backward level by level."""
     import warnings
