@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 430 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 440 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -329,6 +329,19 @@ int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_
 int rqhip_linear_wgrad_f16(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                            const unsigned *g_col_max, const unsigned *x_col_max, float *g_masked, float *dW,
                            void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
+
+/* The weight gradients of SEVERAL layers in one launch, for the batch sizes the reference's gin files train with (64-640 rows:
+ * configs/rqvae_ml32m.gin, rqvae_amazon.gin), where the kernels above are latency and launches (csrc/wgrad_jobs.hip).  Job i:
+ * dW[i] [N[i], K[i]] = g[i]^T x[i] with g[i] [M, N[i]] ALREADY masked by the layer's ReLU and x[i] [M, K[i]], all row-major
+ * fp32; every job has the same M.  g, x, dW, N, K are HOST arrays of n_jobs <= 8 entries (read during the call).  Every (job,
+ * 64 x 64 block of dW) is one workgroup that reduces over all M rows -- no row ranges, no workspace, no reduction launch, a fixed
+ * summation order, a job's bits independent of the other jobs -- in three-piece bf16 arithmetic: v = h + m + l exactly, the six
+ * piece products that matter (dropped terms <= 2^-23 of a product), fp32 accumulation; an entry's error is within
+ * (sqrt(M) + 8) 2^-24 of the sum of its terms' magnitudes (tests/test_gpu_wgrad.py).  Shapes: N and K multiples of 32
+ * (rqhip_linear_wgrad_jobs_supported); anything else is RQHIP_EARG.  Correct for any M; meant for M up to a few thousand. */
+int rqhip_linear_wgrad_jobs_supported(int N, int K);
+int rqhip_linear_wgrad_jobs(const float *const *g, const float *const *x, float *const *dW, const int *N, const int *K,
+                            int n_jobs, int64_t M, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The activation GEMMs of the MLPs (reference modules/encoder.py:25-38: `relu(x W^T)` forward; autograd's `g W` data

@@ -104,7 +104,12 @@ __device__ __forceinline__ void load_tile_rows(const RqFwdParams &p, long long t
     const long long row = tile * 32 + il;
     const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
     if (FULLD) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.res0 + (size_t)rowc * D + h * KSTEPS);
+        // (the lane's half-row offset is laundered: otherwise `p.res0 + h * KSTEPS` is formed once per wave as a 64-bit
+        // per-lane pointer that lives across every scan -- with the one of the emb_sum store, the two register pairs the
+        // filtered kernel spilled in rounds 4-5, profiles/r05_rq_forward_spills.txt)
+        int hv = h;
+        asm volatile("" : "+v"(hv));
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.res0 + ((size_t)rowc * D + hv * KSTEPS));
 #pragma unroll
         for (int j = 0; j < KSTEPS / 4; ++j) {
             const f32x4 q = src[j];
@@ -1065,7 +1070,9 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
                     e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
                 }
             } else if (FULLD) {
-                load_pair_row_vec<KSTEPS>(p.cb + ((size_t)l * K + bidx) * D, h, e);
+                int hv = h;   // (laundered: `p.cb + h * KSTEPS` as a per-lane pointer across the scans was spilled, see load_tile_rows)
+                asm volatile("" : "+v"(hv));
+                load_pair_row_vec<KSTEPS>(p.cb + ((size_t)l * K + bidx) * D, hv, e);
             } else {
                 const float *src = p.cb + ((size_t)l * K + bidx) * D + h;
 #pragma unroll
@@ -1135,7 +1142,9 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
         if (h == 0 && p.loss) p.loss[rowv] = lsum;
         if (p.emb_sum) {
             if (FULLD) {
-                store_pair_row<KSTEPS>(p.emb_sum + (size_t)rowv * D, h, es);
+                int hv = h;   // (laundered like the row: see load_tile_rows)
+                asm volatile("" : "+v"(hv));
+                store_pair_row<KSTEPS>(p.emb_sum + (size_t)rowv * D, hv, es);
             } else {
                 float *dst = p.emb_sum + (size_t)rowv * D + h;
 #pragma unroll

@@ -216,33 +216,82 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_kernel(const WgradParams p
 }
 
 // dW = balanced-tree sum of the row ranges' partial blocks: leaves padded with zeros to a power of two P, then
-// a[j] += a[j + s] for every j that is a multiple of 2s, s = 1, 2, 4, ... (adjacent pairs first; fixed order).
-// A workgroup owns kRedElems float4 elements of dW, stages all their partials in LDS and walks the tree there.
-constexpr int kRedElems = 4;
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, int pow2,
+// a[j] += a[j + s] for every j that is a multiple of 2s, s = 1, 2, 4, ... (adjacent pairs first; fixed order -- the oracle's
+// rqo_linear_wgrad restates it).
+//
+// A workgroup of 256 threads owns E = 256 / T float4 elements of dW; thread (q, e) sums the subtree of leaves
+// [q P/T, (q+1) P/T) of element e in registers -- eight leaves fetched at a time, each fetch a run of E consecutive float4s --
+// and the T subtree sums meet in LDS for the upper levels of the same tree.  T is chosen per launch (wgrad_reduce_threads) so
+// that every layer has >= 256 K threads in flight: the partial blocks are 4-64 MB per layer and the kernel is a pure stream.
+// (Rounds 2-4 staged P x 4 float4s per workgroup in LDS and walked the whole tree there, 4 float4s of dW per workgroup of 256
+// threads: 2.5 TB/s over the step's 320 MB of partial blocks, 126 us of a 2.63 ms step, profiles/r05_bench_kernel_stats_summary.txt.)
+__device__ __forceinline__ wg_f32x4 wg_add4(wg_f32x4 l, const wg_f32x4 r) {
+    l.x = l.x + r.x; l.y = l.y + r.y; l.z = l.z + r.z; l.w = l.w + r.w;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, int pow2, int tlog,
                                                            size_t nk4, float *__restrict__ dw) {
-    extern __shared__ __attribute__((aligned(16))) char red_smem[];
-    wg_f32x4 *a = reinterpret_cast<wg_f32x4 *>(red_smem);   // [pow2][kRedElems]
-    const size_t base = (size_t)blockIdx.x * kRedElems;
-    const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(part);
-    for (int i = threadIdx.x; i < pow2 * kRedElems; i += 256) {
-        const int k = i / kRedElems, e = i % kRedElems;
-        a[i] = (k < msplit && base + e < nk4) ? src[(size_t)k * nk4 + base + e] : wg_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    for (int s = 1; s < pow2; s <<= 1) {
-        const int pairs = pow2 / (2 * s) * kRedElems;
-        for (int i = threadIdx.x; i < pairs; i += 256) {
-            const int j = (i / kRedElems) * 2 * s, e = i % kRedElems;
-            wg_f32x4 l = a[j * kRedElems + e];
-            const wg_f32x4 r = a[(j + s) * kRedElems + e];
-            l.x = l.x + r.x; l.y = l.y + r.y; l.z = l.z + r.z; l.w = l.w + r.w;
-            a[j * kRedElems + e] = l;
+    __shared__ wg_f32x4 a[256];   // [q][e]
+    const int T = 1 << tlog, E = 256 >> tlog;
+    const int e = threadIdx.x & (E - 1), q = threadIdx.x >> (8 - tlog);
+    const size_t elem = (size_t)blockIdx.x * E + e;
+    const bool live = elem < nk4;
+    const int lpt = pow2 >> tlog;                 // leaves per thread (a power of two >= 1)
+    const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(part) + elem;
+    const wg_f32x4 zero = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kLevels = 10;                   // subtrees of up to 8 << 10 leaves per thread
+    wg_f32x4 st[kLevels];
+#pragma unroll
+    for (int j = 0; j < kLevels; ++j) st[j] = zero;
+    wg_f32x4 sum = zero;
+    const int groups = lpt >= 8 ? lpt >> 3 : 1;
+    for (int g = 0; g < groups; ++g) {
+        const int k0 = q * lpt + g * 8;
+        wg_f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (live && i < lpt && k0 + i < msplit) ? src[(size_t)(k0 + i) * nk4] : zero;
+        // the levels of the tree inside this group (only those the subtree really has: no additions of padding beyond P)
+        if (lpt >= 2) {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) v[i] = wg_add4(v[i], v[i + 1]);
         }
+        if (lpt >= 4) {
+            v[0] = wg_add4(v[0], v[2]);
+            v[4] = wg_add4(v[4], v[6]);
+        }
+        if (lpt >= 8) v[0] = wg_add4(v[0], v[4]);
+        // groups combine like a binary counter: group g closes every level whose bit of g is set (left + right)
+        wg_f32x4 c = v[0];
+        bool placed = false;
+#pragma unroll
+        for (int j = 0; j < kLevels; ++j) {
+            if (!placed) {
+                if ((g >> j) & 1) {
+                    c = wg_add4(st[j], c);
+                } else {
+                    st[j] = c;
+                    placed = true;
+                }
+            }
+        }
+        sum = c;   // (after the last group -- all ones -- c has climbed to the subtree's root)
+    }
+    a[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 1; s < T; s <<= 1) {
+        if ((q & (2 * s - 1)) == 0) a[threadIdx.x] = wg_add4(a[threadIdx.x], a[(q + s) * E + e]);
         __syncthreads();
     }
-    if (threadIdx.x < kRedElems && base + threadIdx.x < nk4)
-        reinterpret_cast<wg_f32x4 *>(dw)[base + threadIdx.x] = a[threadIdx.x];
+    if (q == 0 && live) reinterpret_cast<wg_f32x4 *>(dw)[elem] = a[e];
+}
+
+// log2 of the subtrees per element: enough threads for a streaming launch, never more subtrees than leaves
+static int wgrad_reduce_tlog(size_t nk4, int pow2) {
+    int tlog = 2;
+    while (tlog < 6 && (nk4 << tlog) < (size_t)256 * 1024) tlog += 2;
+    while ((1 << tlog) > pow2) --tlog;
+    return tlog;
 }
 
 struct WgradPlan {
@@ -403,9 +452,10 @@ static int linear_wgrad_impl(const float *g, const float *y, const float *x, int
     if (rc) { profile_end(s); return rc; }
     if (pl.msplit > 1) {
         const size_t nk4 = (size_t)N * K / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + kRedElems - 1) / kRedElems)), dim3(256),
-                           (size_t)pl.pow2 * kRedElems * sizeof(wg_f32x4), s, reinterpret_cast<const float *>(workspace),
-                           pl.msplit, pl.pow2, nk4, dW);
+        const int tlog = wgrad_reduce_tlog(nk4, pl.pow2);
+        const size_t per_wg = (size_t)256 >> tlog;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + per_wg - 1) / per_wg)), dim3(256), 0, s,
+                           reinterpret_cast<const float *>(workspace), pl.msplit, pl.pow2, tlog, nk4, dW);
         RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
     }
     profile_end(s);

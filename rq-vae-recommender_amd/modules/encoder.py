@@ -167,10 +167,18 @@ class _MLPStack(torch.autograd.Function):
         off = 0
         premasked = not relus[n - 1]      # is g already masked by this layer's ReLU (or is there none)?
         gws = [None] * n
+        # batches below the split kernels' row count: every weight gradient of the stack in ONE launch after the data gradients
+        # (csrc/wgrad_jobs.hip; same bits as the per-layer path, which runs the same kernel with one job)
+        deferred = g.is_cuda and _lin.wgrad_jobs_ok(g.shape[0], [tuple(w.shape) for i, w in enumerate(weights) if need_w[i]])
+        pending = []
         for i in range(n - 1, -1, -1):
             w, a = weights[i], acts[i]
             y = acts[i + 1] if (relus[i] and not premasked) else None
-            if need_w[i]:
+            if need_w[i] and deferred:
+                if y is not None:
+                    g, gsc = torch.ops.aten.threshold_backward(g, y, 0.0), _lin.Scales()
+                pending.append((i, g, a, _grad_sink(w)))
+            elif need_w[i]:
                 sink = _grad_sink(w)
                 gw, g, gsc = _lin.weight_grad(g, y, a, w, out=sink, want_masked=need_in[i], g_scales=gsc, x_scales=scs[i],
                                               premasked=premasked)
@@ -195,6 +203,10 @@ class _MLPStack(torch.autograd.Function):
             else:
                 g, gsc = g.mm(w), _lin.Scales()
                 premasked = not lower_relu
+        if pending:
+            outs = [sk if sk is not None else torch.empty_like(weights[i]) for (i, _, _, sk) in pending]
+            for (i, _, _, sk), gw in zip(pending, ops.linear_wgrad_jobs([(gm, a) for _, gm, a, _ in pending], outs=outs)):
+                gws[i] = _adopt(gw, sk)
         return (g if ctx.needs_input_grad[0] else None), None, None, None, *gws
 
 

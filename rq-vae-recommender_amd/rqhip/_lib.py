@@ -92,6 +92,8 @@ SIGNATURES = {
     "rqhip_linear_wgrad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_linear_wgrad_ex": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, C.c_uint, _vp]),
     "rqhip_linear_wgrad_f16": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_linear_wgrad_jobs_supported": (_int, [_int, _int]),
+    "rqhip_linear_wgrad_jobs": (_int, [_vp, _vp, _vp, C.POINTER(_int), C.POINTER(_int), _int, _i64, _vp]),
     "rqhip_gemm_split_supported": (_int, [_int, _int]),
     "rqhip_weight_image_bytes": (_sz, [_int, _int, _int]),
     "rqhip_weight_images": (_int, [C.POINTER(ImageJob), _int, _vp]),

@@ -175,6 +175,25 @@ def wgrad_f16_ok(n_out: int, n_in: int, rows: int = _SPLIT_MIN_ROWS) -> bool:
     return bool(f16() and rows >= _SPLIT_MIN_ROWS and n_out % 128 == 0 and n_in % 128 == 0 and (n_out % 256 == 0 or n_in % 256 == 0))
 
 
+_WGRAD_JOBS = True
+
+
+def use_wgrad_jobs(on: bool = True) -> bool:
+    """Batches below the split kernels' 4096 rows -- the sizes the reference's gin files train with -- take the job-table
+    weight-gradient kernel (csrc/wgrad_jobs.hip: every layer of an MLP stack in one launch, no row ranges, no reduction launches;
+    default on).  Off: round 4's per-layer kernels (A/B: tools/bench_small_batch.py --no-jobs).  Returns the previous setting."""
+    global _WGRAD_JOBS
+    before, _WGRAD_JOBS = _WGRAD_JOBS, bool(on)
+    return before
+
+
+def wgrad_jobs_ok(rows: int, shapes) -> bool:
+    """Do the weight gradients of layers `shapes` = [(n_out, n_in), ...] over `rows` batch rows run as ONE job-table launch?"""
+    shapes = list(shapes)
+    return bool(_WGRAD_JOBS and _ARITH != _FP32 and 0 < rows < _SPLIT_MIN_ROWS and 0 < len(shapes) <= ops.WGRAD_JOBS_MAX
+                and all(ops.linear_wgrad_jobs_supported(n, k) for n, k in shapes))
+
+
 def images(jobs: List[Tuple[Tensor, bool]]) -> List[Tensor]:
     """The weight images of `jobs` = [(w, transpose), ...] in the current arithmetic, one launch.  Rebuilt at EVERY forward:
     a first version cached an image per `w._version` -- and trained on stale weights: the fused AdamW update (and any
@@ -243,6 +262,10 @@ def weight_grad(g: Tensor, y: Optional[Tensor], x: Tensor, w: Tensor, *, out: Op
         return gw, gp, None
     if premasked:
         y = None
+    if g.is_cuda and wgrad_jobs_ok(g.shape[0], [tuple(w.shape)]):     # small batches: the job-table kernel with one job
+        gp = g if y is None else torch.ops.aten.threshold_backward(g, y, 0.0)
+        gw = ops.linear_wgrad_jobs([(gp, x)], outs=[out] if out is not None else None)[0]
+        return gw, gp, (g_scales if y is None else None)
     if wgrad_f16_ok(w.shape[0], w.shape[1], g.shape[0]):
         if y is not None:   # mask + maxima in one pass; the weight-gradient kernel then runs without a mask
             r, c, g = ops.maxima(g, y, rows=want_masked, cols=True, write_masked=True)

@@ -6,6 +6,7 @@ rejected loudly: the HIP kernels are the product path, there is no host fallback
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import NamedTuple, Optional
 
 import torch
@@ -562,6 +563,47 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
                                          _lib.WGRAD_FP32 if exact_fp32 else 0, _stream())
             check(rc, "rqhip_linear_wgrad_ex")
     return dw, (g if y is None else gm)
+
+
+def linear_wgrad_jobs_supported(n_out: int, n_in: int) -> bool:
+    return bool(_lib.lib().rqhip_linear_wgrad_jobs_supported(int(n_out), int(n_in)))
+
+
+WGRAD_JOBS_MAX = 8
+
+
+def linear_wgrad_jobs(jobs, outs=None):
+    """The weight gradients of several layers in ONE launch (rqhip_linear_wgrad_jobs, csrc/wgrad_jobs.hip): `jobs` =
+    [(g [M, N_i] ALREADY masked by the layer's ReLU, x [M, K_i]), ...], at most 8, one M; `outs[i]`: a contiguous fp32
+    [N_i, K_i] tensor to receive dW_i (or None).  Returns [dW_i].  The small-batch path of the MLP stacks."""
+    if not jobs:
+        return []
+    if len(jobs) > WGRAD_JOBS_MAX:
+        raise RqHipError(f"linear_wgrad_jobs: at most {WGRAD_JOBS_MAX} jobs per launch (got {len(jobs)})")
+    gs = [_f32c(g, "g") for g, _ in jobs]
+    xs = [_f32c(x, "x") for _, x in jobs]
+    _need_gpu(*gs, *xs)
+    M, dev = gs[0].shape[0], gs[0].device
+    dws = []
+    for i, (g, x) in enumerate(zip(gs, xs)):
+        if g.dim() != 2 or x.dim() != 2 or g.shape[0] != M or x.shape[0] != M or g.device != dev or x.device != dev:
+            raise RqHipError(f"linear_wgrad_jobs: job {i}: g {tuple(g.shape)}, x {tuple(x.shape)}; every job has M = {M} rows")
+        N, K = g.shape[1], x.shape[1]
+        out = outs[i] if outs is not None else None
+        if out is not None and (tuple(out.shape) != (N, K) or out.dtype != torch.float32 or not out.is_contiguous()):
+            raise RqHipError("linear_wgrad_jobs: `outs[i]` must be a contiguous float32 [N,K] tensor")
+        dws.append(out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dev))
+    if M == 0:          # no rows: every gradient is zero (and an empty tensor has no address to hand over)
+        for d in dws:
+            d.zero_()
+        return dws
+    n = len(jobs)
+    vp, ci = C.c_void_p * n, C.c_int * n
+    with torch.cuda.device(dev):
+        rc = _lib.lib().rqhip_linear_wgrad_jobs(vp(*[_ptr(g) for g in gs]), vp(*[_ptr(x) for x in xs]), vp(*[_ptr(d) for d in dws]),
+                                                ci(*[g.shape[1] for g in gs]), ci(*[x.shape[1] for x in xs]), n, M, _stream())
+        check(rc, "rqhip_linear_wgrad_jobs")
+    return dws
 
 
 def gemm_split_supported(n_cols: int, n_red: int) -> bool:

@@ -501,20 +501,22 @@ def test_split_gemms_follow_the_optimizer():
         assert abs(la - lb) <= 2e-5 * abs(lb), (a, b)
 
 
+@pytest.mark.parametrize("rows", [9000, 640])
 @pytest.mark.parametrize("arith", ["f16x2", "bf16x3"])
-def test_mlp_stack_node_equals_the_per_layer_functions_bit_for_bit(arith):
+def test_mlp_stack_node_equals_the_per_layer_functions_bit_for_bit(arith, rows):
     """modules/encoder.py: the whole-stack autograd node (weight images in one launch, scales handed from epilogue to epilogue,
     the ReLU backward in the data-gradient epilogues) runs the arithmetic of the per-layer Functions (one node per layer, scales
     from maxima passes, mask in its own pass): the same maxima give the same exponents, so outputs and every gradient are
-    bit-identical."""
+    bit-identical.  rows = 640: the small-batch path -- library GEMMs, and the job-table weight gradients (csrc/wgrad_jobs.hip), one
+    launch per stack in the node, one launch per layer in the Functions: same kernel, same bits."""
     from modules.encoder import MLP
     from rqhip import linear
     before = linear.use_arith(arith)
     try:
         torch.manual_seed(5)
         mlp = MLP(768, [512, 256, 128], 32).cuda()
-        x = torch.nn.functional.normalize(torch.randn(9000, 768, device="cuda"), dim=-1).requires_grad_(True)
-        gout = torch.randn(9000, 32, device="cuda") * 1e-4
+        x = torch.nn.functional.normalize(torch.randn(rows, 768, device="cuda"), dim=-1).requires_grad_(True)
+        gout = torch.randn(rows, 32, device="cuda") * 1e-4
 
         def run(fn):
             for p in mlp.parameters():
@@ -528,8 +530,8 @@ def test_mlp_stack_node_equals_the_per_layer_functions_bit_for_bit(arith):
         for u, v in zip(a, b):
             assert torch.equal(u, v)
         dec = MLP(32, [128, 256, 512], 768).cuda()            # the decoder's shape: its input needs a gradient
-        z = torch.randn(9000, 32, device="cuda", requires_grad=True)
-        g2 = torch.randn(9000, 768, device="cuda") * 1e-5
+        z = torch.randn(rows, 32, device="cuda", requires_grad=True)
+        g2 = torch.randn(rows, 768, device="cuda") * 1e-5
         outs = []
         for fn in (dec._run, dec._run_layerwise):
             for p in dec.parameters():

@@ -105,6 +105,60 @@ def test_wgrad_split_ragged_rows_vs_fp64(M, N, K, mask, kind):
     assert ((dw.double() - ref).abs() <= bound).all(), float(((dw.double() - ref).abs() / bound).max())
 
 
+@pytest.mark.parametrize("M", [1, 17, 64, 100, 640, 641, 1000, 3000])
+def test_wgrad_jobs_whole_stack_vs_fp64(M):
+    """csrc/wgrad_jobs.hip: the weight gradients of a whole MLP stack in one launch (the small-batch path).  Every block shape
+    (64 x 64, 32 x 128, 128 x 32), row counts that do not fill a 64-row stage, adversarial magnitudes (twelve decades over the
+    rows of g and the columns of x): elementwise within a few ulps of the sum of the terms' magnitudes, about as exact as the
+    library's fp32 GEMM on plain operands, bit-reproducible run to run, and a job's result does not depend on the other jobs of its launch."""
+    from rqhip import ops
+    for layers in (LAYERS[:4], LAYERS[4:]):
+        g = torch.Generator().manual_seed(M)
+        jobs = []
+        for N, K in layers:
+            gy = (torch.randn(M, N, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (M, 1), generator=g).float())).cuda()
+            gy = gy * (torch.rand(M, N, generator=g) > 0.5).cuda()                       # as a ReLU mask leaves it
+            x = (torch.randn(M, K, generator=g) * torch.pow(10.0, torch.randint(-6, 7, (1, K), generator=g).float())).cuda()
+            jobs.append((gy, x))
+        sink = torch.empty(layers[0], device="cuda")
+        dws = ops.linear_wgrad_jobs(jobs, outs=[sink] + [None] * (len(jobs) - 1))
+        assert dws[0] is sink
+        again = ops.linear_wgrad_jobs(jobs)
+        for (gy, x), dw, dw2 in zip(jobs, dws, again):
+            assert torch.equal(dw, dw2)
+            assert torch.equal(dw, ops.linear_wgrad_jobs([(gy, x)])[0])                  # alone in its launch: same bits
+            ref = gy.double().t().mm(x.double())
+            bound = gy.double().abs().t().mm(x.double().abs()) * (M ** 0.5 + 8) * 2.0 ** -24 + 1e-30
+            assert ((dw.double() - ref).abs() <= bound).all(), (tuple(dw.shape), float(((dw.double() - ref).abs() / bound).max()))
+        # on operands of one scale (what a training step feeds it): about the library fp32 GEMM's error against fp64 -- the
+        # dropped piece products add at most one fp32 rounding per term to the accumulation's own
+        g = torch.Generator().manual_seed(M + 1)
+        jobs = [(torch.randn(M, N, generator=g).cuda() * 1e-3, torch.randn(M, K, generator=g).cuda()) for N, K in layers]
+        for (gy, x), dw in zip(jobs, ops.linear_wgrad_jobs(jobs)):
+            ref = gy.double().t().mm(x.double())
+            scale = ref.abs().max().item() + 1e-300
+            err = (dw.double() - ref).abs().max().item() / scale
+            lib = (gy.t().mm(x).double() - ref).abs().max().item() / scale
+            assert err <= max(2 * lib, 3e-7), (tuple(dw.shape), err, lib)
+
+
+def test_wgrad_jobs_arguments():
+    from rqhip import ops
+    from rqhip._lib import RqHipError
+    assert ops.linear_wgrad_jobs([]) == []
+    assert ops.linear_wgrad_jobs_supported(512, 768) and ops.linear_wgrad_jobs_supported(32, 128) and ops.linear_wgrad_jobs_supported(128, 32)
+    assert ops.linear_wgrad_jobs_supported(32, 32) and not ops.linear_wgrad_jobs_supported(48, 64) and not ops.linear_wgrad_jobs_supported(64, 0)
+    g, x = torch.randn(8, 64, device="cuda"), torch.randn(8, 64, device="cuda")
+    with pytest.raises(RqHipError):
+        ops.linear_wgrad_jobs([(g, x)] * 9)
+    with pytest.raises(RqHipError):
+        ops.linear_wgrad_jobs([(g, torch.randn(9, 64, device="cuda"))])
+    with pytest.raises(RqHipError):
+        ops.linear_wgrad_jobs([(torch.randn(8, 48, device="cuda"), x)])
+    dw = ops.linear_wgrad_jobs([(torch.zeros(0, 64, device="cuda"), torch.zeros(0, 64, device="cuda"))])[0]   # no rows: zeros
+    assert dw.shape == (64, 64) and not dw.any()
+
+
 def _col_worst_mantissa(shape, g):
     """tests/test_gpu_gemm_split.py:worst_mantissa: every value on the coherent worst case of the 11 + 11-bit split"""
     a = torch.randint(0, 1024, shape, generator=g).double()
@@ -148,13 +202,15 @@ def test_wgrad_f16_operand_families_vs_fp64(N, K):
     assert (dw.double() - ref).abs().max().item() <= max((gp.t().mm(x).double() - ref).abs().max().item(), 2e-7 * ref.abs().max().item())
 
 
-def test_mlp_backward_matches_torch_autograd():
-    """The module path (modules/encoder.py) with the fused kernels vs the same MLP as plain torch ops."""
+@pytest.mark.parametrize("rows", [5000, 640, 64])
+def test_mlp_backward_matches_torch_autograd(rows):
+    """The module path (modules/encoder.py) with the fused kernels vs the same MLP as plain torch ops: a batch the split kernels
+    take, and the reference's own batch sizes (the job-table weight gradients, csrc/wgrad_jobs.hip)."""
     from modules.encoder import MLP
     torch.manual_seed(3)
     mlp = MLP(768, [512, 256, 128], 32).cuda()
-    x = torch.randn(5000, 768, device="cuda", requires_grad=True)
-    gout = torch.randn(5000, 32, device="cuda")
+    x = torch.randn(rows, 768, device="cuda", requires_grad=True)
+    gout = torch.randn(rows, 32, device="cuda")
     mlp(x).backward(gout)
     got = [p.grad.clone() for p in mlp.parameters()] + [x.grad.clone()]
     for p in mlp.parameters():

@@ -3,6 +3,7 @@
 same step replayed from a hipGraph (torch.cuda.CUDAGraph).
   python tools/bench_small_batch.py            # rqvae_amazon.gin: batch 640, D = 32, STE
   python tools/bench_small_batch.py c3         # rqvae_ml32m.gin (BASELINE config 3): batch 64, D = 64, rotation trick, lr 1e-4
+  python tools/bench_small_batch.py --no-jobs  # A/B: the per-layer weight-gradient kernels instead of the job table (csrc/wgrad_jobs.hip)
   python tools/bench_small_batch.py --json     # both, one JSON line on stdout (bench.py's `secondary.small_batch` runs this in a
                                                # subprocess with a time limit: a graph replay that hangs cannot take the bench line with it)"""
 import json
@@ -21,7 +22,10 @@ from rqhip import tuning  # noqa: E402
 
 tuning.enable_tuned_gemms()
 JSON = "--json" in sys.argv
-ARGS = [a for a in sys.argv[1:] if a != "--json"]
+if "--no-jobs" in sys.argv:      # A/B: round 4's per-layer weight-gradient kernels instead of csrc/wgrad_jobs.hip
+    from rqhip import linear as _linear
+    _linear.use_wgrad_jobs(False)
+ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs")]
 
 
 def timeit(fn, n=200):
