@@ -44,13 +44,32 @@ struct RqBwdParams {
 #define RQ_PROBE(bit) 0
 #endif
 
-template <int KSTEPS, int MODE>
+// VEC: D == 2 * KSTEPS and every row pointer 16-byte aligned -> rows move as float4 half-rows + v_permlane32_swap (rq_rowmath.h)
+// instead of one predicated dword per feature.  Same values in the same registers, so the same result bits.  (At batch 64, D = 64,
+// rotation trick -- the reference's rqvae_ml32m.gin -- the dword form was 58 us for TWO waves of work: ~800 predicated loads per lane,
+// each in its own branch, profiles/r05_small_batch_kernels.txt.)
+template <int KSTEPS, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
     const int lane = threadIdx.x & 63;
     const int il = lane & 31, h = lane >> 5;
     const int D = p.D, L = p.L, K = p.K;
     const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
     const long long gw = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    auto load_row = [&](const float *base, float(&v)[KSTEPS]) {
+        if constexpr (VEC) load_pair_row_vec<KSTEPS>(base, h, v);
+        else load_pair_row<KSTEPS>(base, D, h, v);
+    };
+    auto store_row = [&](float *base, const float(&v)[KSTEPS]) {   // (callers test the row)
+        if constexpr (VEC) {
+            store_pair_row<KSTEPS>(base, h, v);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 2 * kk + h;
+                if (d < D) base[d] = v[kk];
+            }
+        }
+    };
 
     for (long long tile = gw; tile < p.n_tiles; tile += waves) {
         const long long row = tile * 32 + il;
@@ -58,20 +77,17 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
         const long long rc = ok ? row : p.B - 1;
 
         float r[KSTEPS], e[KSTEPS], o[KSTEPS];
-        load_pair_row<KSTEPS>(p.res0 + (size_t)rc * D, D, h, r);
+        load_row(p.res0 + (size_t)rc * D, r);
         // pass 1: replay res_1 .. res_{L-1}
         for (int l = 0; l + 1 < L; ++l) {
             const long long id = p.ids[(size_t)l * p.B + rc];
-            load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + id) * D, D, h, e);
+            load_row(p.cb + ((size_t)l * K + id) * D, e);
             const float xsq = (MODE == RQHIP_MODE_ROTATION) ? pair_sumsq<KSTEPS>(r) : 0.0f;
             level_output<KSTEPS, MODE>(r, e, xsq, o);
             float *dst = p.ws + ((size_t)(l + 1) * p.B + rc) * D;
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                r[kk] = r[kk] - o[kk];
-                const int d = 2 * kk + h;
-                if (ok && d < D) dst[d] = r[kk];
-            }
+            for (int kk = 0; kk < KSTEPS; ++kk) r[kk] = r[kk] - o[kk];
+            if (ok) store_row(dst, r);
         }
         // r now holds res_{L-1}
         const float gl = p.g_loss ? p.g_loss[rc] : 0.0f;
@@ -82,23 +98,52 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
         for (int l = L - 1; l >= 0; --l) {
             if (l != L - 1) {
                 const float *src = (l == 0) ? p.res0 + (size_t)rc * D : p.ws + ((size_t)l * p.B + rc) * D;
-                load_pair_row<KSTEPS>(src, D, h, r);
+                load_row(src, r);
             }
             const long long id = p.ids[(size_t)l * p.B + rc];
-            load_pair_row<KSTEPS>(p.cb + ((size_t)l * K + id) * D, D, h, e);
+            load_row(p.cb + ((size_t)l * K + id) * D, e);
             const size_t lrow = ((size_t)l * p.B + rc) * D;
             float A[KSTEPS], gr[KSTEPS];
+            if constexpr (VEC) {
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const int d = 2 * kk + h;
-                float a = 0.0f;
-                if (p.g_embs && d < D) a = p.g_embs[lrow + d];
-                if (p.g_embsum) a = a + ((d < D) ? p.g_embsum[(size_t)rc * D + d] : 0.0f);
-                A[kk] = a - G[kk];
-                gr[kk] = (p.g_resid && d < D) ? p.g_resid[lrow + d] : 0.0f;
+                for (int kk = 0; kk < KSTEPS; ++kk) A[kk] = gr[kk] = 0.0f;
+                if (p.g_embs) load_row(p.g_embs + lrow, A);
+                if (p.g_embsum) {
+                    load_row(p.g_embsum + (size_t)rc * D, gr);   // (gr as the temporary: it is loaded for real below)
+#pragma unroll
+                    for (int kk = 0; kk < KSTEPS; ++kk) A[kk] = A[kk] + gr[kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    A[kk] = A[kk] - G[kk];
+                    gr[kk] = 0.0f;
+                }
+                if (p.g_resid) load_row(p.g_resid + lrow, gr);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const int d = 2 * kk + h;
+                    float a = 0.0f;
+                    if (p.g_embs && d < D) a = p.g_embs[lrow + d];
+                    if (p.g_embsum) a = a + ((d < D) ? p.g_embsum[(size_t)rc * D + d] : 0.0f);
+                    A[kk] = a - G[kk];
+                    gr[kk] = (p.g_resid && d < D) ? p.g_resid[lrow + d] : 0.0f;
+                }
             }
             float *dE = (p.g_cb && p.atomic_scatter) ? p.g_cb + ((size_t)l * K + id) * D : nullptr;
             float *V = (p.g_cb && !p.atomic_scatter) ? p.ws + lrow : nullptr;
+            float vv[VEC ? KSTEPS : 1];   // VEC: this level's codeword-gradient vector of the row, stored as a row below
+            auto emit = [&](int kk, float v) {
+                if constexpr (VEC) {
+                    vv[kk] = v;
+                } else {
+                    const int d = 2 * kk + h;
+                    if (ok && d < D) {
+                        if (dE) atomicAdd(dE + d, v);
+                        if (V) V[d] = v;
+                    }
+                }
+            };
             if (MODE == RQHIP_MODE_ROTATION) {
                 float w[KSTEPS], u[KSTEPS], q[KSTEPS], scale;
                 const float xsq = pair_sumsq<KSTEPS>(r);
@@ -110,42 +155,32 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(const RqBwdParams p) {
                     const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
                     const float embg = (2.0f * (e[kk] - r[kk])) * gl;
                     G[kk] = ((gr[kk] + G[kk]) + lin) + commit;
-                    const int d = 2 * kk + h;
-                    if (ok && d < D) {
-                        if (dE) atomicAdd(dE + d, embg);
-                        if (V) V[d] = embg;
-                    }
+                    emit(kk, embg);
                 }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < KSTEPS; ++kk) {
                     const float commit = (2.0f * p.beta) * (r[kk] - e[kk]) * gl;
                     const float embg = (2.0f * (e[kk] - r[kk])) * gl;
-                    const int d = 2 * kk + h;
                     if (MODE == RQHIP_MODE_EVAL) {
                         const float contrib = A[kk] + embg;
                         G[kk] = (gr[kk] + G[kk]) + commit;
-                        if (ok && d < D) {
-                            if (dE) atomicAdd(dE + d, contrib);
-                            if (V) V[d] = contrib;
-                        }
+                        emit(kk, contrib);
                     } else {
                         G[kk] = ((gr[kk] + G[kk]) + A[kk]) + commit;
-                        if (ok && d < D) {
-                            if (dE) atomicAdd(dE + d, embg);
-                            if (V) V[d] = embg;
-                        }
+                        emit(kk, embg);
                     }
                 }
             }
-        }
-        if (ok && p.g_res0) {
+            if constexpr (VEC) {
+                if (ok && dE) {
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const int d = 2 * kk + h;
-                if (d < D) p.g_res0[(size_t)row * D + d] = G[kk];
+                    for (int kk = 0; kk < KSTEPS; ++kk) atomicAdd(dE + 2 * kk + h, vv[kk]);
+                }
+                if (ok && V) store_row(V, vv);
             }
         }
+        if (ok && p.g_res0) store_row(p.g_res0 + (size_t)row * D, G);
     }
 }
 
@@ -752,6 +787,55 @@ __global__ __launch_bounds__(256) void rq_cbgrad_scatter_kernel(const float *__r
     }
 }
 
+// ---- kernel 2s: the same sum for a SMALL batch, one workgroup per level, no partial tables ------------------------------
+// The scatter kernel above zeroes, fills and writes out a [levels, K, D + 1] LDS table per workgroup and a third kernel adds the
+// workgroups' tables: for the 64 rows of the reference's rqvae_ml32m.gin that is 2 x 18 + 5 us of moving zeros
+// (profiles/r05_small_batch_kernels.txt).  Here workgroup l keeps level l's [K, D] table, walks the batch in blocks of 256 rows and
+// adds every row's vector to its code's table row with the fused kernel's owner-computes scheme (cb_accumulate: wave id mod 8
+// owns the code, rows in ascending order -- a fixed summation order, no atomics), then writes the table to g_cb[l] itself.
+constexpr size_t kScatterLdsBudgetSmall = 150 * 1024;
+constexpr int kSmallCbRows = 256;
+constexpr long long kSmallCbMaxB = 2048;
+static size_t small_cb_lds(int D, int K) {
+    return ((size_t)K * D + (size_t)kSmallCbRows * (D + 1)) * sizeof(float) + (size_t)kSmallCbRows * sizeof(int);
+}
+static bool small_cb_fits(long long B, int D, int K) { return B <= kSmallCbMaxB && D <= 64 && small_cb_lds(D, K) <= kScatterLdsBudgetSmall; }
+
+__global__ __launch_bounds__(kFusedThreads) void rq_cbgrad_small_kernel(const float *__restrict__ V, const int64_t *__restrict__ ids,
+                                                                        long long B, int D, int K, float *__restrict__ g_cb) {
+    extern __shared__ __attribute__((aligned(16))) float small_smem[];
+    float *tab = small_smem;                                   // [K][D]
+    float *stage = tab + (size_t)K * D;                        // [kSmallCbRows][D + 1]
+    int *ids_s = reinterpret_cast<int *>(stage + (size_t)kSmallCbRows * (D + 1));
+    const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (K * D is a multiple of 4 and the table 16-byte aligned whenever D is a multiple of 4; else one float at a time)
+    const bool by4 = (D & 3) == 0;
+    if (by4) {
+        for (int e = threadIdx.x; e < K * D / 4; e += kFusedThreads) reinterpret_cast<rq_f32x4 *>(tab)[e] = rq_f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        for (int e = threadIdx.x; e < K * D; e += kFusedThreads) tab[e] = 0.0f;
+    }
+    for (long long base = 0; base < B; base += kSmallCbRows) {
+        const int rows = (int)((B - base < kSmallCbRows) ? B - base : kSmallCbRows);
+        __syncthreads();   // the table is zeroed / the previous block's rows are consumed
+        for (int e = threadIdx.x; e < rows * D; e += kFusedThreads) {
+            const int r = e / D, d = e - r * D;
+            stage[(size_t)r * (D + 1) + d] = V[((size_t)l * B + base + r) * D + d];
+        }
+        for (int r = threadIdx.x; r < rows; r += kFusedThreads) ids_s[r] = (int)ids[(size_t)l * B + base + r];
+        __syncthreads();
+        cb_accumulate(tab, stage, ids_s, rows, D, wave, lane);
+    }
+    __syncthreads();
+    float *out = g_cb + (size_t)l * K * D;
+    if (by4 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+        for (int e = threadIdx.x; e < K * D / 4; e += kFusedThreads)
+            reinterpret_cast<rq_f32x4 *>(out)[e] = reinterpret_cast<const rq_f32x4 *>(tab)[e];
+    } else {
+        for (int e = threadIdx.x; e < K * D; e += kFusedThreads) out[e] = tab[e];
+    }
+}
+
 // ---- kernel 3: fixed-order sum of the per-workgroup partials ------------------------------------------------
 // 64 outputs per 256-thread block; thread (seg, j) sums partials g = seg, seg+4, ... in ascending order, the four
 // segment sums are combined as ((s0 + s1) + (s2 + s3)).
@@ -837,17 +921,17 @@ static int scatter_wgs(long long B) {
 
 static bool scatter_fits_lds(int D, int K) { return (size_t)K * (D + 1) * sizeof(float) <= kScatterLdsBudget; }
 
-template <int KSTEPS>
-static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
+template <int KSTEPS, bool VEC>
+static int launch_bwd_v(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
     switch (mode) {
         case RQHIP_MODE_EVAL:
-            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_EVAL>), dim3(grid), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_EVAL, VEC>), dim3(grid), dim3(256), 0, s, p);
             break;
         case RQHIP_MODE_STE:
-            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_STE>), dim3(grid), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_STE, VEC>), dim3(grid), dim3(256), 0, s, p);
             break;
         case RQHIP_MODE_ROTATION:
-            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_ROTATION>), dim3(grid), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((rq_backward_kernel<KSTEPS, RQHIP_MODE_ROTATION, VEC>), dim3(grid), dim3(256), 0, s, p);
             break;
         default:
             set_error("rq_backward: unsupported mode %d", mode);
@@ -855,6 +939,11 @@ static int launch_bwd(const RqBwdParams &p, int mode, int grid, hipStream_t s) {
     }
     RQ_CHECK_LAUNCH("rq_backward_kernel");
     return 0;
+}
+// vec: D == 2 * KSTEPS and every row pointer of the call 16-byte aligned
+template <int KSTEPS>
+static int launch_bwd(const RqBwdParams &p, int mode, int grid, bool vec, hipStream_t s) {
+    return vec ? launch_bwd_v<KSTEPS, true>(p, mode, grid, s) : launch_bwd_v<KSTEPS, false>(p, mode, grid, s);
 }
 
 }  // namespace rqhip
@@ -1022,7 +1111,8 @@ static int rq_backward_impl(const float *res0, int64_t B, int D, const float *co
     if (fused_fits(D, K, L)) {
         const int G = fused_wgs(B);
         float *partial = p.ws + (size_t)L * (size_t)B * (size_t)D;
-        const bool vec = D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) &&
+        // (D = 128 with the rotation trick keeps the dword form: the row form spills more there)
+    const bool vec = !(D > 64 && mode == RQHIP_MODE_ROTATION) && D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) &&
                          al16(g_resid) && al16(g_res0);
         // one launch per group of levels whose tables fit LDS together (all of them for 3 x 256 x 32; one level at a
         // time for K = 1024): every launch replays the cheap register chain, the first one writes g_res0
@@ -1077,15 +1167,25 @@ static int rq_backward_impl(const float *res0, int64_t B, int D, const float *co
     long long cap = (long long)cu_count() * 8;
     const int grid = (int)(want < cap ? want : cap);
     int rc;
+    const bool vec = D == 2 * ksteps_for(D) && al16(res0) && al16(codebooks) && al16(g_embs) && al16(g_embsum) && al16(g_resid) &&
+                     al16(g_res0) && al16(workspace);
     switch (ksteps_for(D)) {
-        case 4: rc = launch_bwd<4>(p, mode, grid, s); break;
-        case 8: rc = launch_bwd<8>(p, mode, grid, s); break;
-        case 16: rc = launch_bwd<16>(p, mode, grid, s); break;
-        case 32: rc = launch_bwd<32>(p, mode, grid, s); break;
-        default: rc = launch_bwd<64>(p, mode, grid, s); break;
+        case 4: rc = launch_bwd<4>(p, mode, grid, vec, s); break;
+        case 8: rc = launch_bwd<8>(p, mode, grid, vec, s); break;
+        case 16: rc = launch_bwd<16>(p, mode, grid, vec, s); break;
+        case 32: rc = launch_bwd<32>(p, mode, grid, vec, s); break;
+        default: rc = launch_bwd<64>(p, mode, grid, vec, s); break;
     }
     if (rc || !g_codebooks || !lds_path) return rc;
 
+    if (small_cb_fits(B, D, K)) {   // a small batch: one workgroup per level adds its rows' vectors in row order, no partial tables
+        static LdsGrant small_grant;
+        RQ_RETURN_IF_HIP(small_grant.ensure(reinterpret_cast<const void *>(rq_cbgrad_small_kernel), (int)kScatterLdsBudgetSmall));
+        hipLaunchKernelGGL(rq_cbgrad_small_kernel, dim3(L), dim3(kFusedThreads), small_cb_lds(D, K), s, p.ws, ids, (long long)B, D, K,
+                           g_codebooks);
+        RQ_CHECK_LAUNCH("rq_cbgrad_small_kernel");
+        return RQHIP_OK;
+    }
     // embedding backward: LDS-private scatter in groups of whole levels, then a fixed-order reduce
     const int G = scatter_wgs(B);
     const long long rows_per_wg = (B + G - 1) / G;
