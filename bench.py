@@ -26,6 +26,8 @@ Extra objects on the JSON line:
                   (tools/profile_bench.sh), used only when that file carries the sha256 of the librqhip.so loaded here.
                   `all_fp32_kernel` = the same launch with RQHIP_FWD_SCAN_FP32, timed in this run (untimed region).
                   `step_frac_of_fp32_peak` prices the WHOLE step (MLP GEMMs included) against the same peak.
+  box          -- two fixed library workloads timed after the step (bf16 8192^3 GEMM TFLOP/s, 1 GiB copy GB/s): which kind of box of
+                  the pool this line was measured on (the same build spreads 33-38 M items/s across boxes).
   long_run     -- when the K timed steps took less than --min-seconds (default 1 s; the driver's K = 20 is 0.1 s), a
                   second, longer timed region of the same step (same barriers) and its items/s; `value` stays the K-step
                   figure the contract asks for.
@@ -183,6 +185,39 @@ def cpu_baseline(batch_rows, levels, codes, budget_s=24.0):
             "note": "the reference's own modules on the 8-vCPU build container, and this port beside them on that host: "
                     "BASELINE.md section 2, profiles/r04_reference_vs_port_cpu.json (tools/time_reference_cpu.py); "
                     "cgroup_cpu_quota_cores / affinity_cpus: what the box lets this process use of its hardware threads"}
+
+
+def box_calibration(device):
+    """Two fixed library workloads, timed after the step (untimed region): the same build measured 33-38 M items/s on different boxes
+    of the pool with EVERY kernel 12-18 % apart (profiles/r05_bench_n1_sample_*.json) -- these two numbers say which kind of box a
+    line comes from.  bf16 8192^3 GEMM through the library (matrix pipe under the power cap), 1 GiB device copy (HBM)."""
+    try:
+        a = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+        b = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+        for _ in range(3):
+            a @ b
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(20):
+            a @ b
+        ev[1].record()
+        torch.cuda.synchronize()
+        gemm = 20 * 2 * 8192 ** 3 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12
+        del a, b
+        src = torch.empty(1 << 28, device=device, dtype=torch.float32)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        ev[0].record()
+        for _ in range(10):
+            dst.copy_(src)
+        ev[1].record()
+        torch.cuda.synchronize()
+        copy = 10 * 2 * src.numel() * 4 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
+        return {"bf16_gemm_8192_tflops": round(gemm, 1), "copy_read_plus_write_GBps": round(copy, 1)}
+    except Exception as e:  # noqa
+        return {"error": repr(e)[:200]}
 
 
 def small_batch_secondary(cpu):
@@ -750,6 +785,7 @@ def main():
             line["n_physical_gpus"] = 1
         del model, opt, reducer, batches, X
         torch.cuda.empty_cache()
+        line["box"] = box_calibration(device)
         if not args.no_parity:
             line["parity"] = parity_gate(device, args.config)
             if args.config != "c4":     # the C4-shaped fixture (4 x 1024 codebooks, 300 000 rows end to end) beside it
