@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void recon_bwd_spec_kernel(const float *__rest
 // (one more rounding than (2 d) g; rows that match -- every row of a training step -- are not touched).
 // row_max [parts][B] / col_max [N] (optional): the maxima the fused epilogue emitted for g_spec (the scales of the fp16 split
 // kernels that read it next) are brought up to date for the rows that change: the row's new maximum goes to part 0 (the other
-// parts are cleared), the columns are maxed into atomically (a stale, larger column maximum is a valid scale).
+// parts are cleared), the columns are maxed into atomically (a stale, larger column maximum -- a row that was scaled down -- is a valid
+// scale that costs the fp16 low piece one bit per binade of overestimate; the result then differs in the last bits from a fresh maxima pass).
 __global__ __launch_bounds__(256) void recon_rescale_rows_kernel(const float *__restrict__ g, long long B, int N,
                                                                  float row_scale, float *__restrict__ gs,
                                                                  unsigned *__restrict__ row_max, int parts,

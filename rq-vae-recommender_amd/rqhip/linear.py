@@ -6,7 +6,10 @@ The large layers run on the 16-bit matrix cores with fp32's accuracy (csrc/gemm_
 product arithmetic is `f16x2`: every row (column, for the weight gradients) is scaled by an exact power of two and split into
 two fp16 pieces, three piece products per product.  The scales are the maxima of the rows / columns of the operand, which the
 kernel that WROTE the operand emits from its epilogue (`Scales`, handed from layer to layer by modules/encoder.py:_MLPStack);
-a caller that has none gets them from one `ops.maxima` pass -- same maxima, same exponents, same result bits either way.
+a caller that has none gets them from one `ops.maxima` pass -- same maxima, same exponents, same result bits either way.  (One exception:
+when the reconstruction loss's upstream gradient is not the announced 1 / B -- `ops.recon_rescale_rows` -- rows that were scaled DOWN leave
+the column maxima of that gradient too large: still a valid scale, one low-order bit of the fp16 low piece per binade of overestimate,
+and not the bits a fresh maxima pass would give.  No shipped training loop takes that path: the loss is a mean.)
 `use_arith("bf16x3")` keeps round 3's three-piece bf16 kernels for A/B (bench.py --mlp split6)."""
 from typing import List, Optional, Tuple
 

@@ -284,6 +284,17 @@ def train(
         # several ranks: the RCCL all-reduces of FlatGradReducer are captured with the step (one graph per rank, replayed in
         # lockstep: every rank runs the same sequence of full batches; the short batch that ends an epoch is eager on all of them)
         graphed = _GraphedStep(model, optimizer, reducer, batch_size, vae_input_dim, device, t)
+        if world > 1:
+            # A replayed step issues another sequence of collectives than an eager one (early + late runs vs one whole-buffer
+            # all-reduce), so every rank must take the same branch on the same iterations.  That follows from identical batchers: the
+            # same number of rows and the same batch size on every rank -- checked once here; ranks that disagree train eagerly.
+            mine = (len(train_dataset), int(batch_size), int(gradient_accumulate_every))
+            seen = [None] * world
+            _dist.all_gather_object(seen, mine)
+            if any(other != mine for other in seen):
+                if rank == 0:
+                    print(f"use_hip_graph: ranks disagree on (rows, batch_size, accumulate) = {seen}; falling back to the eager step")
+                graphed = None
     graph_after = start_iter + 3  # a few eager steps first (k-means init, allocator warm-up)
     window: List[torch.Tensor] = []
     shown = (float("nan"),) * 3
