@@ -192,6 +192,7 @@ def box_calibration(device):
     of the pool with EVERY kernel 12-18 % apart (profiles/r05_bench_n1_sample_*.json) -- these two numbers say which kind of box a
     line comes from.  bf16 8192^3 GEMM through the library (matrix pipe under the power cap), 1 GiB device copy (HBM)."""
     try:
+        import torch
         a = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
         b = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
         for _ in range(3):

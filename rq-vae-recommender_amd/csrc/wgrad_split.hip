@@ -87,6 +87,18 @@ __device__ __forceinline__ int ws_exp_of_bits(unsigned b) {
     return (b == 0u || e == 255) ? 0 : (e == 0 ? -126 : e - 127) - 14;
 }
 
+// Loads and waits placed by hand for the pipelined part of the main loop (see there): an asm load is invisible to the compiler's
+// s_waitcnt pass, ws_await<N> is the wait -- "at most N loads still in flight" -- and ties the four registers of a set to itself.
+__device__ __forceinline__ ws_f32x4 ws_load4(const float *p) {
+    ws_f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void ws_await(ws_f32x4 (&r)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+}
+
 // TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given; NP: pieces per operand (3 bf16 / 2 fp16 under column scales)
 template <int TA, int TB, int WA, int WB, bool MASK, int NP>
 __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSplitParams p) {
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.0f;
 
-    ws_f32x4 rv[UQ][4], ry[MASK ? UQ : 1][4];
+    ws_f32x4 rv0[UQ][4], rv1[UQ][4], ry[MASK ? UQ : 1][4];   // (rv1: the second staging set of the two-stage prefetch, see the main loop)
     int ue[NP == 2 ? UQ : 1][4];   // NP == 2: exponents of the four columns of each of this thread's staging units
 #pragma unroll
     for (int q = 0; q < (NP == 2 ? UQ : 0); ++q) {
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             if (MASK) ycur[q][j] = p.y + (isg ? off : (size_t)0);
         }
     }
-    auto fetch_tail = [&](long long stage) {
+    auto fetch_tail = [&](long long stage, ws_f32x4 (&rv)[UQ][4]) {
         const long long row0 = r_begin + stage * kWsRows;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
@@ -193,9 +205,9 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
         }
     };
     // (stages are fetched in order 0, 1, 2, ...: `cur` always points at the next one)
-    auto fetch = [&](long long stage) {
+    auto fetch = [&](long long stage, ws_f32x4 (&rv)[UQ][4]) {
         if (stage >= n_full) {
-            fetch_tail(stage);
+            fetch_tail(stage, rv);
             return;
         }
 #pragma unroll
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
             }
         }
     };
-    auto stash = [&](long long stage, int buf) {
+    auto stash = [&](long long stage, int buf, ws_f32x4 (&rv)[UQ][4]) {
         const long long row0 = r_begin + stage * kWsRows;
         unsigned *dst = sbuf + buf * (PART_G + PART_X);
         if (WS_PROBE & 1) return;
@@ -278,12 +290,6 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     // all multiply) nothing overlapped: 3.2 us per 16-row stage measured, the SUM of 1.3 us of matrix time and the
     // staging.  Both phases read buffer `buf` and write buffer `buf ^ 1`, which every wave left at the last barrier.
     const bool stage_first = wave < (WA * WB) / 2;
-    if (n_stage > 0) {
-        fetch(0);
-        stash(0, 0);
-        if (n_stage > 1) fetch(1);
-    }
-    __syncthreads();
     auto multiply = [&](int buf) {
         const ws_bf16x8 *gA = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X));
         const ws_bf16x8 *xB = reinterpret_cast<const ws_bf16x8 *>(sbuf + buf * (PART_G + PART_X) + PART_G);
@@ -323,18 +329,113 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
                 acc[t][u] = c16;
             }
     };
-    for (long long c = 0; c < n_stage; ++c) {
-        const int buf = (int)(c & 1);
-        if (stage_first) {
-            if (c + 1 < n_stage) stash(c + 1, buf ^ 1);
-            if (c + 2 < n_stage) fetch(c + 2);
+    constexpr bool kTwoSets = !MASK && UQ == 1 && WS_PROBE == 0;
+    if constexpr (!kTwoSets) {
+        if (n_stage > 0) {
+            fetch(0, rv0);
+            stash(0, 0, rv0);
+            if (n_stage > 1) fetch(1, rv0);
         }
-        multiply(buf);
-        if (!stage_first) {
-            if (c + 1 < n_stage) stash(c + 1, buf ^ 1);
-            if (c + 2 < n_stage) fetch(c + 2);
+        __syncthreads();
+        for (long long c = 0; c < n_stage; ++c) {
+            const int buf = (int)(c & 1);
+            if (stage_first) {
+                if (c + 1 < n_stage) stash(c + 1, buf ^ 1, rv0);
+                if (c + 2 < n_stage) fetch(c + 2, rv0);
+            }
+            multiply(buf);
+            if (!stage_first) {
+                if (c + 1 < n_stage) stash(c + 1, buf ^ 1, rv0);
+                if (c + 2 < n_stage) fetch(c + 2, rv0);
+            }
+            if (!(WS_PROBE & 16)) __syncthreads();
         }
-        if (!(WS_PROBE & 16)) __syncthreads();
+    } else {
+        // The product path (f16 pieces, no mask, one staging unit per thread): TWO staging sets, the rows of stage c + 3 requested
+        // while stage c is multiplied -- a load has two barrier intervals to arrive.  With one set (rounds 3-4: requested in iteration
+        // c, split in iteration c + 1) the phase-skipping probe without global loads ran in 200 us against 313 for dW [512, 768]
+        // (profiles/r05_wgrad_prefetch.txt): a third of the kernel was waiting for its rows.  In the steady part the loads and waits
+        // are placed by hand (ws_load4 / ws_await<4>: "all but the other set's four loads have arrived") because the compiler's wait
+        // placement covers every load in flight once the refill sits behind a branch; that part is straight-line per wave role --
+        // two copies of the loop, same barriers -- so that no register of a set is copied while its load is in flight.  Whole stages
+        // only (plain loads); the range's first / last stages and short ranges take the compiler-managed form below.
+        auto load_set = [&](ws_f32x4 (&r)[UQ][4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[0][j] = ws_load4(cur[0][j]);
+                cur[0][j] += step16[0];
+            }
+        };
+        long long c = 0;
+        if (n_full >= 5) {
+            load_set(rv0);                    // stage 0
+            load_set(rv1);                    // stage 1
+            ws_await<4>(rv0[0]);
+            stash(0, 0, rv0);
+            load_set(rv0);                    // stage 2
+            __syncthreads();
+            if (stage_first) {
+                for (; c + 4 < n_full; c += 2) {
+                    ws_await<4>(rv1[0]);
+                    stash(c + 1, 1, rv1);
+                    load_set(rv1);            // stage c + 3
+                    multiply(0);
+                    __syncthreads();
+                    ws_await<4>(rv0[0]);
+                    stash(c + 2, 0, rv0);
+                    load_set(rv0);            // stage c + 4
+                    multiply(1);
+                    __syncthreads();
+                }
+                ws_await<0>(rv1[0]);
+                ws_await<0>(rv0[0]);
+            } else {
+                for (; c + 4 < n_full; c += 2) {
+                    multiply(0);
+                    ws_await<4>(rv1[0]);
+                    stash(c + 1, 1, rv1);
+                    load_set(rv1);            // stage c + 3
+                    __syncthreads();
+                    multiply(1);
+                    ws_await<4>(rv0[0]);
+                    stash(c + 2, 0, rv0);
+                    load_set(rv0);            // stage c + 4
+                    __syncthreads();
+                }
+                ws_await<0>(rv1[0]);
+                ws_await<0>(rv0[0]);
+            }
+        } else {
+            if (n_stage > 0) fetch(0, rv0);
+            if (n_stage > 1) fetch(1, rv1);
+            if (n_stage > 0) stash(0, 0, rv0);
+            if (n_stage > 2) fetch(2, rv0);
+            __syncthreads();
+        }
+        // here: LDS buffer 0 holds stage c (c even), rv1 stage c + 1, rv0 stage c + 2, `cur` points at stage c + 3
+        for (; c < n_stage; c += 2) {
+            if (stage_first) {
+                if (c + 1 < n_stage) stash(c + 1, 1, rv1);
+                if (c + 3 < n_stage) fetch(c + 3, rv1);
+            }
+            multiply(0);
+            if (!stage_first) {
+                if (c + 1 < n_stage) stash(c + 1, 1, rv1);
+                if (c + 3 < n_stage) fetch(c + 3, rv1);
+            }
+            __syncthreads();
+            if (c + 1 >= n_stage) break;
+            if (stage_first) {
+                if (c + 2 < n_stage) stash(c + 2, 0, rv0);
+                if (c + 4 < n_stage) fetch(c + 4, rv0);
+            }
+            multiply(1);
+            if (!stage_first) {
+                if (c + 2 < n_stage) stash(c + 2, 0, rv0);
+                if (c + 4 < n_stage) fetch(c + 4, rv0);
+            }
+            __syncthreads();
+        }
     }
 
     // partial block -> workspace (or dW itself when there is a single row range).  acc[t][u][r]:
