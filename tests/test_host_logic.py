@@ -301,3 +301,38 @@ def test_grad_sink_is_claimed_once_per_parameter_and_epoch():
     red.zero_()
     w.grad = torch.ones(3, 2)
     assert claim_grad_sink(w) is None                      # a gradient is already there: autograd accumulates
+
+
+def test_small_batch_weight_gradient_routing_and_its_abi_argument_checks():
+    """Which batches take the job-table weight-gradient kernel (csrc/wgrad_jobs.hip) is host logic: below the split kernels' 4096
+    rows, at most eight supported layers, not under the strict fp32 arithmetic; and the C entry point refuses bad job tables before
+    it touches a device (no GPU here)."""
+    import ctypes as C
+    from rqhip import _lib, linear, ops
+    mlp = [(512, 768), (256, 512), (128, 256), (32, 128)]
+    assert linear.wgrad_jobs_ok(640, mlp) and linear.wgrad_jobs_ok(64, mlp[::-1]) and linear.wgrad_jobs_ok(4095, mlp)
+    assert not linear.wgrad_jobs_ok(4096, mlp) and not linear.wgrad_jobs_ok(100_000, mlp) and not linear.wgrad_jobs_ok(0, mlp)
+    assert not linear.wgrad_jobs_ok(640, mlp + [(48, 64)])            # a layer no block shape tiles
+    assert not linear.wgrad_jobs_ok(640, mlp * 3) and not linear.wgrad_jobs_ok(640, [])
+    before = linear.use_arith("fp32")
+    try:
+        assert not linear.wgrad_jobs_ok(640, mlp)                     # the oracle-ordered kernels keep that arithmetic to themselves
+    finally:
+        linear.use_arith(before)
+    off = linear.use_wgrad_jobs(False)
+    try:
+        assert not linear.wgrad_jobs_ok(640, mlp)
+    finally:
+        linear.use_wgrad_jobs(off)
+    assert ops.linear_wgrad_jobs_supported(32, 32) and not ops.linear_wgrad_jobs_supported(16, 64)
+    l = _lib.lib()
+    vp, ci = C.c_void_p * 9, C.c_int * 9
+    fake = vp(*[0x1000] * 9)                                          # never dereferenced: every call below is refused first
+    assert l.rqhip_linear_wgrad_jobs(fake, fake, fake, ci(*[64] * 9), ci(*[64] * 9), 9, 640, None) == -1   # RQHIP_EARG
+    assert l.rqhip_linear_wgrad_jobs(fake, fake, fake, ci(*[64] * 9), ci(*[64] * 9), -1, 640, None) == -1   # RQHIP_EARG
+    assert l.rqhip_linear_wgrad_jobs(fake, fake, fake, ci(*[64] * 9), ci(*[64] * 9), 2, -5, None) == -1   # RQHIP_EARG
+    assert l.rqhip_linear_wgrad_jobs(fake, fake, fake, ci(*([48] + [64] * 8)), ci(*[64] * 9), 2, 640, None) == -1   # RQHIP_EARG
+    assert l.rqhip_linear_wgrad_jobs(vp(*([0] + [0x1000] * 8)), fake, fake, ci(*[64] * 9), ci(*[64] * 9), 2, 640, None) == -1   # RQHIP_EARG
+    assert l.rqhip_linear_wgrad_jobs(None, None, None, None, None, 0, 640, None) == 0      # no jobs: nothing to do
+    with pytest.raises(_lib.RqHipError):
+        ops.linear_wgrad_jobs([(torch.zeros(8, 64), torch.zeros(8, 64))])                              # CPU tensors: no fallback
