@@ -184,14 +184,26 @@ __global__ __launch_bounds__(1024) void loss_means_kernel(const float *__restric
     float s_sum = 0.0f, s_r = 0.0f, s_q = 0.0f;
     const bool vec = ((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(quant)) & 15) == 0;
     const long long n4 = vec ? B / 4 : 0;
-    for (long long i = t; i < n4; i += 1024) {
-        const f32x4 a = reinterpret_cast<const f32x4 *>(recon)[i];
-        const f32x4 b = reinterpret_cast<const f32x4 *>(quant)[i];
+    // (eight groups fetched per trip, then added in the same order as before: with one group per trip the 24 trips of a 100 000-row
+    // batch were 24 memory round trips in a row -- 16 us for 0.8 MB)
+    for (long long i0 = t; i0 < n4; i0 += 8 * 1024) {
+        f32x4 a[8], b[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s_sum = s_sum + (a[j] + b[j]);
-            s_r = s_r + a[j];
-            s_q = s_q + b[j];
+        for (int u = 0; u < 8; ++u) {
+            const long long i = i0 + (long long)u * 1024;
+            a[u] = i < n4 ? reinterpret_cast<const f32x4 *>(recon)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            b[u] = i < n4 ? reinterpret_cast<const f32x4 *>(quant)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + (long long)u * 1024 < n4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s_sum = s_sum + (a[u][j] + b[u][j]);
+                    s_r = s_r + a[u][j];
+                    s_q = s_q + b[u][j];
+                }
+            }
         }
     }
     for (long long i = 4 * n4 + t; i < B; i += 1024) {
