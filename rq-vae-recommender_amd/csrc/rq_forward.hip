@@ -1513,7 +1513,13 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
         p.tpg = (tiles + 7) / 8;
         p.ngroups = (tiles + p.tpg - 1) / p.tpg;
     }
-    p.incsq = filt && p.resident;
+    // ... unless the launch is ONE round of row tiles and the level is one chunk (a small batch at D = 64: the reference's
+    // rqvae_ml32m.gin, batch 64): every workgroup then stages every level exactly once, the norms cost it nothing extra, and the
+    // launch in front (10 us of a 250 us training step, strided row reads) goes away.
+    const bool one_round = p.n_tiles <= (long long)cu_count() * waves_per_wg;
+    const bool chunk_with_norms = filt && !p.resident && p.nchunks == 1 && one_round &&
+                                  (size_t)p.Kc * (code_bytes + csq_copy) + fixed_bytes + gm_bytes <= (size_t)kLdsBudget;
+    p.incsq = filt && (p.resident || chunk_with_norms);
     if (!p.incsq)
         if (int rc = launch_csq()) return rc;
     const size_t lds = (size_t)p.Kc * (code_bytes + (p.incsq ? csq_copy : 0)) * (p.resident ? L : 1) + fixed_bytes + gm_bytes;
