@@ -6,7 +6,7 @@
 // of wgrad_split.hip / wgrad.hip are all latency: eight launches of 18-20 us plus eight reductions of 5 us per training step --
 // 16 row ranges per 256 x 256 block so that 96 workgroups exist at all, 25 MB of partial blocks for 0.5 GFLOP -- 190 of the
 // step's 410 us of kernel time (profiles/r05_small_batch_kernels.txt).  Here:
-//   * a JOB TABLE: every (layer, 64 x 64 block of dW) of the stack is one workgroup of the same launch -- 137 workgroups for
+//   * a JOB TABLE: every (layer, 64 x 64 block of dW) of the stack is one workgroup of the same launch -- 138 workgroups for
 //     768-512-256-128-32; a block is reduced over ALL M rows by its workgroup: no row ranges, no partial blocks, no second kernel,
 //     a fixed summation order;
 //   * a workgroup is 16 waves: thread (column c of the block's g / x columns, row octet o) fetches EIGHT CONSECUTIVE ROWS of its
