@@ -96,6 +96,11 @@ def parse_args():
     ap.add_argument("--no-small-batch", action="store_true", help="skip secondary.small_batch (a subprocess: batch 640 / batch 64 steps, eager and hipGraph)")
     ap.add_argument("--cpu-rows", type=int, default=8192)
     ap.add_argument("--pmc-file", default=None, help="JSON of separate rocprofv3 --pmc passes (tools/summarize_profile.py)")
+    ap.add_argument("--pmc-window", default=None,
+                    help="profiling runs (tools/profile_bench.sh): bracket ONE extra step between two marker launches (rqhip_maxima on a 1 x 4 "
+                         "matrix: the only maxima_kernel dispatches with a grid of one workgroup) and write the ordered (kind, flops, bytes) tags "
+                         "of its matrix-kernel launches to this file -- tools/summarize_profile.py matches the rocprofv3 --pmc dispatches "
+                         "between the markers to the tags (profiles/r0N_pmc_kernels_<cfg>.json: HBM bytes per launch SHAPE)")
     ap.add_argument("--mlp", choices=("split", "split6", "library"), default="split",
                     help="A/B only.  `split` (the product): the MLP GEMMs and weight gradients as two fp16 pieces per operand "
                          "under exact power-of-two scales, three piece products (csrc/gemm_split.hip, wgrad_split.hip); `split6`: "
@@ -468,6 +473,19 @@ def main():
                     "why": f"the {steps} timed steps took {elapsed:.3f} s < --min-seconds {args.min_seconds}"}
 
     # ---- untimed from here ------------------------------------------------------------------------------
+    if args.pmc_window and rank == 0:
+        tiny = torch.zeros((1, 4), device=device)
+        ops.maxima(tiny)                                   # marker dispatch
+        ops.profile_enable(n_micro * 48 + 64)
+        ops.profile_select("gemm_split", "wgrad")
+        step()
+        torch.cuda.synchronize()
+        wrecs = ops.profile_read_tagged(n_micro * 48 + 64)
+        ops.profile_enable(0)
+        ops.maxima(tiny)                                   # marker dispatch
+        torch.cuda.synchronize()
+        with open(args.pmc_window, "w") as fh:
+            json.dump({"tags": [[k, fl, by] for k, _ms, fl, by in wrecs], "config": args.config, "rows": B, "micro": micro}, fh)
     # Per-kernel records for `roofline_kernels`: the same step, every library launch bracketed by HIP events on its stream
     # (rqhip_profile_*: tag, duration, algorithmic FLOPs and bytes of the launch).  Its own region because ~50 event pairs
     # per step are not free; the records of `roofline` above come from the timed region itself.
@@ -581,8 +599,11 @@ def main():
         traffic, traffic_src = None, None
         from rqhip import _lib as _rqlib
         lib_sha = _sha256_file(os.path.abspath(args.lib) if args.lib else _rqlib.SO_PATH)
-        pmc = args.pmc_file or next((q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_{args.config}.json") for r in ("r05", "r04"))
-                                     if os.path.exists(q)), os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{args.config}.json"))
+        import glob as _glob
+        def _newest(pattern):     # profiles/r0N_<pattern>: the newest round first
+            return sorted(_glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True)
+        pmc = args.pmc_file or next(iter(_newest(f"r[0-9][0-9]_pmc_traffic_{args.config}.json")),
+                                    os.path.join(ROOT, "profiles", f"r06_pmc_traffic_{args.config}.json"))
         pmc_json = None
         if not os.path.exists(pmc):
             traffic_src = f"null: no PMC file {os.path.relpath(pmc, ROOT)}"
@@ -608,13 +629,15 @@ def main():
         for kind, ms, fl, by in prof_records:
             key = (kind, fl, by)
             groups.setdefault(key, []).append(ms)
-        pmc_k = {}
-        pmc_all = os.path.join(ROOT, "profiles", f"r04_pmc_kernels_{args.config}.json")
-        if os.path.exists(pmc_all):
+        # HBM bytes per launch SHAPE (tag "kind:flops:bytes"), from the rocprofv3 --pmc passes of tools/profile_bench.sh matched to the tags of
+        # a marked step (--pmc-window); used only when collected on the very library this run loaded
+        pmc_k, pmc_k_src = {}, "null: no profiles/r0N_pmc_kernels_%s.json for this build (tools/profile_bench.sh)" % args.config
+        for pmc_all in _newest(f"r[0-9][0-9]_pmc_kernels_{args.config}.json"):
             with open(pmc_all) as fh:
                 pj = json.load(fh)
-            if pj.get("librqhip_sha256") == lib_sha:
-                pmc_k = pj.get("kernels", {})
+            if pj.get("librqhip_sha256") == lib_sha and B == cfg["rows"]:
+                pmc_k, pmc_k_src = pj.get("kernels", {}), os.path.relpath(pmc_all, ROOT)
+                break
         rk = []
         for (kind, fl, by), mss in groups.items():
             mean = float(np.mean(mss))
@@ -665,12 +688,27 @@ def main():
                    "algorithmic_gflop_per_launch": round(dfl / 1e9, 3), "algorithmic_mb_per_launch": round(dby / 1e6, 2),
                    "issued_tflops": round(issued_mult * dfl / (dmean * 1e-3) / 1e12, 1),
                    "frac": round(issued_mult * dfl / (dmean * 1e-3) / 1e12 / issued_peak, 4), "traffic": None, "traffic_ratio": None}
-            if pmc_json is not None:     # HBM bytes of that launch by the PMC counters (2 FETCH_SIZE + WRITE_SIZE, largest launch)
-                cand = [(2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024.0 for n, v in pmc_json.get("kernels", {}).items()
-                        if ("wgrad" in n if dk == "wgrad" else "gemm" in n) and "FETCH_SIZE_KB_max" in v and "WRITE_SIZE_KB_max" in v]
-                if cand:
-                    dom["traffic"] = max(cand)
-                    dom["traffic_ratio"] = round(max(cand) / dby, 3) if dby else None
+            tr = pmc_k.get(f"{dk}:{int(dfl)}:{int(dby)}")
+            if tr:
+                dom["traffic"] = tr
+                dom["traffic_ratio"] = round(tr / dby, 3) if dby else None
+        # the family's HBM traffic: PMC bytes (2 FETCH_SIZE + WRITE_SIZE) of every member launch of a step, matched by launch shape
+        fam_traffic = fam_traffic_ratio = fam_traffic_tw = None
+        fam_cov = 0
+        if pmc_k and fam:
+            tb = ab = tw_num = tw_den = 0.0
+            for (kind, fl, by), v in fam.items():
+                tr = pmc_k.get(f"{kind}:{int(fl)}:{int(by)}")
+                if tr and by:
+                    fam_cov += len(v)
+                    tb += tr * len(v)
+                    ab += by * len(v)
+                    tw_num += (tr / by) * sum(v)
+                    tw_den += sum(v)
+            if fam_cov:
+                fam_traffic = tb / fam_cov                   # mean PMC bytes per launch of the family
+                fam_traffic_ratio = round(tb / ab, 3)        # all PMC bytes / all algorithmic bytes of the matched launches
+                fam_traffic_tw = round(tw_num / tw_den, 3)   # per-launch ratios weighted by launch time
         roofline_family = {
             "kernel": ("MLP matrix-kernel family: gemm_f16_kernel / gemm_split_kernel (activation GEMMs with ReLU / mask / reconstruction-"
                        "loss epilogues) + wgrad_split_kernel (weight gradients), " f"{round(fam_launches / max(n_rec, 1), 1)} launches per step"
@@ -685,9 +723,12 @@ def main():
             "family_ms_per_step": round(fam_ms / max(n_rec, 1), 4), "share_of_step": round(fam_ms / max(n_rec, 1) / ms_per_step, 3),
             "recorded_steps": n_rec,
             "launches": fam_launches,
-            "traffic": dom["traffic"] if dom else None,
-            "traffic_source": (traffic_src if (dom and dom["traffic"]) else "null: no PMC passes for this build (tools/profile_bench.sh)")
-                              + "; of the dominant member's largest launch",
+            "traffic": fam_traffic,
+            "traffic_ratio": fam_traffic_ratio, "traffic_ratio_time_weighted": fam_traffic_tw,
+            "traffic_source": (f"{pmc_k_src}: mean HBM bytes per launch over the family's {fam_launches} launches ({fam_cov} matched by shape), "
+                               "2*FETCH_SIZE+WRITE_SIZE of separate rocprofv3 --pmc passes on the same librqhip.so; traffic_ratio = PMC bytes / "
+                               "algorithmic bytes over those launches, _time_weighted = per-launch ratios weighted by launch time"
+                               if fam_cov else pmc_k_src),
             "dominant_member": dom,
         }
         workload = {
@@ -701,7 +742,9 @@ def main():
             "metric": "item-embeddings quantized/sec (RQ-VAE fwd+bwd)",
             "value": round(value, 1), "unit": "items/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"split": "f32 (MLP GEMMs f16x2-emulated)", "split6": "f32 (MLP GEMMs bf16x3-emulated)", "library": "f32"}[args.mlp],
+            "data": "synthetic",
             "config": {"workload": workload, "name": args.config, "rows_per_gpu_per_step": B, "micro_batch_rows": micro,
                        "levels": LEVELS, "codebook_size": CODES, "embed_dim": EMBED,
                        "parallelism": f"row-shard x{world}, 1 flat grad all-reduce per step (RCCL)"},
@@ -791,16 +834,31 @@ def main():
             line["parity"] = parity_gate(device, args.config)
             if args.config != "c4":     # the C4-shaped fixture (4 x 1024 codebooks, 300 000 rows end to end) beside it
                 try:
-                    p4 = parity_gate(device, "c4")
+                    # ... under BOTH arithmetics of the MLP GEMMs in this one process: the product's f16x2 emulation and
+                    # strict fp32 (library GEMMs) -- does the emulation add id flips against the reference?
+                    p4 = {}
+                    for arm, arith in (("f16x2", "f16x2"), ("fp32", "fp32")):
+                        prev = _lin.use_arith(arith)
+                        try:
+                            p4[arm] = parity_gate(device, "c4")
+                        finally:
+                            _lin.use_arith(prev)
+                    pa = p4["f16x2"] if args.mlp != "library" else p4["fp32"]
                     line["parity"]["c4"] = {
-                        "rows_total": p4["end_to_end"]["eval"]["rows_total"], "mismatches_eval": p4["end_to_end"]["eval"]["mismatches"],
-                        "mismatches_train": p4["end_to_end"]["train"]["mismatches"], "ids_exact_rate": p4["ids_exact_rate"],
-                        "mismatch_margins_eval": p4["end_to_end"]["eval"]["mismatch_margins"],
-                        "hard_rows_mismatches": p4["kernel_level_hard_rows"]["mismatches"],
-                        "kernel_level_mismatches": p4["kernel_level"]["mismatches"],
-                        "all_mismatches_flagged": p4["all_mismatches_flagged"], "loss_max_abs_err": p4["loss_max_abs_err"],
-                        "pass": p4["pass"]}
-                    line["parity"]["c4_mismatches"] = p4["mismatches"]
+                        "rows_total": pa["end_to_end"]["eval"]["rows_total"], "mismatches_eval": pa["end_to_end"]["eval"]["mismatches"],
+                        "mismatches_train": pa["end_to_end"]["train"]["mismatches"], "ids_exact_rate": pa["ids_exact_rate"],
+                        "mismatch_margins_eval": pa["end_to_end"]["eval"]["mismatch_margins"],
+                        "hard_rows_mismatches": pa["kernel_level_hard_rows"]["mismatches"],
+                        "kernel_level_mismatches": pa["kernel_level"]["mismatches"],
+                        "all_mismatches_flagged": pa["all_mismatches_flagged"], "loss_max_abs_err": pa["loss_max_abs_err"],
+                        "pass": pa["pass"],
+                        "mismatches_f16x2": {"eval": p4["f16x2"]["end_to_end"]["eval"]["mismatches"], "train": p4["f16x2"]["end_to_end"]["train"]["mismatches"],
+                                             "all_flagged": p4["f16x2"]["all_mismatches_flagged"], "pass": p4["f16x2"]["pass"]},
+                        "mismatches_fp32": {"eval": p4["fp32"]["end_to_end"]["eval"]["mismatches"], "train": p4["fp32"]["end_to_end"]["train"]["mismatches"],
+                                            "all_flagged": p4["fp32"]["all_mismatches_flagged"], "pass": p4["fp32"]["pass"]},
+                        "arms": "the same fixture end to end with the MLP GEMMs as f16x2 split kernels (the product) and as library fp32 GEMMs "
+                                "(bench.py --mlp library), same process; tau (tests/parity_gate.py) 2e-6 end to end"}
+                    line["parity"]["c4_mismatches"] = pa["mismatches"]
                 except Exception as e:  # noqa: BLE001  (a missing fixture must not cost the line)
                     line["parity"]["c4"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:

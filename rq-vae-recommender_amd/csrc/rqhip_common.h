@@ -40,7 +40,7 @@ inline int check_hip(hipError_t e, const char *what) {
     } while (0)
 
 // words behind a weight image (csrc/gemm_split.hip:weight_images_kernel) that hold the GEMM kernels' tile dispensers: zero between
-// launches; the exponents of the rows of B follow them (shared by gemm_split.hip and gemm_img.hip)
+// launches; the exponents of the rows of B follow them (csrc/gemm_split.hip)
 constexpr int kWeightImageTailWords = 32;
 
 int cu_count();          // compute units of the CURRENT device (cached per device)

@@ -98,7 +98,10 @@ class ItemData(Dataset):
 
     # batches of this many rows and more run the MLPs' fp16-split kernels, which scale every row by its largest |value|
     # (rqhip/linear.py:_SPLIT_MIN_ROWS): that maximum is a property of the item, computed once per corpus and gathered with the batch
-    _SCALES_MIN_ROWS = 4096
+    @property
+    def _SCALES_MIN_ROWS(self) -> int:
+        from rqhip import linear as _lin
+        return _lin._SPLIT_MIN_ROWS
 
     def _corpus_maxima(self):
         """(row maxima int32 [N], column maxima int32 [768]) of the resident matrix's feature columns, bit patterns (rqhip_maxima)."""

@@ -106,7 +106,11 @@ class FlatGradReducer:
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dtype = self.params[0].device, self.params[0].dtype
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dtype)
+        # every slice starts on a 16-byte boundary (the kernels that read the buffer -- csrc/adamw.hip, the weight-gradient kernels'
+        # sinks -- use 16-byte accesses): a parameter whose numel is not a multiple of 4 is followed by up to 3 floats of padding,
+        # which stay zero and ride along in the all-reduce
+        self._padded = [(p.numel() + 3) // 4 * 4 for p in self.params]
+        self.flat = torch.zeros(sum(self._padded), device=dev, dtype=dtype)
         self._views = []
         self._offsets = []
         self.epoch = 0      # bumped by zero_(): a slice may be written in place by ONE backward node per epoch
@@ -119,11 +123,11 @@ class FlatGradReducer:
         self.overlap_launches = 0               # (tests / logs) early launches so far
         self._timing = None                     # enable_timing(): [(event before, event after, host seconds)] per allreduce_mean()
         offset = 0
-        for p in self.params:
+        for p, padded in zip(self.params, self._padded):
             n = p.numel()
             self._views.append(self.flat[offset:offset + n].view_as(p))
             self._offsets.append(offset)
-            offset += n
+            offset += padded
 
     def attach(self, model: Optional[nn.Module] = None) -> "FlatGradReducer":
         """Publish the slices: `param._rq_grad_view` for every parameter and, for an RqVae whose level codebooks are plain
@@ -138,8 +142,9 @@ class FlatGradReducer:
             cbs = [l.embedding.weight for l in layers]
             idx = [next((i for i, p in enumerate(self.params) if p is c), None) for c in cbs]
             shapes_ok = all(c.shape == cbs[0].shape for c in cbs)
-            if None not in idx and shapes_ok and all(b == a + 1 for a, b in zip(idx, idx[1:])):
-                K, D = cbs[0].shape
+            K, D = cbs[0].shape
+            if (None not in idx and shapes_ok and all(b == a + 1 for a, b in zip(idx, idx[1:]))
+                    and all(self._offsets[b] == self._offsets[a] + K * D for a, b in zip(idx, idx[1:]))):   # (no padding between them)
                 off = self._offsets[idx[0]]
                 model._rq_cb_grad_sink = SimpleNamespace(view=self.flat[off:off + len(cbs) * K * D].view(len(cbs), K, D),
                                                          params=cbs, owner=self)
@@ -159,7 +164,7 @@ class FlatGradReducer:
         """Maximal contiguous [lo, hi) ranges of the flat buffer covered by the parameters `idx` (ascending)."""
         runs: List[list] = []
         for i in sorted(idx):
-            lo, hi = self._offsets[i], self._offsets[i] + self.params[i].numel()
+            lo, hi = self._offsets[i], self._offsets[i] + self._padded[i]
             if runs and runs[-1][1] == lo:
                 runs[-1][1] = hi
             else:

@@ -29,31 +29,6 @@ _FP32 = -1   # no split kernels at all: library fp32 GEMMs, fp32-MFMA weight gra
 _ARITH_NAMES = {"f16x2": ops.F16X2, "bf16x3": ops.BF16X3, "fp32": _FP32}
 
 
-_IMAGES = True
-
-
-def use_images(on: bool = True) -> bool:
-    """Round 5's product path (default on): inside an MLP stack (modules/encoder.py:_MLPStack) activations and gradients travel as
-    operand IMAGES (csrc/gemm_img.hip) -- split into their two fp16 pieces once, by the kernel that produces them -- instead of fp32
-    matrices every consumer splits again.  Off: round 4's kernels (A/B: bench.py --mlp split).  Returns the previous setting."""
-    global _IMAGES
-    before, _IMAGES = _IMAGES, bool(on)
-    return before
-
-
-def images_on() -> bool:
-    return bool(_IMAGES and _SPLIT_GEMMS and _ARITH == ops.F16X2)
-
-
-def img_gemm_ok(rows: int, n_cols: int, n_red: int) -> bool:
-    """Does a GEMM of `rows` rows against a weight image of n_cols columns (reduction n_red) take csrc/gemm_img.hip?"""
-    return bool(images_on() and rows >= _SPLIT_MIN_ROWS and ops.gemm_img_supported(n_cols, n_red))
-
-
-def img_wgrad_ok(n_out: int, n_in: int, rows: int) -> bool:
-    return bool(images_on() and wgrad_f16_ok(n_out, n_in, rows) and ops.img_supported(n_out) and ops.img_supported(n_in))
-
-
 def use_split_gemms(on: bool = True) -> bool:
     """Route the large activation GEMMs through csrc/gemm_split.hip (default) or the library (A/B: tools/ab_step.py).
     Returns the previous setting."""

@@ -34,7 +34,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self._cache = {}
 
     def _shared_step(self, gi: int, group) -> torch.Tensor:
-        """One step counter per group, on the device; parameters loaded from a torch AdamW checkpoint bring their own (all equal)."""
+        """One step counter per group, on the device; parameters loaded from a torch AdamW checkpoint bring their own (all equal).
+        CONTRACT (differs from torch.optim.AdamW, which counts per parameter): every parameter of a group takes part in every step() --
+        a parameter whose .grad is None on some steps, or that receives its first gradient later than the others, is bias-corrected
+        with the GROUP's count.  The RQ-VAE training loops of this package (every parameter gets a gradient every step) satisfy it."""
         st = self._steps.get(gi)
         live = [self.state[p]["step"] for p in group["params"] if p in self.state and "step" in self.state[p]]
         if st is None or any(s is not st for s in live):
@@ -71,7 +74,10 @@ class FlatAdamW(torch.optim.Optimizer):
                     st["step"] = self._steps.get(gi, torch.zeros((), dtype=torch.float32, device=dev))
                     self._steps.setdefault(gi, st["step"])
             step = self._shared_step(gi, group)
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            # (the kernel reads 16 bytes at a time: a gradient that is a misaligned view of someone's packed buffer is copied once;
+            # rqhip.dist.FlatGradReducer pads its slices, so its views never take this branch)
+            grads = [p.grad if (p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0) else p.grad.clone(memory_format=torch.contiguous_format)
+                     for p in ps]
             key = (gi, tuple(p.data_ptr() for p in ps), tuple(g.data_ptr() for g in grads),
                    tuple(self.state[p]["exp_avg"].data_ptr() for p in ps), tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in ps))
             arrs = self._cache.get(gi)

@@ -141,16 +141,18 @@ class _GraphedStep:
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
-            for _ in range(2):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for p, saved in zip(self._model.parameters(), params):
-                p.copy_(saved)
-        self._opt.load_state_dict(opt_state)
-        torch.set_rng_state(rng_cpu)
-        torch.cuda.set_rng_state(rng_dev)
+        try:
+            with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
+                for _ in range(2):
+                    self._step()
+        finally:                                # (also when a warm-up step raised: the caller falls back to eager from where it was)
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():
+                for p, saved in zip(self._model.parameters(), params):
+                    p.copy_(saved)
+            self._opt.load_state_dict(opt_state)
+            torch.set_rng_state(rng_cpu)
+            torch.cuda.set_rng_state(rng_dev)
         self._reducer.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -172,6 +174,32 @@ class _GraphedStep:
         captured kernels -- replaying across such an excursion faulted or hung on ROCm 7.0."""
         self.graph = None
         self.out = None
+
+
+_AUTO_GRAPH_MIN_FULL_BATCHES = 8      # `use_hip_graph=None`: fewer full batches per epoch than this train eagerly
+
+
+def _capture_or_eager(graphed: "_GraphedStep", x: torch.Tensor, world: int):
+    """The first capture (and every re-capture) of the graphed step, or None: a model variant that cannot be captured -- a quantiser
+    shape on the torch-operator path with a host synchronisation, a library that allocates inside the step -- trains eagerly with a
+    message instead of ending the run (it did train eagerly before hipGraph replay became the default).  The rolled-back warm-up
+    steps of `capture` restore parameters, optimizer state and random streams before the capture proper, and a failed capture leaves
+    nothing half-applied: `torch.cuda.graph` ends the capture on the way out.  With several ranks the outcome is agreed on (a rank
+    that fell back while the others replay would issue a different sequence of collectives)."""
+    ok = True
+    try:
+        graphed.capture(x)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        graphed.invalidate()
+        print(f"use_hip_graph: capturing the training step failed ({type(e).__name__}: {str(e)[:200]}); falling back to the eager step",
+              flush=True)
+    if world > 1:
+        import torch.distributed as _dist
+        flags = [None] * world
+        _dist.all_gather_object(flags, ok)
+        ok = all(flags)
+    return graphed if ok else None
 
 
 @gin.configurable
@@ -280,21 +308,26 @@ def train(
 
     t = 0.2  # the reference's constant gumbel temperature (train_rqvae.py:177)
     graphed = None
+    if world > 1:
+        # A replayed step issues another sequence of collectives than an eager one (early + late runs vs one whole-buffer all-reduce), so
+        # every rank must take the same branch on the same iterations.  That follows from identical batchers -- the same number of rows and
+        # the same batch size on every rank -- and from the same graph decision; gathered on EVERY rank whatever its own decision (a rank
+        # that decided "eager" from its own inputs while the others capture would hang in the first collective).
+        mine = (len(train_dataset), int(batch_size), int(gradient_accumulate_every), bool(graphable))
+        seen = [None] * world
+        _dist.all_gather_object(seen, mine)
+        if any(other != mine for other in seen):
+            if rank == 0 and any(g for *_x, g in seen):
+                print(f"use_hip_graph: ranks disagree on (rows, batch_size, accumulate, graph) = {seen}; every rank takes the eager step")
+            graphable = False
+    if graphable and use_hip_graph is None and len(train_dataset) // max(batch_size, 1) < _AUTO_GRAPH_MIN_FULL_BATCHES:
+        # auto mode: every epoch tail (a short batch, eager) costs a re-capture -- two rolled-back warm-up steps, a snapshot of the
+        # optimizer state and the capture; with only a handful of full batches between two of them the graph cannot pay that back
+        graphable = False
     if graphable:
         # several ranks: the RCCL all-reduces of FlatGradReducer are captured with the step (one graph per rank, replayed in
         # lockstep: every rank runs the same sequence of full batches; the short batch that ends an epoch is eager on all of them)
         graphed = _GraphedStep(model, optimizer, reducer, batch_size, vae_input_dim, device, t)
-        if world > 1:
-            # A replayed step issues another sequence of collectives than an eager one (early + late runs vs one whole-buffer
-            # all-reduce), so every rank must take the same branch on the same iterations.  That follows from identical batchers: the
-            # same number of rows and the same batch size on every rank -- checked once here; ranks that disagree train eagerly.
-            mine = (len(train_dataset), int(batch_size), int(gradient_accumulate_every))
-            seen = [None] * world
-            _dist.all_gather_object(seen, mine)
-            if any(other != mine for other in seen):
-                if rank == 0:
-                    print(f"use_hip_graph: ranks disagree on (rows, batch_size, accumulate) = {seen}; falling back to the eager step")
-                graphed = None
     graph_after = start_iter + 3  # a few eager steps first (k-means init, allocator warm-up)
     window: List[torch.Tensor] = []
     shown = (float("nan"),) * 3
@@ -325,7 +358,8 @@ def train(
                 graphed = None
         if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
             if graphed.graph is None:
-                graphed.capture(data.x)
+                graphed = _capture_or_eager(graphed, data.x, world)
+        if graphed is not None and graphed.graph is not None and it >= graph_after and data.x.shape[0] == batch_size:
             model_output = graphed.run(data.x)
             total_loss = model_output.loss.detach()
         else:

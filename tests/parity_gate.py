@@ -20,7 +20,11 @@ import torch
 
 INPUT_DIM, HIDDEN, EMBED = 768, [512, 256, 128], 32
 TAU_KERNEL = 1e-6   # identical inputs: only the summation order of quantize.py:113-117 differs (few ulp)
-TAU_E2E = 2e-5      # inputs differ too: the encoder GEMMs (hipBLASLt vs MKL) perturb res0 by ~1e-6 relative
+TAU_E2E = 2e-6      # inputs differ too: the encoder GEMMs (another summation order than MKL's) perturb res0 in its last bits;
+                    # largest margin of a mismatching row ever measured (rounds 3-5, C4 shape, 2 x 300 000 rows): 6.5e-7
+# ceilings on the mismatching rows PER MODE (eval / STE train), end to end, per fixture: measured 0-1 (c2, 100 000 rows) and 9 (c4 shape,
+# 300 000 rows) -- a regression that multiplied the near-tie flips would fail here long before the exact-match rate moved
+E2E_MISMATCH_CEILING = {"c2": 2, "c4": 15}
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -90,3 +90,37 @@ def test_flat_adamw_in_a_captured_graph_advances_its_step_counter():
         ropt.step()
     for a, b in zip(ps, ref):
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+def test_flat_adamw_on_a_model_with_odd_sizes_through_the_flat_gradient_buffer():
+    """gradients that are views of rqhip.dist.FlatGradReducer's buffer stay 16-byte aligned behind parameters whose numel is
+    not a multiple of 4 (the slices are padded), and a misaligned gradient from anywhere else is copied instead of rejected."""
+    from rqhip.dist import FlatGradReducer
+    from rqhip.optim import FlatAdamW
+    torch.manual_seed(5)
+    shapes = [(7, 3), (5,), (9, 7), (2, 2)]
+    ours = [torch.randn(s).cuda().requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+    red = FlatGradReducer(ours)
+    opt, ropt = FlatAdamW(ours, lr=1e-2, weight_decay=1e-2), torch.optim.AdamW(ref, lr=1e-2, weight_decay=1e-2, foreach=True)
+    for step in range(3):
+        gs = [torch.randn(s).cuda() for s in shapes]
+        for p, v, q, g in zip(ours, red._views, ref, gs):
+            v.copy_(g)
+            p.grad = v                      # a view of the padded flat buffer
+            q.grad = g.clone()
+            assert v.data_ptr() % 16 == 0
+        opt.step()
+        ropt.step()
+    for a, b in zip(ours, ref):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+    # a packed buffer WITHOUT padding (somebody else's): the second gradient starts 84 bytes in
+    packed = torch.randn(21 + 5, device="cuda")
+    ours[0].grad, ours[1].grad = packed[:21].view(7, 3), packed[21:]
+    ours[2].grad = ours[3].grad = None
+    ref[0].grad, ref[1].grad = packed[:21].view(7, 3).clone(), packed[21:].clone()
+    ref[2].grad = ref[3].grad = None
+    opt.step()
+    ropt.step()
+    for a, b in zip(ours[:2], ref[:2]):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())

@@ -336,3 +336,19 @@ def test_small_batch_weight_gradient_routing_and_its_abi_argument_checks():
     assert l.rqhip_linear_wgrad_jobs(None, None, None, None, None, 0, 640, None) == 0      # no jobs: nothing to do
     with pytest.raises(_lib.RqHipError):
         ops.linear_wgrad_jobs([(torch.zeros(8, 64), torch.zeros(8, 64))])                              # CPU tensors: no fallback
+
+
+def test_flat_grad_reducer_pads_every_slice_to_16_bytes():
+    """a parameter whose numel is not a multiple of 4 must not misalign the slices behind it (csrc/adamw.hip and the
+    weight-gradient sinks read 16 bytes at a time)."""
+    from rqhip.dist import FlatGradReducer
+    ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((3,), (5, 1), (2, 4), (7,), (4, 4))]
+    red = FlatGradReducer(ps)
+    assert red._offsets == [0, 4, 12, 20, 28] and red.flat.numel() == 44
+    for p, v in zip(ps, red._views):
+        assert v.shape == p.shape and v.storage_offset() % 4 == 0
+    # contiguous runs cover the padding (one all-reduce per run); a run never splits a parameter
+    assert red._runs([0, 1, 2]) == [(0, 20)] and red._runs([0, 2]) == [(0, 4), (12, 20)] and red._runs([3, 4]) == [(20, 44)]
+    for v in red._views:
+        v.fill_(1.0)
+    assert float(red.flat.sum()) == 3 + 5 + 8 + 7 + 16          # the padding floats stay zero

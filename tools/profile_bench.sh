@@ -6,7 +6,7 @@
 # gpurun_out/prof_$TAG/; tools/summarize_profile.py turns them into the files committed under profiles/.
 set -u
 REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
-TAG="${TAG:-r03}"
+TAG="${TAG:-r06}"
 CFG="${CFG:-c2}"   # c2 | c4
 OUT="$REPO/gpurun_out/prof_${TAG}$([ $CFG = c2 ] || echo _$CFG)"
 mkdir -p "$OUT"
@@ -19,7 +19,8 @@ timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/s
     python "$REPO/bench.py" --config $CFG --steps $([ $CFG = c2 ] && echo 20 || echo 3) --warmup 3 --no-cpu-baseline --no-parity --no-small-batch --no-strict --min-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
-        python "$REPO/bench.py" --config $CFG --steps $([ $CFG = c2 ] && echo 5 || echo 1) --warmup 2 --no-cpu-baseline --no-parity --no-small-batch --no-strict --min-seconds 0 > /dev/null 2> "$OUT/pmc_$c.err"
+        python "$REPO/bench.py" --config $CFG --steps $([ $CFG = c2 ] && echo 5 || echo 1) --warmup 2 --no-cpu-baseline --no-parity --no-small-batch --no-strict --min-seconds 0 \
+            --pmc-window "$OUT/window_tags_$c.json" > /dev/null 2> "$OUT/pmc_$c.err"
 done
 # keep what summarize_profile.py reads (gpurun copies back at most 64 MiB): the stats table, and the counter rows
 # of the hand-written kernels; drop the per-dispatch traces

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 CFG = sys.argv[2] if len(sys.argv) > 2 else "c2"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}" + ("" if CFG == "c2" else f"_{CFG}"))
 PRE = TAG if CFG == "c2" else f"{TAG}_{CFG}"     # file-name prefix under profiles/
@@ -71,6 +71,56 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         k[f"{counter}_KB_max"] = max(vals)
         k[f"{counter}_KB_mean"] = sum(vals) / len(vals)
         k["launches_fetch" if counter == "FETCH_SIZE" else "launches_write"] = len(vals)
+# ---- HBM bytes per launch SHAPE: the dispatches between the two marker launches of bench.py --pmc-window, matched in order to the tags ----
+MAIN = ("gemm_f16_kernel", "gemm_split_kernel", "wgrad_split_kernel", "wgrad_kernel<", "wgrad_jobs_kernel")
+shape_bytes, shape_note = {}, []
+for counter, weight in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):     # gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)
+    tags_file = os.path.join(SRC, f"window_tags_{counter}.json")
+    if not os.path.exists(tags_file):
+        shape_note.append(f"{counter}: no window_tags file")
+        continue
+    tags = json.load(open(tags_file))["tags"]
+    disp = {}
+    for r in csv.DictReader(open(one(f"pmc_{counter}/**/*counter_collection.csv"))):
+        if "rqhip::" not in r["Kernel_Name"] or r["Counter_Name"] != counter:
+            continue
+        d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "grid": int(r.get("Grid_Size", 0) or 0), "kb": 0.0})
+        d["kb"] += float(r["Counter_Value"])
+    order = [disp[k] for k in sorted(disp)]
+    marks = [i for i, d in enumerate(order) if "maxima_kernel" in d["name"] and d["grid"] == 256]
+    if len(marks) < 2:
+        shape_note.append(f"{counter}: markers not found ({len(marks)})")
+        continue
+    win = order[marks[-2] + 1:marks[-1]]
+    seq, cur = [], None
+    for d in win:
+        if any(m in d["name"] for m in MAIN):
+            cur = {"kb": d["kb"], "name": d["name"]}
+            seq.append(cur)
+        elif "wgrad_reduce_kernel" in d["name"] and cur is not None:
+            cur["kb"] += d["kb"]               # the partial-block reduction belongs to the weight gradient before it
+    if len(seq) != len(tags):
+        shape_note.append(f"{counter}: {len(seq)} matrix dispatches in the window vs {len(tags)} tags")
+        continue
+    per = {}
+    for d, (kind, fl, by) in zip(seq, tags):
+        per.setdefault(f"{kind}:{int(fl)}:{int(by)}", []).append(d["kb"] * 1024.0)
+    for k, v in per.items():
+        shape_bytes[k] = shape_bytes.get(k, 0.0) + weight * sum(v) / len(v)
+    shape_note.append(f"{counter}: {len(seq)} dispatches matched")
+ok_shapes = all("matched" in n for n in shape_note) and len(shape_note) == 2
+with open(os.path.join(DST, f"{TAG}_pmc_kernels_{cfg_name}.json"), "w") as f:
+    json.dump({"librqhip_sha256": lib_sha,
+               "what": "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) of every matrix-kernel launch shape of one "
+                       "training step; key = 'kind:algorithmic flops:algorithmic bytes' (the tags of rqhip_profile_*); a weight gradient includes "
+                       "its partial-block reduction launches; bench.py --pmc-window brackets the step, tools/summarize_profile.py matches in order",
+               "matching": shape_note, "kernels": shape_bytes if ok_shapes else {}}, f, indent=1)
+    f.write("\n")
+print("per-shape traffic:", shape_note)
+for k, v in sorted(shape_bytes.items(), key=lambda kv: -kv[1]):
+    kind, fl, by = k.split(":")
+    print(f"  {kind:12s} {float(fl) / 1e9:8.2f} GFLOP  algorithmic {float(by) / 1e6:8.1f} MB  PMC {v / 1e6:8.1f} MB  ratio {v / float(by):.3f}")
+
 fwk = [k for k in pmc["kernels"] if "rq_forward_kernel" in k and "FETCH_SIZE_KB_max" in pmc["kernels"][k]
        and "WRITE_SIZE_KB_max" in pmc["kernels"][k]]
 if fwk:
