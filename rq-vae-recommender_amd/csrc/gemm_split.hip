@@ -445,13 +445,15 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
         // the WN column waves of a row meet in LDS (red / mred lie behind the transposition blocks), in wave order
         __syncthreads();
         if (want_rowmax) {
-            unsigned *dst = p.c_rowmax + (size_t)(n0 / COLS) * p.M;
+            // (parts are counted per 256 columns by the callers: a 512-column tile writes its maximum into both of its parts)
+            unsigned *dst = p.c_rowmax + (size_t)(n0 / (COLS > 256 ? 256 : COLS)) * p.M;
             for (int r = tid; r < ROWS; r += kGsThreads) {
                 if (m0 + r >= p.M) continue;
                 unsigned mx = mred[r];
 #pragma unroll
                 for (int w = 1; w < WN; ++w) mx = gs_umax(mx, mred[w * ROWS + r]);
                 dst[m0 + r] = mx;
+                if (COLS > 256) dst[p.M + m0 + r] = mx;
             }
         }
         if (EPI == 2) {
@@ -667,9 +669,11 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
 //   * every load is unconditional (rows past M re-read row M - 1 and are never stored): the loop body is ONE basic block,
 //     which lets the scheduler overlap the split arithmetic of the next stage with the matrix instructions of this one.
 // Same products in the same order per accumulator as gs_tile<.., NP = 2, ..>: identical result bits.
-template <int EPI, int TA>
+template <int EPI, int TA, int COLS = 256>
 __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbuf, int *s_aexp, unsigned *s_colmax, long long m0, int n0) {
-    constexpr int COLS = 256, WAVES = 4, UB = kGsUB, kThreads = 64 * WAVES;
+    // COLS = 256: 4 waves side by side (the product); COLS = 512: 8 waves side by side, ONE workgroup per CU -- the full output width of the
+    // 512-column layers, so that a strip of A is fetched and split once per row tile (A/B arm, tile_rows = -5)
+    constexpr int WAVES = COLS / 64, UB = kGsUB, kThreads = 64 * WAVES;
     constexpr int ROWS = 32 * TA;
     constexpr int AQ = (ROWS * 4 + kThreads - 1) / kThreads;         // float4s of A per thread and stage (2 for 128 rows, 1 for 32)
     constexpr bool kAllLive = (ROWS * 4) % kThreads == 0;
@@ -873,9 +877,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSpl
 // [16] workgroups that have left (the last one re-arms all of them).  (Round 4 also tried starting the second workgroup of
 // every CU half a tile late: neutral to -7 %, tools/experiments/gemm_split_r04_variants.hip.)
 constexpr int kGsQueues = 8;
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams p) {
-    constexpr int kThreads = 256, kBigRows = 128, kSmallRows = 64, COLS = 256;
+template <int EPI, int COLS = 256>
+__global__ __launch_bounds__(COLS, COLS == 256 ? 2 : 1) void gemm_f16_kernel(const GemmSplitParams p) {
+    constexpr int kThreads = COLS, kBigRows = 128, kSmallRows = 64;
     constexpr unsigned kSmallBit = 0x80000000u, kNone = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
@@ -924,11 +928,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmSplitParams 
         // (the two workgroups of a CU read the same B stages), at the price of fetching every A strip once per column tile
         if (!(tile & kSmallBit)) {
             const int ct = p.rt_fastest ? (int)(tile / rt_big) : (int)(tile % nct), rt = p.rt_fastest ? (int)(tile % rt_big) : (int)(tile / nct);
-            gs_tile2<EPI, kBigRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
+            gs_tile2<EPI, kBigRows / 32, COLS>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
         } else {
             const unsigned st = tile & ~kSmallBit;
             const int ct = p.rt_fastest ? (int)(st / rt_small) : (int)(st % nct), rt = p.rt_fastest ? (int)(st % rt_small) : (int)(st / nct);
-            gs_tile2<EPI, kSmallRows / 32>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
+            gs_tile2<EPI, kSmallRows / 32, COLS>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
         }
     }
     if (lds_colmax) {   // (every wave of the workgroup passed the loop's barriers after its last LDS maximum)
@@ -1074,10 +1078,11 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     // arithmetic at 256-column tiles; the staged loop the rest: bf16x3 with 8 waves / one workgroup per CU, f16x2 at 128-column
     // tiles with 4 waves / two per CU.  tile_rows (tools only): force big (256 / 128) or small (64 / 32) tiles in the staged loop.
     const bool tile2 = np == 2 && cols == 256;
-    const int waves = np == 3 ? 8 : 4;
-    const int big_rows = 32 * waves;
+    const bool wide = tile2 && a->tile_rows == -5 && Nc % 512 == 0 && epi != RQHIP_EPI_RECON;   // (A/B arm: 128 x 512 tiles, 8 waves, one workgroup per CU)
+    const int waves = (np == 3 || wide) ? 8 : 4;
+    const int big_rows = wide ? 128 : 32 * waves;
     const int small_rows = tile2 ? 64 : (waves / (cols / 64)) * 32;
-    p.n_col_tiles = Nc / cols;
+    p.n_col_tiles = Nc / (wide ? 512 : cols);
     const long long slots = (long long)cus * (waves == 4 ? 2 : 1);
     // whole rounds of big tiles, the remainder as small tiles (see the kernels)
     const long long rt_all = (M + big_rows - 1) / big_rows;
@@ -1094,7 +1099,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
     size_t lds = tile2 ? (size_t)2 * 4 * (128 * 4 + 32) * 4 : (size_t)2 * (np * 2 * (big_rows + cols) * 16);   // the stage buffers
-    const size_t lds_epi = gs_epilogue_lds(waves, big_rows, cols / 64);                                         // re-used by the epilogue
+    const size_t lds_epi = gs_epilogue_lds(waves, big_rows, wide ? 8 : cols / 64);                              // re-used by the epilogue
     if (lds < lds_epi) lds = lds_epi;
     const long long tiles = (long long)p.n_tiles;
     const int grid = (int)(tiles < slots ? tiles : slots);
@@ -1109,7 +1114,9 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         return 0;
     };
     int rc;
-    if (tile2) {
+    if (wide) {
+        rc = epi == 3 ? go(gemm_f16_kernel<3, 512>) : epi == 1 ? go(gemm_f16_kernel<1, 512>) : go(gemm_f16_kernel<0, 512>);
+    } else if (tile2) {
         rc = epi == 3 ? go(gemm_f16_kernel<3>) : epi == 2 ? go(gemm_f16_kernel<2>) : epi == 1 ? go(gemm_f16_kernel<1>) : go(gemm_f16_kernel<0>);
     } else if (np == 2) {
         rc = epi == 3 ? go(gemm_split_kernel<3, 128, 2, 4>) : epi == 1 ? go(gemm_split_kernel<1, 128, 2, 4>) : go(gemm_split_kernel<0, 128, 2, 4>);

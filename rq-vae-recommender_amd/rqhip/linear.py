@@ -172,6 +172,27 @@ def wgrad_jobs_ok(rows: int, shapes) -> bool:
                 and all(ops.linear_wgrad_jobs_supported(n, k) for n, k in shapes))
 
 
+_WIDE_TILES = False
+_WIDE_MIN_RED = 512
+
+
+def use_wide_tiles(on: bool = True) -> bool:
+    """A/B arm, default OFF (round 6): layers of 512 (mod 512) output columns with a reduction of 512 and more on
+    full-output-width tiles (128 x 512, 8 waves, ONE workgroup per CU: a strip of A is fetched and split once per row tile) instead of
+    two 128 x 256 tiles of two workgroups per CU.  Same result bits; HBM traffic and VALU work per matrix instruction fall as intended
+    and the kernels get 4-6 % SLOWER inside the step (768 -> 512 forward 258 -> 273 us, its data gradient 269 -> 280 us:
+    profiles/r06_gemm_wide_ab.txt) -- eight waves behind one barrier idle together, two independent workgroups do not.
+    bench.py --wide-tiles, tools/gemm_wide_ab.py.  Returns the previous setting."""
+    global _WIDE_TILES
+    before, _WIDE_TILES = _WIDE_TILES, bool(on)
+    return before
+
+
+def _tile_code(n_cols: int, n_red: int, epilogue: int) -> int:
+    """rqhip_gemm_args.tile_rows for a layer: -5 selects the 128 x 512 tile (csrc/gemm_split.hip), 0 the default."""
+    return -5 if (_WIDE_TILES and f16() and n_cols % 512 == 0 and n_red >= _WIDE_MIN_RED and epilogue != _lib.EPI_RECON) else 0
+
+
 def images(jobs: List[Tuple[Tensor, bool]]) -> List[Tensor]:
     """The weight images of `jobs` = [(w, transpose), ...] in the current arithmetic, one launch.  Rebuilt at EVERY forward:
     a first version cached an image per `w._version` -- and trained on stale weights: the fused AdamW update (and any
@@ -194,7 +215,7 @@ def gemm(a: Tensor, image: Tensor, n_cols: int, *, epilogue: int = _lib.EPI_STOR
     rows_in = ensure_scales(a, a_scales, True, False).rows if f16() else None
     c, loss_rows, crm = ops.gemm_split_ex(a, image, n_cols, arith=_ARITH, epilogue=epilogue, aux=aux, row_scale=row_scale,
                                           a_row_max=rows_in, want_row_max=want_rows and f16(),
-                                          col_max_out=col_out if f16() else None)
+                                          col_max_out=col_out if f16() else None, tile_rows=_tile_code(n_cols, a.shape[1], epilogue))
     return c, loss_rows, Scales(crm, col_out if f16() else None)
 
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""A/B of the product GEMM tile (128 x 256, 4 waves, two workgroups per CU) against the full-output-width tile of the 512-column layers
+(128 x 512, 8 waves, ONE workgroup per CU: every strip of A is fetched and split once per row tile) -- VERDICT r5 item 1(a).
+f16x2 arithmetic, row + column maxima emitted as in the training step; 100 000 rows; times back to back (HIP events) and bits compared.
+usage (GPU box): python tools/gemm_wide_ab.py [rows]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "rq-vae-recommender_amd")]
+from rqhip import _lib, ops  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+print(f"{'R -> Nc':>12} {'epilogue':>8} | {'128x256 x2':>10} {'128x512 x1':>10} | bits equal (C, row max, col max)")
+torch.manual_seed(0)
+for R, Nc in [(768, 512), (256, 512), (512, 512), (768, 1024)]:
+    x = torch.relu(torch.randn(M, R, device="cuda"))
+    w = torch.randn(Nc, R, device="cuda") / R ** 0.5
+    y = torch.relu(torch.randn(M, Nc, device="cuda"))
+    img = ops.weight_planes(w, arith=ops.F16X2)
+    rows = ops.maxima(x, cols=False)[0]
+    for name, epi, aux in (("relu", _lib.EPI_RELU, None), ("mask", _lib.EPI_MASK, y), ("store", _lib.EPI_STORE, None)):
+        outs, ts = [], []
+        for tr in (0, -5):
+            def run():
+                cm = torch.zeros(Nc, dtype=torch.int32, device="cuda")
+                c, _, crm = ops.gemm_split_ex(x, img, Nc, epilogue=epi, aux=aux, a_row_max=rows, want_row_max=True, col_max_out=cm, tile_rows=tr)
+                return c, crm, cm
+            outs.append(run())
+            ts.append(timeit(run))
+        (c0, r0, m0), (c1, r1, m1) = outs
+        same = (torch.equal(c0, c1), torch.equal(r0.max(dim=0).values, r1.max(dim=0).values), torch.equal(m0, m1))
+        print(f"{R:5d} -> {Nc:4d} {name:>8} | {ts[0]:10.1f} {ts[1]:10.1f} | {same}")
