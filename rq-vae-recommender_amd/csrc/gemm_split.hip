@@ -818,11 +818,13 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
 // The staged-B loop (gs_tile): instantiated for the two shapes the product kernel does not take -- the three-piece bf16
 // arithmetic (A/B arm `bench.py --mlp split6`: 8 waves, one workgroup per CU, 256-row tiles) and 128-column tiles of the
 // f16x2 arithmetic (layers of 128 (mod 256) columns: 4 waves, two workgroups per CU, 128-row tiles).
-template <int EPI, int COLS, int NP, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void gemm_split_kernel(const GemmSplitParams p) {
+// BIGROWS (0 = 32 WAVES): rows of the big tile.  <.., 256, 2, 8, 128> is round 6's occupancy A/B arm (tile_rows = -6): 8 waves of
+// 64 x 64 (64 accumulators, <= 128 registers), TWO workgroups per CU = four waves per SIMD, both operands through LDS.
+template <int EPI, int COLS, int NP, int WAVES, int BIGROWS = 0>
+__global__ __launch_bounds__(64 * WAVES, BIGROWS ? 4 : 2) void gemm_split_kernel(const GemmSplitParams p) {   // (second argument: waves per SIMD)
     constexpr int kGsThreads = 64 * WAVES;
     constexpr int kSmallRows = (WAVES / (COLS / 64)) * 32;   // WAVES = 8: 64 (COLS = 256) or 128 (COLS = 128); WAVES = 4: half
-    constexpr int kBigRows = 32 * WAVES;
+    constexpr int kBigRows = BIGROWS ? BIGROWS : 32 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
     __shared__ unsigned s_tile;
@@ -1079,11 +1081,12 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     // tiles with 4 waves / two per CU.  tile_rows (tools only): force big (256 / 128) or small (64 / 32) tiles in the staged loop.
     const bool tile2 = np == 2 && cols == 256;
     const bool wide = tile2 && a->tile_rows == -5 && Nc % 512 == 0 && epi != RQHIP_EPI_RECON;   // (A/B arm: 128 x 512 tiles, 8 waves, one workgroup per CU)
-    const int waves = (np == 3 || wide) ? 8 : 4;
-    const int big_rows = wide ? 128 : 32 * waves;
+    const bool occ4 = tile2 && a->tile_rows == -6 && epi != RQHIP_EPI_RECON;                    // (A/B arm: 128 x 256 tiles, 8 waves of 64 x 64, two workgroups per CU)
+    const int waves = (np == 3 || wide || occ4) ? 8 : 4;
+    const int big_rows = (wide || occ4) ? 128 : 32 * waves;
     const int small_rows = tile2 ? 64 : (waves / (cols / 64)) * 32;
     p.n_col_tiles = Nc / (wide ? 512 : cols);
-    const long long slots = (long long)cus * (waves == 4 ? 2 : 1);
+    const long long slots = (long long)cus * ((waves == 4 || occ4) ? 2 : 1);
     // whole rounds of big tiles, the remainder as small tiles (see the kernels)
     const long long rt_all = (M + big_rows - 1) / big_rows;
     long long rt_big = ((rt_all * p.n_col_tiles) / slots) * slots / p.n_col_tiles;   // row tiles of the whole rounds
@@ -1098,7 +1101,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.rt_big = (int)rt_big;
     p.n_big = (unsigned)(rt_big * p.n_col_tiles);
     p.n_tiles = p.n_big + (unsigned)(rt_small * p.n_col_tiles);
-    size_t lds = tile2 ? (size_t)2 * 4 * (128 * 4 + 32) * 4 : (size_t)2 * (np * 2 * (big_rows + cols) * 16);   // the stage buffers
+    size_t lds = (tile2 && !occ4) ? (size_t)2 * 4 * (128 * 4 + 32) * 4 : (size_t)2 * (np * 2 * (big_rows + cols) * 16);   // the stage buffers
     const size_t lds_epi = gs_epilogue_lds(waves, big_rows, wide ? 8 : cols / 64);                              // re-used by the epilogue
     if (lds < lds_epi) lds = lds_epi;
     const long long tiles = (long long)p.n_tiles;
@@ -1114,7 +1117,9 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         return 0;
     };
     int rc;
-    if (wide) {
+    if (occ4) {
+        rc = epi == 3 ? go(gemm_split_kernel<3, 256, 2, 8, 128>) : epi == 1 ? go(gemm_split_kernel<1, 256, 2, 8, 128>) : go(gemm_split_kernel<0, 256, 2, 8, 128>);
+    } else if (wide) {
         rc = epi == 3 ? go(gemm_f16_kernel<3, 512>) : epi == 1 ? go(gemm_f16_kernel<1, 512>) : go(gemm_f16_kernel<0, 512>);
     } else if (tile2) {
         rc = epi == 3 ? go(gemm_f16_kernel<3>) : epi == 2 ? go(gemm_f16_kernel<2>) : epi == 1 ? go(gemm_f16_kernel<1>) : go(gemm_f16_kernel<0>);
