@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 440 /* major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 450 /* 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -429,6 +429,49 @@ int rqhip_recon_rescale_rows_ex(const float *g_out, int64_t B, int N, float row_
                                 int row_parts, unsigned *col_max, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The RQ <-> MLP seam (first clause): the encoder's last Linear (128 -> D), every quantisation level and the
+ * decoder's first Linear (D -> 128) + ReLU as ONE row-local launch -- reference modules/rqvae.py:118-139 (`res = self.encode(x)` ends
+ * in that Linear, modules/encoder.py:25-38; the level loop) and :146 (`self.decode(embs.sum(axis=-1))` starts with the other).  D = 32
+ * and a hidden width of 128 (the reference's configs/rqvae_amazon.gin); all levels' codebooks must fit the LDS next to the two weights
+ * (rqhip_rq_seam_supported).  Either GEMM and the quantisation can be switched off, which makes the same kernel the stand-alone
+ * 128 -> D / D -> 128 layer: the data gradients of the backward, with the ReLU backward applied on load (h_mask) or in the epilogue
+ * (RQHIP_EPI_MASK).  Arithmetic: every GEMM output is ONE fp32 FMA chain over the input features in ascending order (the fp32 matrix
+ * instruction, as the distance scan of rqhip_rq_forward): independent of batch size and launch form, restated by
+ * oracle/rq_oracle.c:rqo_linear_chain; the quantisation is rqhip_rq_forward's, bit for bit, on the res0 the input GEMM produced.
+ */
+typedef struct {
+    int64_t B;
+    int D;                  /* 32 */
+    int H;                  /* width of h / out: 128 */
+    /* input side: h given -> res0 = h' . Win^T, h' = h where h_mask > 0 else 0 (h_mask NULL: h' = h); h NULL -> rows come from res0 */
+    const float *h;         /* [B, H] or NULL */
+    const float *h_mask;    /* [B, H] or NULL */
+    const float *w_in;      /* [D, H] row-major (nn.Linear.weight of the H -> D layer); w_in_transposed: [H, D], used as its transpose */
+    int w_in_transposed;
+    const float *res0;      /* [B, D]: the rows when h == NULL */
+    float *res0_out;        /* [B, D] or NULL: the input GEMM's result */
+    /* quantisation: L == 0 skips it (the rows go straight to the output GEMM); else as rqhip_rq_forward (filtered scan, all levels resident) */
+    const float *codebooks; /* [L, K, D] */
+    int L, K, mode;         /* RQHIP_MODE_EVAL / STE / ROTATION */
+    float beta;
+    int64_t *ids;           /* [L, B] */
+    float *emb_sum;         /* [B, D] or NULL */
+    float *loss;            /* [B] or NULL */
+    float *embs_norm;       /* [B, L] or NULL */
+    /* output side: w_out given -> out = epilogue(s . Wout^T), s = the sum of the levels' outputs (L == 0: the rows) */
+    const float *w_out;     /* [H, D] row-major (nn.Linear.weight of the D -> H layer); w_out_transposed: [D, H], used as its transpose; or NULL */
+    int w_out_transposed;
+    int out_epilogue;       /* RQHIP_EPI_STORE / RQHIP_EPI_RELU / RQHIP_EPI_MASK (out where out_mask > 0 else 0) */
+    const float *out_mask;  /* [B, H]: RQHIP_EPI_MASK */
+    float *out;             /* [B, H] */
+    unsigned *out_row_max;  /* optional [H / 32][B]: bit patterns of the largest |value| of each row of `out` per 32-column block (the
+                               a_row_max / a_row_parts = H / 32 of the rqhip_gemm_split_ex that reads `out` next) */
+    unsigned *out_col_max;  /* optional [H]: column maxima of `out`, maxed into atomically (zero it first) */
+} rqhip_seam_args;
+int rqhip_rq_seam_supported(int D, int H, int L, int K);   /* 1 when rqhip_rq_seam takes these shapes on the current device */
+int rqhip_rq_seam(const rqhip_seam_args *args, rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The AdamW update of all parameters in one launch (reference train_rqvae.py:136-138: AdamW with decoupled weight decay on every
  * parameter, codebooks included).  Arithmetic of torch's `_fused_adamw_` in fp32 (no amsgrad, no maximize); tensors p / g / m / v of
  * numel[i] contiguous fp32 elements, 16-byte aligned, caller-owned; `step`: device float scalar = steps taken so far, incremented by
@@ -450,6 +493,7 @@ int rqhip_adamw_step(float *const *p, const float *const *g, float *const *m, fl
 #define RQHIP_PROF_WGRAD 4       /* rqhip_linear_wgrad*: the kernel and its partial-sum reduction */
 #define RQHIP_PROF_MAXIMA 5      /* rqhip_maxima */
 #define RQHIP_PROF_IMAGES 6      /* rqhip_weight_images */
+#define RQHIP_PROF_SEAM 7        /* rqhip_rq_seam: flops = the GEMMs' 2 B D H each + the levels' L (2 D K + 5 D) per row */
 typedef struct {
     int tag;
     float ms;

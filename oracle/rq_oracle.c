@@ -680,3 +680,29 @@ int rqo_linear_wgrad(const float *g, const float *y, const float *x, int64_t M, 
     free(gp); free(leaf);
     return RQO_OK;
 }
+
+/* ---- the RQ <-> MLP seam's linear layers (csrc/rq_forward.hip: seam_in / seam_out; reference modules/encoder.py:25-38, a bias-free
+ * nn.Linear, optionally followed by ReLU) -------------------------------------------------------------------------------------------
+ * out[b][n] = epilogue( chain_d x'[b][d] * W(n, d) ): ONE fp32 FMA chain over the input features d = 0 .. n_in - 1 from 0 (what the fp32
+ * matrix instruction accumulates, as dot_chain above).
+ *   x'     = x where xmask > 0 else 0 (xmask NULL: x) -- aten.threshold_backward(x, xmask, 0), the ReLU backward of a data gradient
+ *   W(n,d) = transposed ? w[d * n_out + n] : w[n * n_in + d]
+ *   epilogue: 0 store, 1 relu (v < 0 -> 0; NaN stays), 3 mask (omask <= 0 -> 0) */
+int rqo_linear_chain(const float *x, const float *xmask, int64_t B, int n_in, const float *w, int n_out, int transposed, int epilogue,
+                     const float *omask, float *out) {
+    if (B < 0 || n_in < 1 || n_out < 1 || !w || (B > 0 && (!x || !out)) || (epilogue == 3 && !omask)) return -1;
+    for (int64_t b = 0; b < B; ++b) {
+        for (int n = 0; n < n_out; ++n) {
+            float acc = 0.0f;
+            for (int d = 0; d < n_in; ++d) {
+                float xv = x[(size_t)b * n_in + d];
+                if (xmask && xmask[(size_t)b * n_in + d] <= 0.0f) xv = 0.0f;
+                acc = fmaf(xv, transposed ? w[(size_t)d * n_out + n] : w[(size_t)n * n_in + d], acc);
+            }
+            if (epilogue == 1 && acc < 0.0f) acc = 0.0f;
+            if (epilogue == 3 && omask[(size_t)b * n_out + n] <= 0.0f) acc = 0.0f;
+            out[(size_t)b * n_out + n] = acc;
+        }
+    }
+    return 0;
+}

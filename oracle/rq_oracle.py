@@ -254,3 +254,18 @@ def linear_wgrad(g, y, x, msplit: int):
                                 _p(dw))
     _chk(rc, "linear_wgrad")
     return dw, gm
+
+
+def linear_chain(x, w, transposed: bool = False, epilogue: int = 0, xmask=None, omask=None) -> np.ndarray:
+    """out = epilogue(x' . W^T) with every output ONE fp32 FMA chain over the input features (rqo_linear_chain: the seam's GEMMs).
+    w: [n_out, n_in], or [n_in, n_out] with `transposed`; epilogue 0 store / 1 relu / 3 mask by omask > 0; xmask: x kept where > 0."""
+    x, w = _f(x), _f(w)
+    B, n_in = x.shape
+    n_out = w.shape[1] if transposed else w.shape[0]
+    assert (w.shape[0] if transposed else w.shape[1]) == n_in
+    xm = None if xmask is None else _f(xmask)
+    om = None if omask is None else _f(omask)
+    out = np.empty((B, n_out), dtype=np.float32)
+    _chk(lib().rqo_linear_chain(_p(x), _p(xm), C.c_int64(B), C.c_int(n_in), _p(w), C.c_int(n_out), C.c_int(1 if transposed else 0),
+                                C.c_int(int(epilogue)), _p(om), _p(out)), "linear_chain")
+    return out

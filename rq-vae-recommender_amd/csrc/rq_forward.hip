@@ -95,6 +95,17 @@ struct RqFwdParams {
     // filtered scan with all levels resident: the codebook norms are formed by the kernel itself while it stages the codes
     // (no rq_csq_kernel launch in front: 7-12 us of every call); fp32 copy in LDS for the exact re-decision
     int incsq;
+    // ---- the RQ <-> MLP seam (rq_seam_kernel only; SURVEY.md section 8 row f2, first clause) ----
+    const float *sm_h;        // [B, 128] rows in front of the input GEMM (res0 = h . w_in^T), or nullptr: rows come from res0
+    const float *sm_hmask;    // [B, 128] or nullptr: h is taken as h where hmask > 0 else 0 (the ReLU backward of a data gradient)
+    const float *sm_win;      // input weight, [D, 128] row-major (sm_win_t: [128, D], used transposed)
+    float *sm_res0_out;       // [B, D] the input GEMM's result (or nullptr)
+    const float *sm_wout;     // output weight, [128, D] row-major (sm_wout_t: [D, 128], used transposed); nullptr: no output GEMM
+    const float *sm_omask;    // [B, 128]: epilogue 3 keeps out where omask > 0
+    float *sm_out;            // [B, 128]
+    unsigned *sm_rowmax;      // [4][B] bit patterns of the largest |value| of every row's four 32-column blocks, or nullptr
+    unsigned *sm_colmax;      // [128] column maxima (atomic maxima: zeroed by the caller), or nullptr
+    int sm_win_t, sm_wout_t, sm_epi;   // epilogue: 0 store, 1 ReLU, 3 mask
 };
 
 // rows of a tile as lane (il, h) fetches them: full-width kernels take their half of the row as float4s ("raw", see
@@ -834,10 +845,10 @@ __device__ __forceinline__ void finish_split(float best, int bcode, const float 
 //       `best` / `second` then hold SCORES (larger is better), not distances.  next_tile >= 0: its rows are fetched into
 //       `rn` once the last level's scan is over (a prefetch issued before the tile would keep KSTEPS registers alive
 //       across every scan: the filtered kernel spilled 20 of them).
-template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN, bool FILT, int RES>
+template <int KSTEPS, int MODE, bool FULLD, int NT, bool COOP, bool MARGIN, bool FILT, int RES, bool SEAM = false>
 __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const float *csqmax_s, float *cand_s,
                                         float *gm_s, float *csqf_s, long long tile, float (&r)[KSTEPS], int D, int buf_floats,
-                                        int phase, long long next_tile, float (&rn)[KSTEPS]) {
+                                        int phase, long long next_tile, float (&rn)[KSTEPS], float *es_ret = nullptr) {
     constexpr int KQ = KSTEPS / 4;
     constexpr int S = FILT ? KSTEPS / 8 : 1;   // 16-wide K steps of the bf16 matrix instruction
     constexpr bool TRACK2 = MARGIN || FILT;   // the runner-up is tracked
@@ -1136,6 +1147,10 @@ __device__ __forceinline__ void rq_tile(const RqFwdParams &p, float *smem, const
     }
 
     RQ_STAMP(100);
+    if constexpr (SEAM) {    // the sum of the levels' outputs stays in registers for the output GEMM (seam_out)
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) es_ret[kk] = es[kk];
+    }
     if (writer) {
         long long rowv = row;
         asm volatile("" : "+v"(rowv));
@@ -1247,6 +1262,222 @@ __global__ __launch_bounds__(NT) void rq_forward_kernel(const RqFwdParams p) {
             RQ_TRACE(trace_slot);
             ++trace_slot;
         }
+    }
+}
+
+// ---- the RQ <-> MLP seam: 128 -> D GEMM, all levels, D -> 128 GEMM as ONE row-local launch ---------------------------------
+// SURVEY.md section 8 row f2, first clause; reference modules/rqvae.py:118-154 (encoder's last Linear, the level loop, embs.sum, the
+// decoder's first Linear + ReLU of modules/encoder.py:25-38).  A wave owns 32 rows from the encoder's 128-wide hidden activation to
+// the decoder's: res0 never leaves the registers between the GEMM that forms it and the scans, the sum of the levels' outputs goes
+// from the last level straight into the output GEMM.  Both GEMMs run on the fp32 matrix pipe with the weight's output features as
+// the A operand, i.e. every output is ONE fp32 FMA chain over the input features in ascending order -- the arithmetic of the
+// distance scan, restated by oracle/rq_oracle.c:rqo_linear_chain -- so the result does not depend on tiling, batch size or launch
+// form: the same kernel with L = 0 and one GEMM switched off IS the stand-alone 128 -> D / D -> 128 layer (the data gradients of
+// the backward, with the ReLU backward applied on load / in the epilogue), bit-identical to its fused use.
+// Weight images in LDS, behind everything rq_forward_kernel keeps there: the A-operand layout of stage_codes (float4 (q, h, n):
+// element j = W[n][d = 2 (4 q + j) + h]).
+constexpr int kSeamH = 128;                          // width of the hidden activation on either side
+constexpr int kSeamWFloats = kSeamH * 32;            // one weight image: 128 x 32 (either orientation) fp32, 16 KB
+constexpr int kSeamLdsFloats = 2 * kSeamWFloats + kSeamH;   // both images + the column maxima of the output
+
+// image[(q * 2 + hh) * n_out + n][j] = W(n, d) for d = 2 (4 q + j) + hh < n_in, W(n, d) = t ? w[d * n_out + n] : w[n * n_in + d]
+template <int NT>
+__device__ __forceinline__ void seam_stage_weight(float *img, const float *__restrict__ w, int n_out, int n_in, int t) {
+    const int total = n_out * n_in;
+    for (int e = threadIdx.x; e < total; e += NT) {
+        // walk the SOURCE contiguously (coalesced reads; the LDS writes scatter, once per workgroup)
+        const int n = t ? e % n_out : e / n_in, d = t ? e / n_out : e % n_in;
+        const int kk = d >> 1, hh = d & 1;
+        img[(((kk >> 2) * 2 + hh) * n_out + n) * 4 + (kk & 3)] = w[e];
+    }
+}
+
+// rows of tile `tile` of h [B, 128] -> res0 = h . w_in^T in pair layout (r[kk] = feature 2 kk + h of row il), stored to sm_res0_out
+template <int KSTEPS>
+__device__ __forceinline__ void seam_in(const RqFwdParams &p, const float *win_s, long long tile, int il, int h, bool store,
+                                        float (&r)[KSTEPS]) {
+    static_assert(KSTEPS == 16, "the seam kernels are built for D = 32");
+    constexpr int KH = kSeamH / 2;                       // 64 K steps of the 32x32x2 instruction
+    const long long row = tile * 32 + il;
+    const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
+    int hv = h;
+    asm volatile("" : "+v"(hv));                         // (per-lane row pointers are formed here, not hoisted across tiles)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.sm_h + ((size_t)rowc * kSeamH + hv * KH));
+    float raw[KH];
+#pragma unroll
+    for (int j = 0; j < KH / 4; ++j) {
+        const f32x4 q = src[j];
+        raw[4 * j + 0] = q.x; raw[4 * j + 1] = q.y; raw[4 * j + 2] = q.z; raw[4 * j + 3] = q.w;
+    }
+    if (p.sm_hmask) {   // threshold_backward(h, mask, 0): 0 where mask <= 0 (a NaN mask keeps the value, as torch does)
+        const f32x4 *msk = reinterpret_cast<const f32x4 *>(p.sm_hmask + ((size_t)rowc * kSeamH + hv * KH));
+#pragma unroll
+        for (int j = 0; j < KH / 4; ++j) {
+            const f32x4 m = msk[j];
+            raw[4 * j + 0] = m.x <= 0.0f ? 0.0f : raw[4 * j + 0];
+            raw[4 * j + 1] = m.y <= 0.0f ? 0.0f : raw[4 * j + 1];
+            raw[4 * j + 2] = m.z <= 0.0f ? 0.0f : raw[4 * j + 2];
+            raw[4 * j + 3] = m.w <= 0.0f ? 0.0f : raw[4 * j + 3];
+        }
+    }
+    float x[KH];
+    rows_to_pairs<KH>(raw, x);                           // x[kk] = feature 2 kk + h of row il
+    const f32x4 *img = reinterpret_cast<const f32x4 *>(win_s);
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 cur = img[(size_t)h * 32 + il];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+        const f32x4 nxt = img[(size_t)(((q + 1 < KH / 4) ? q + 1 : q) * 2 + h) * 32 + il];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i], x[4 * q + i], acc, 0, 0, 0);
+        cur = nxt;
+    }
+    // acc[j]: output feature 8 (j >> 2) + 4 h + (j & 3) of row il
+    if (store && p.sm_res0_out && tile < p.n_tiles && row < p.B) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.sm_res0_out + (size_t)row * (2 * KSTEPS) + 4 * hv);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[2 * g] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    }
+    // ... into pair layout: lane (il, 0) keeps its even features and takes the partner's, lane (il, 1) the odd ones
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = i >> 1, sx = i & 1;
+        rq_swap32(acc[2 * i], acc[2 * i + 1], r[4 * g + sx], r[4 * g + 2 + sx]);
+    }
+}
+
+// out[row][n] = epilogue(sum_d es[d] W_out(n, d)) for the 32-column blocks blk0, blk0 + bstep, ... < 4 of the 128 output columns
+template <int KSTEPS>
+__device__ __forceinline__ void seam_out(const RqFwdParams &p, const float *wout_s, unsigned *colmax_s, long long tile, int il, int h,
+                                         const float (&es)[KSTEPS], int blk0, int bstep) {
+    static_assert(KSTEPS == 16, "the seam kernels are built for D = 32");
+    const long long row = tile * 32 + il;
+    const bool row_ok = tile < p.n_tiles && row < p.B;
+    const long long rowc = row_ok ? row : (p.B - 1);
+    const f32x4 *img = reinterpret_cast<const f32x4 *>(wout_s);
+    int hv = h;
+    asm volatile("" : "+v"(hv));
+    for (int blk = blk0; blk < kSeamH / 32; blk += bstep) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KSTEPS / 4; ++q) {
+            const f32x4 a = img[(size_t)(q * 2 + h) * kSeamH + 32 * blk + il];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], es[4 * q + i], acc, 0, 0, 0);
+        }
+        // acc[j]: column 32 blk + 8 (j >> 2) + 4 h + (j & 3) of row il
+        const size_t at = (size_t)rowc * kSeamH + 32 * blk + 4 * hv;
+        unsigned rmx = 0u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (p.sm_epi == 1) {          // (a NaN stays a NaN, as torch.relu)
+                v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
+                v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+            } else if (p.sm_epi == 3) {   // threshold_backward(out, omask, 0)
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(p.sm_omask + at + 8 * g);
+                v.x = m.x <= 0.0f ? 0.0f : v.x; v.y = m.y <= 0.0f ? 0.0f : v.y;
+                v.z = m.z <= 0.0f ? 0.0f : v.z; v.w = m.w <= 0.0f ? 0.0f : v.w;
+            }
+            if (row_ok) *reinterpret_cast<f32x4 *>(p.sm_out + at + 8 * g) = v;
+            if (p.sm_rowmax || p.sm_colmax) {
+                const float vc[4] = {v.x, v.y, v.z, v.w};   // (scalars: `v[c]` inside this loop read element 0 for every c with this compiler)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned bits = row_ok ? (__builtin_bit_cast(unsigned, vc[c]) & 0x7fffffffu) : 0u;
+                    rmx = bits > rmx ? bits : rmx;
+                    if (p.sm_colmax) {
+                        // maximum over the 32 rows of the tile: lanes 0 .. 31 (h = 0) / 32 .. 63 (h = 1) hold the same column
+                        unsigned m = bits;
+                        m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, true));   // row_shr:1
+                        m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xf, 0xf, true));   // row_shr:2
+                        m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xf, 0xf, true));   // row_shr:4
+                        m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xf, 0xf, true));   // row_shr:8
+                        m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, true));   // row_bcast:15 -> rows 1, 3
+                        if (il == 31 && m != 0u) atomicMax(&colmax_s[32 * blk + 8 * g + 4 * h + c], m);
+                    }
+                }
+            }
+        }
+        if (p.sm_rowmax) {
+            const unsigned o = (unsigned)shfl_xor32((int)rmx);
+            rmx = o > rmx ? o : rmx;
+            if (row_ok && h == 0) p.sm_rowmax[(size_t)blk * p.B + row] = rmx;
+        }
+    }
+}
+
+// The seam kernel: rq_forward_kernel's filtered, all-levels-resident form at D = 32 (KSTEPS = 16, 768 threads) with the input GEMM in
+// front of every tile and the output GEMM behind it; L = 0 skips the quantisation (and the codebook staging) altogether.
+template <int MODE>
+__global__ __launch_bounds__(768) void rq_seam_kernel(const RqFwdParams p) {
+    constexpr int KSTEPS = 16, NT = 768, D = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 31, h = lane >> 5;
+    const int K = p.K, Kc = p.Kc, L = p.L;
+    const int buf_floats = Kc * (KSTEPS * 2 + 2);
+    constexpr int kWavesPerWg = NT / RQ_WAVE;
+    const long long total_waves = (long long)gridDim.x * kWavesPerWg;
+    const long long wave_slot = (long long)wave * gridDim.x + blockIdx.x;
+    float *csqmax_s = smem + L * buf_floats;
+    float *cand_s = csqmax_s + 16;
+    float *gm_s = cand_s + kCoopLdsFloats;
+    float *csqf_s = gm_s + (size_t)kWavesPerWg * 8 * 64 / (p.gm16 ? 2 : 1);
+    float *win_s = csqf_s + (size_t)L * Kc;
+    float *wout_s = win_s + kSeamWFloats;
+    unsigned *colmax_s = reinterpret_cast<unsigned *>(wout_s + kSeamWFloats);
+    if (tid < 16) csqmax_s[tid] = 0.0f;
+    if (tid < kCoopSteps) reinterpret_cast<int *>(cand_s + 2 * kCoopCandFloats)[tid] = 0;
+    if (tid < kSeamH) colmax_s[tid] = 0u;
+    if (p.sm_h) seam_stage_weight<NT>(win_s, p.sm_win, D, kSeamH, p.sm_win_t);
+    if (p.sm_wout) seam_stage_weight<NT>(wout_s, p.sm_wout, kSeamH, D, p.sm_wout_t);
+    if (L > 0) {
+        __syncthreads();   // the level maxima are zeroed before anybody raises them
+        stage_codes_bf16<KSTEPS, NT>(smem, buf_floats, L, p.cb, p.csq, p.Kp, 0, Kc, K, csqf_s, reinterpret_cast<unsigned *>(csqmax_s), 0);
+    }
+    __syncthreads();
+
+    float rn[KSTEPS];   // (no row prefetch across tiles here: a 128-wide row is 64 registers per lane)
+    auto tile_rows = [&](long long tile, float (&r)[KSTEPS], bool store) {
+        if (p.sm_h) {
+            seam_in<KSTEPS>(p, win_s, tile, il, h, store, r);
+        } else {
+            float raw[KSTEPS];
+            load_tile_rows<KSTEPS, true>(p, tile, il, h, D, raw);
+            rows_to_pairs<KSTEPS>(raw, r);
+        }
+    };
+    for (int it = 0; it < p.n_iter; ++it) {
+        const long long tile = (long long)it * total_waves + wave_slot;
+        if (tile >= p.coop_first) break;
+        float r[KSTEPS], es[KSTEPS];
+        tile_rows(tile, r, true);
+        if (L > 0) {
+            rq_tile<KSTEPS, MODE, true, NT, false, false, true, 1, true>(p, smem, csqmax_s, cand_s, gm_s, csqf_s, tile, r, D, buf_floats, 0,
+                                                                         -1, rn, es);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) es[kk] = r[kk];
+        }
+        if (p.sm_wout) seam_out<KSTEPS>(p, wout_s, colmax_s, tile, il, h, es, 0, 1);
+    }
+    // cooperative tiles (L > 0 only): the four waves of a tile each form res0 (wave 0 stores it) and, behind the levels, one 32-column
+    // block of the output
+    if (L > 0 && wave < kCoopWaves) {
+        int phase = 0;
+        for (long long tile = p.coop_first + blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+            float r[KSTEPS], es[KSTEPS];
+            tile_rows(tile, r, wave == 0);
+            rq_tile<KSTEPS, MODE, true, NT, true, false, true, 1, true>(p, smem, csqmax_s, cand_s, gm_s, csqf_s, tile, r, D, buf_floats,
+                                                                        phase, -1, rn, es);
+            phase += L;
+            if (p.sm_wout) seam_out<KSTEPS>(p, wout_s, colmax_s, tile, il, h, es, wave, kCoopWaves);
+        }
+    }
+    if (p.sm_colmax) {
+        __syncthreads();
+        if (tid < kSeamH && colmax_s[tid]) atomicMax(p.sm_colmax + tid, colmax_s[tid]);
     }
 }
 
@@ -1480,6 +1711,7 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
     p.embs_norm = embs_norm; p.tie_margin = tie_margin;
     p.B = B; p.n_tiles = (B + 31) / 32; p.D = D; p.L = L; p.K = K; p.Kp = Kp; p.beta = beta;
     p.tpg = 1; p.ngroups = 0; p.gm16 = 0; p.incsq = 0;
+    p.sm_h = nullptr; p.sm_wout = nullptr;
     const int waves_per_wg = (ksteps <= 16 ? 768 : ksteps == 32 ? 512 : 256) / RQ_WAVE;
     const bool filt = filtered_launch(p, flags);
     // per code: the operand image (Dp words) + its squared norm (fp32 scan) or the three bf16 pieces of -|c|^2/2 (filtered)
@@ -1550,5 +1782,108 @@ extern "C" int rqhip_rq_forward_ex(const float *res0, int64_t B, int D, const fl
         case 16: return launch_mode<16>(p, mode, grid, lds, flags, s);
         case 32: return launch_mode<32>(p, mode, grid, lds, flags, s);
         default: return launch_mode<64>(p, mode, grid, lds, flags, s);
+    }
+}
+
+// ---- the RQ <-> MLP seam (rq_seam_kernel) ---------------------------------------------------------------------------------------
+// LDS of a launch: rq_forward_kernel's filtered resident layout for L levels of Kp codes + the two weight images + the column maxima;
+// gm16 (bf16 group maxima, rounded up) when the fp32 form does not fit.  Returns 0 when even that does not fit.
+static size_t seam_lds_bytes(int L, int Kp, int *gm16) {
+    const size_t code_bytes = (size_t)(32 + 2) * sizeof(float) + sizeof(float);   // bf16 image + q pieces + the fp32 norm
+    const size_t fixed = 64 + kCoopLdsFloats * sizeof(float) + (size_t)kSeamLdsFloats * sizeof(float);
+    const size_t gm32 = (size_t)(768 / RQ_WAVE) * 8 * 64 * sizeof(float);
+    const size_t levels = (size_t)L * Kp * code_bytes;
+    *gm16 = 0;
+    if (levels + fixed + gm32 <= (size_t)kLdsBudget) return levels + fixed + gm32;
+    *gm16 = 1;
+    if (levels + fixed + gm32 / 2 <= (size_t)kLdsBudget) return levels + fixed + gm32 / 2;
+    return 0;
+}
+
+extern "C" int rqhip_rq_seam_supported(int D, int H, int L, int K) {
+    if (D != 32 || H != kSeamH || L < 0 || L > 16 || (L > 0 && (K < 1 || K > 65536))) return 0;
+    int gm16;
+    return seam_lds_bytes(L, L > 0 ? pad32(K) : 0, &gm16) != 0 ? 1 : 0;
+}
+
+extern "C" int rqhip_rq_seam(const rqhip_seam_args *a, rqhip_stream_t stream) {
+    if (!a) {
+        set_error("rq_seam: null argument block");
+        return RQHIP_EARG;
+    }
+    if (a->B < 0 || !rqhip_rq_seam_supported(a->D, a->H, a->L, a->K)) {
+        set_error("rq_seam: unsupported shape (D = %d must be 32, H = %d must be %d, L = %d levels of K = %d codes must fit the LDS "
+                  "beside the two weight images: rqhip_rq_seam_supported)", a->D, a->H, kSeamH, a->L, a->K);
+        return RQHIP_EUNSUPPORTED;
+    }
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool pre = a->h != nullptr, post = a->w_out != nullptr;
+    if ((pre && !a->w_in) || (!pre && a->B > 0 && !a->res0) || (post && !a->out) || (a->L > 0 && (!a->codebooks || (a->B > 0 && !a->ids))) ||
+        (!pre && a->L == 0 && !post) || (post && a->out_epilogue == RQHIP_EPI_MASK && !a->out_mask) ||
+        (post && a->out_epilogue != RQHIP_EPI_STORE && a->out_epilogue != RQHIP_EPI_RELU && a->out_epilogue != RQHIP_EPI_MASK)) {
+        set_error("rq_seam: inconsistent arguments (h needs w_in; no h needs res0; w_out needs out; levels need codebooks and ids; "
+                  "RQHIP_EPI_MASK needs out_mask; something must be asked for)");
+        return RQHIP_EARG;
+    }
+    if (a->L > 0 && a->mode != RQHIP_MODE_EVAL && a->mode != RQHIP_MODE_STE && a->mode != RQHIP_MODE_ROTATION) {
+        set_error("rq_seam: mode %d is not EVAL/STE/ROTATION", a->mode);
+        return RQHIP_EARG;
+    }
+    if (!al16(a->h) || !al16(a->h_mask) || !al16(a->res0) || !al16(a->res0_out) || !al16(a->codebooks) || !al16(a->emb_sum) ||
+        !al16(a->out) || !al16(a->out_mask)) {
+        set_error("rq_seam: row pointers must be 16-byte aligned");
+        return RQHIP_EARG;
+    }
+    if (a->B == 0) return RQHIP_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RqFwdParams p;
+    p.res0 = a->res0; p.cb = a->codebooks; p.csq = nullptr; p.csqmax = nullptr;
+    p.ids = a->ids; p.embs = nullptr; p.residuals = nullptr; p.emb_sum = a->L > 0 ? a->emb_sum : nullptr;
+    p.loss = a->L > 0 ? a->loss : nullptr; p.embs_norm = a->L > 0 ? a->embs_norm : nullptr; p.tie_margin = nullptr;
+    p.B = a->B; p.n_tiles = (a->B + 31) / 32; p.D = 32; p.L = a->L; p.K = a->K; p.Kp = a->L > 0 ? pad32(a->K) : 0; p.beta = a->beta;
+    p.resident = 1; p.Kc = p.Kp; p.nchunks = 1; p.incsq = 1;
+    int gm16 = 0;
+    const size_t lds = seam_lds_bytes(p.L, p.Kp, &gm16);
+    p.gm16 = gm16;
+    const int tiles = p.Kc / 32;
+    p.tpg = tiles > 0 ? (tiles + 7) / 8 : 1;
+    p.ngroups = tiles > 0 ? (tiles + p.tpg - 1) / p.tpg : 0;
+    p.sm_h = a->h; p.sm_hmask = pre ? a->h_mask : nullptr; p.sm_win = a->w_in; p.sm_win_t = a->w_in_transposed ? 1 : 0;
+    p.sm_res0_out = pre ? a->res0_out : nullptr;
+    p.sm_wout = a->w_out; p.sm_wout_t = a->w_out_transposed ? 1 : 0; p.sm_epi = a->out_epilogue; p.sm_omask = a->out_mask;
+    p.sm_out = a->out; p.sm_rowmax = post ? a->out_row_max : nullptr; p.sm_colmax = post ? a->out_col_max : nullptr;
+    // grid and cooperative tiles: rq_forward's rules (one workgroup of 12 waves per CU; small batches and the partly filled last round
+    // of a big one are worked on by four waves per tile) -- with levels only: a bare GEMM tile is short
+    const int cus = cu_count();
+    const int waves_per_wg = 768 / RQ_WAVE;
+    long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
+    const long long cap = cus;
+    const bool all_coop = p.L > 0 && f_resident_small(1, p.n_tiles, cap);
+    if (all_coop) want = p.n_tiles;
+    const int grid = (int)(want < cap ? want : cap);
+    const long long total_waves = (long long)grid * waves_per_wg;
+    p.coop_first = all_coop ? 0 : p.n_tiles;
+    if (!all_coop && p.L > 0) {
+        const long long rem = p.n_tiles % ((long long)grid * 4);
+        if (rem > 0 && rem <= grid) p.coop_first = p.n_tiles - rem;
+    }
+    p.n_iter = (int)((p.coop_first + total_waves - 1) / total_waves);
+    auto go = [&](auto kern) -> int {
+        static LdsGrant grant;
+        RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)kLdsBudget));
+        const double gemm = 2.0 * (double)p.B * 32.0 * kSeamH;
+        profile_begin(s, RQHIP_PROF_SEAM, (pre ? gemm : 0.0) + (post ? gemm : 0.0) + (double)p.B * p.L * (2.0 * 32 * p.K + 5.0 * 32),
+                      (double)p.B * 4.0 * ((pre ? kSeamH + (a->h_mask ? kSeamH : 0) + (a->res0_out ? 32 : 0) : 32) +
+                                           (post ? kSeamH + (a->out_epilogue == RQHIP_EPI_MASK ? kSeamH : 0) : 0) +
+                                           (p.L > 0 ? 2 * p.L + (a->emb_sum ? 32 : 0) + 1 + p.L : 0)));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, p);
+        profile_end(s);
+        RQ_CHECK_LAUNCH("rq_seam_kernel");
+        return 0;
+    };
+    switch (p.L > 0 ? a->mode : RQHIP_MODE_EVAL) {
+        case RQHIP_MODE_EVAL: return go(rq_seam_kernel<RQHIP_MODE_EVAL>);
+        case RQHIP_MODE_STE: return go(rq_seam_kernel<RQHIP_MODE_STE>);
+        default: return go(rq_seam_kernel<RQHIP_MODE_ROTATION>);
     }
 }

@@ -23,12 +23,21 @@ WGRAD_FP32 = 0x1   # rqhip_linear_wgrad_ex
 BWD_CBGRAD_MATRIX = 0x1   # rqhip_rq_backward_ex
 SPLIT_F16X2, SPLIT_BF16X3 = 0, 1                       # arithmetic of the split GEMM kernels (include/rqhip.h)
 EPI_STORE, EPI_RELU, EPI_RECON, EPI_MASK = 0, 1, 2, 3  # rqhip_gemm_split_ex epilogues
-PROF_TAGS = {1: "rq_forward", 2: "rq_backward", 3: "gemm_split", 4: "wgrad", 5: "maxima", 6: "weight_images"}
+PROF_TAGS = {1: "rq_forward", 2: "rq_backward", 3: "gemm_split", 4: "wgrad", 5: "maxima", 6: "weight_images", 7: "rq_seam"}
 
 
 class ImageJob(C.Structure):          # rqhip_image_job
     _fields_ = [("w", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("transpose", C.c_int), ("arith", C.c_int),
                 ("image", C.c_void_p), ("image_bytes", C.c_size_t)]
+
+
+class SeamArgs(C.Structure):          # rqhip_seam_args
+    _fields_ = [("B", C.c_int64), ("D", C.c_int), ("H", C.c_int), ("h", C.c_void_p), ("h_mask", C.c_void_p), ("w_in", C.c_void_p),
+                ("w_in_transposed", C.c_int), ("res0", C.c_void_p), ("res0_out", C.c_void_p), ("codebooks", C.c_void_p),
+                ("L", C.c_int), ("K", C.c_int), ("mode", C.c_int), ("beta", C.c_float), ("ids", C.c_void_p), ("emb_sum", C.c_void_p),
+                ("loss", C.c_void_p), ("embs_norm", C.c_void_p), ("w_out", C.c_void_p), ("w_out_transposed", C.c_int),
+                ("out_epilogue", C.c_int), ("out_mask", C.c_void_p), ("out", C.c_void_p), ("out_row_max", C.c_void_p),
+                ("out_col_max", C.c_void_p)]
 
 
 class GemmArgs(C.Structure):          # rqhip_gemm_args
@@ -106,6 +115,8 @@ SIGNATURES = {
     "rqhip_gemm_split_recon": (_int, [_vp, _i64, _int, _vp, _int, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_recon_rescale_rows": (_int, [_vp, _i64, _int, _f32, _vp, _vp]),
     "rqhip_recon_rescale_rows_ex": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _int, _vp, _vp]),
+    "rqhip_rq_seam_supported": (_int, [_int, _int, _int, _int]),
+    "rqhip_rq_seam": (_int, [C.POINTER(SeamArgs), _vp]),
     "rqhip_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_select": (_int, [C.c_uint]),

@@ -90,6 +90,79 @@ def filter_scores(x: Tensor, codebook: Tensor) -> Tensor:
     return out
 
 
+class RqSeamOut(NamedTuple):
+    res0: Optional[Tensor]       # [B,D]   the input GEMM's result (h given)
+    ids: Optional[Tensor]        # [L,B] int64
+    emb_sum: Optional[Tensor]    # [B,D]
+    loss: Optional[Tensor]       # [B]
+    embs_norm: Optional[Tensor]  # [B,L]
+    out: Optional[Tensor]        # [B,H]   the output GEMM's result
+    out_row_max: Optional[Tensor]   # [H/32, B] int32
+    out_col_max: Optional[Tensor]   # [H] int32 (the caller's zeroed buffer)
+
+
+SEAM_H = 128
+
+
+def rq_seam_supported(D: int, H: int, L: int, K: int) -> bool:
+    """Does rqhip_rq_seam take these shapes (D = 32, H = 128, all levels resident in LDS beside the two weights)?  Host-side query."""
+    return bool(_lib.lib().rqhip_rq_seam_supported(int(D), int(H), int(L), int(K)))
+
+
+def rq_seam(*, h: Optional[Tensor] = None, w_in: Optional[Tensor] = None, w_in_transposed: bool = False, h_mask: Optional[Tensor] = None,
+            res0: Optional[Tensor] = None, want_res0: bool = True,
+            codebooks: Optional[Tensor] = None, mode: int = MODE_EVAL, beta: float = 0.25, want_emb_sum: bool = True,
+            want_loss: bool = True, want_norm: bool = True,
+            w_out: Optional[Tensor] = None, w_out_transposed: bool = False, epilogue: int = _lib.EPI_STORE,
+            out_mask: Optional[Tensor] = None, want_row_max: bool = False, col_max_out: Optional[Tensor] = None) -> RqSeamOut:
+    """The RQ <-> MLP seam in one launch (rqhip_rq_seam): [res0 = h' . w_in^T] -> [L quantisation levels] -> [out = epilogue(s . w_out^T)].
+    h [B,128] (h' = h where h_mask > 0), w_in [32,128] (or [128,32] with w_in_transposed); without h the rows are `res0` [B,32];
+    codebooks [L,K,32] or None (no quantisation: s = the rows); w_out [128,32] (or [32,128] transposed) or None.
+    epilogue: EPI_STORE / EPI_RELU / EPI_MASK (out_mask [B,128]).  want_row_max: int32 [4,B] row maxima of `out`; col_max_out: a ZEROED
+    int32 [128] that receives its column maxima."""
+    _need_gpu(h, w_in, h_mask, res0, codebooks, w_out, out_mask, col_max_out)
+    h, w_in, h_mask, res0 = _f32c(h, "h"), _f32c(w_in, "w_in"), _f32c(h_mask, "h_mask"), _f32c(res0, "res0")
+    codebooks, w_out, out_mask = _f32c(codebooks, "codebooks"), _f32c(w_out, "w_out"), _f32c(out_mask, "out_mask")
+    rows = h if h is not None else res0
+    if rows is None or rows.dim() != 2:
+        raise RqHipError("rq_seam: h [B,128] or res0 [B,32] must be given")
+    B, dev = rows.shape[0], rows.device
+    D, H = 32, SEAM_H
+    L, K = (codebooks.shape[0], codebooks.shape[1]) if codebooks is not None else (0, 0)
+    if h is not None and (tuple(h.shape) != (B, H) or w_in is None or tuple(w_in.shape) != ((H, D) if w_in_transposed else (D, H))
+                          or (h_mask is not None and h_mask.shape != h.shape)):
+        raise RqHipError(f"rq_seam: h {tuple(h.shape)} / w_in {None if w_in is None else tuple(w_in.shape)} / h_mask do not fit")
+    if h is None and tuple(res0.shape) != (B, D):
+        raise RqHipError(f"rq_seam: res0 must be [B,{D}]")
+    if codebooks is not None and (codebooks.dim() != 3 or codebooks.shape[2] != D):
+        raise RqHipError(f"rq_seam: codebooks must be [L,K,{D}]")
+    if w_out is not None and tuple(w_out.shape) != ((D, H) if w_out_transposed else (H, D)):
+        raise RqHipError(f"rq_seam: w_out {tuple(w_out.shape)} does not fit")
+    if epilogue == _lib.EPI_MASK and (out_mask is None or tuple(out_mask.shape) != (B, H)):
+        raise RqHipError("rq_seam: EPI_MASK needs out_mask [B,128]")
+    if col_max_out is not None and (col_max_out.dtype != torch.int32 or col_max_out.numel() != H or not col_max_out.is_contiguous()):
+        raise RqHipError("rq_seam: col_max_out must be a contiguous int32 [128] tensor (zeroed by the caller)")
+    with torch.cuda.device(dev):
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        a = _lib.SeamArgs()
+        a.B, a.D, a.H = B, D, H
+        a.h, a.h_mask, a.w_in, a.w_in_transposed = _ptr(h), _ptr(h_mask), _ptr(w_in), int(bool(w_in_transposed))
+        r0 = f(B, D) if (h is not None and want_res0) else None
+        a.res0, a.res0_out = _ptr(res0) if h is None else None, _ptr(r0)
+        ids = torch.empty((L, B), dtype=torch.int64, device=dev) if L > 0 else None
+        es = f(B, D) if (L > 0 and want_emb_sum) else None
+        loss = f(B) if (L > 0 and want_loss) else None
+        norms = f(B, L) if (L > 0 and want_norm) else None
+        a.codebooks, a.L, a.K, a.mode, a.beta = _ptr(codebooks), L, K, int(mode), float(beta)
+        a.ids, a.emb_sum, a.loss, a.embs_norm = _ptr(ids), _ptr(es), _ptr(loss), _ptr(norms)
+        out = f(B, H) if w_out is not None else None
+        rmx = torch.empty((H // 32, B), dtype=torch.int32, device=dev) if (w_out is not None and want_row_max) else None
+        a.w_out, a.w_out_transposed, a.out_epilogue = _ptr(w_out), int(bool(w_out_transposed)), int(epilogue)
+        a.out_mask, a.out, a.out_row_max, a.out_col_max = _ptr(out_mask), _ptr(out), _ptr(rmx), _ptr(col_max_out if w_out is not None else None)
+        check(_lib.lib().rqhip_rq_seam(C.byref(a), _stream()), "rqhip_rq_seam")
+    return RqSeamOut(r0, ids, es, loss, norms, out, rmx, col_max_out if w_out is not None else None)
+
+
 def rq_forward(res0: Tensor, codebooks: Tensor, mode: int, beta: float, *, want_embs: bool = True,
                want_residuals: bool = True, want_emb_sum: bool = True, want_loss: bool = True,
                want_norm: bool = True, want_margin: bool = False, scan: str = "auto",
