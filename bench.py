@@ -108,6 +108,9 @@ def parse_args():
                          "gradients (round 2's step)")
     ap.add_argument("--wide-tiles", action="store_true", help="A/B (round 6, slower): the 512-column layers on 128 x 512 tiles of 8 waves, one workgroup "
                                                               "per CU, instead of 128 x 256 tiles of two workgroups per CU (profiles/r06_gemm_wide_ab.txt)")
+    ap.add_argument("--no-seam", action="store_true", help="A/B: the 128 <-> 32 layers either side of the quantiser as in round 5 (library / split GEMMs, "
+                                                           "separate maxima and mask passes) instead of the seam kernel (rqhip_rq_seam: fused forward launch, "
+                                                           "its GEMMs as the data gradients)")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of librqhip.so (same ABI) instead of the in-tree one")
     ap.add_argument("--no-narrow", action="store_true", help="A/B: layers of 128 (mod 256) columns on the library instead of the split kernel's 128-column tile")
     ap.add_argument("--min-seconds", type=float, default=1.0,
@@ -385,6 +388,7 @@ def main():
     _lin.use_arith({"split": "f16x2", "split6": "bf16x3", "library": "fp32"}[args.mlp])   # (A/B arms: tools/profile_mlp_ab.sh)
     _lin.use_narrow_tiles(not args.no_narrow)
     _lin.use_wide_tiles(args.wide_tiles)
+    _lin.use_chain_gemms(not args.no_seam)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)
     for lo in range(0, B, 250_000):        # generated in host chunks: 1.25 M x 768 fp32 is 3.8 GB

@@ -1283,27 +1283,37 @@ constexpr int kSeamLdsFloats = 2 * kSeamWFloats + kSeamH;   // both images + the
 // image[(q * 2 + hh) * n_out + n][j] = W(n, d) for d = 2 (4 q + j) + hh < n_in, W(n, d) = t ? w[d * n_out + n] : w[n * n_in + d]
 template <int NT>
 __device__ __forceinline__ void seam_stage_weight(float *img, const float *__restrict__ w, int n_out, int n_in, int t) {
+    // walk the SOURCE contiguously (coalesced reads; the LDS writes scatter, once per workgroup); all of a thread's loads are issued
+    // before its first LDS write (one memory latency per workgroup, not one per trip: a stand-alone launch at batch 640 is two
+    // workgroups whose whole life is this staging, one 64-deep chain of matrix instructions and a store)
+    constexpr int kPer = (kSeamH * 32 + NT - 1) / NT;
     const int total = n_out * n_in;
-    for (int e = threadIdx.x; e < total; e += NT) {
-        // walk the SOURCE contiguously (coalesced reads; the LDS writes scatter, once per workgroup)
-        const int n = t ? e % n_out : e / n_in, d = t ? e / n_out : e % n_in;
-        const int kk = d >> 1, hh = d & 1;
-        img[(((kk >> 2) * 2 + hh) * n_out + n) * 4 + (kk & 3)] = w[e];
+    float v[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = threadIdx.x + u * NT;
+        v[u] = e < total ? w[e] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = threadIdx.x + u * NT;
+        if (e < total) {
+            const int n = t ? e % n_out : e / n_in, d = t ? e / n_out : e % n_in;
+            const int kk = d >> 1, hh = d & 1;
+            img[(((kk >> 2) * 2 + hh) * n_out + n) * 4 + (kk & 3)] = v[u];
+        }
     }
 }
 
 // rows of tile `tile` of h [B, 128] -> res0 = h . w_in^T in pair layout (r[kk] = feature 2 kk + h of row il), stored to sm_res0_out
-template <int KSTEPS>
-__device__ __forceinline__ void seam_in(const RqFwdParams &p, const float *win_s, long long tile, int il, int h, bool store,
-                                        float (&r)[KSTEPS]) {
-    static_assert(KSTEPS == 16, "the seam kernels are built for D = 32");
+// this lane's half (64 floats) of row il of tile `tile` of h, masked by hmask when given
+__device__ __forceinline__ void seam_load_rows(const RqFwdParams &p, long long tile, int il, int h, float (&raw)[kSeamH / 2]) {
     constexpr int KH = kSeamH / 2;                       // 64 K steps of the 32x32x2 instruction
     const long long row = tile * 32 + il;
     const long long rowc = (tile < p.n_tiles && row < p.B) ? row : (p.B - 1);
     int hv = h;
     asm volatile("" : "+v"(hv));                         // (per-lane row pointers are formed here, not hoisted across tiles)
     const f32x4 *src = reinterpret_cast<const f32x4 *>(p.sm_h + ((size_t)rowc * kSeamH + hv * KH));
-    float raw[KH];
 #pragma unroll
     for (int j = 0; j < KH / 4; ++j) {
         const f32x4 q = src[j];
@@ -1320,6 +1330,16 @@ __device__ __forceinline__ void seam_in(const RqFwdParams &p, const float *win_s
             raw[4 * j + 3] = m.w <= 0.0f ? 0.0f : raw[4 * j + 3];
         }
     }
+}
+
+template <int KSTEPS>
+__device__ __forceinline__ void seam_in(const RqFwdParams &p, const float *win_s, long long tile, int il, int h, bool store,
+                                        const float (&raw)[kSeamH / 2], float (&r)[KSTEPS]) {
+    static_assert(KSTEPS == 16, "the seam kernels are built for D = 32");
+    constexpr int KH = kSeamH / 2;
+    const long long row = tile * 32 + il;
+    int hv = h;
+    asm volatile("" : "+v"(hv));
     float x[KH];
     rows_to_pairs<KH>(raw, x);                           // x[kk] = feature 2 kk + h of row il
     const f32x4 *img = reinterpret_cast<const f32x4 *>(win_s);
@@ -1439,9 +1459,13 @@ __global__ __launch_bounds__(768) void rq_seam_kernel(const RqFwdParams p) {
     __syncthreads();
 
     float rn[KSTEPS];   // (no row prefetch across tiles here: a 128-wide row is 64 registers per lane)
+    // (requesting the first tile's rows before the staging was tried: 64 registers that the allocator then keeps across the whole tile
+    // loop -- 158 spilled)
     auto tile_rows = [&](long long tile, float (&r)[KSTEPS], bool store) {
         if (p.sm_h) {
-            seam_in<KSTEPS>(p, win_s, tile, il, h, store, r);
+            float hraw[kSeamH / 2];
+            seam_load_rows(p, tile, il, h, hraw);
+            seam_in<KSTEPS>(p, win_s, tile, il, h, store, hraw, r);
         } else {
             float raw[KSTEPS];
             load_tile_rows<KSTEPS, true>(p, tile, il, h, D, raw);
@@ -1859,7 +1883,9 @@ extern "C" int rqhip_rq_seam(const rqhip_seam_args *a, rqhip_stream_t stream) {
     long long want = (p.n_tiles + waves_per_wg - 1) / waves_per_wg;
     const long long cap = cus;
     const bool all_coop = p.L > 0 && f_resident_small(1, p.n_tiles, cap);
-    if (all_coop) want = p.n_tiles;
+    // (a bare GEMM launch spreads its tiles over the CUs first -- waves are enumerated wave-major: at batch 640, 20 tiles packed into
+    // two workgroups put three 64-deep chains of fp32 matrix instructions on every SIMD they used, 12 us for a 6 us job)
+    if (all_coop || p.L == 0) want = p.n_tiles;
     const int grid = (int)(want < cap ? want : cap);
     const long long total_waves = (long long)grid * waves_per_wg;
     p.coop_first = all_coop ? 0 : p.n_tiles;

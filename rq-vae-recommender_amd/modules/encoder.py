@@ -94,8 +94,12 @@ class _MLPStack(torch.autograd.Function):
         given = _lin.take_scales()          # maxima that came with the input (rqhip/linear.py:attach_scales), or None
         need_w = [bool(f) for f in ctx.needs_input_grad[4:]]
         need_in = [bool(ctx.needs_input_grad[0]) or any(need_w[:i]) for i in range(n)]   # gradient wrt layer i's input wanted
-        fwd_split = [_lin.split_shape_ok(M, w.shape[0], w.shape[1]) for w in weights]
-        dg_split = [need_in[i] and _lin.split_shape_ok(M, w.shape[1], w.shape[0]) for i, w in enumerate(weights)]
+        # the 128 <-> 32 layers either side of the quantiser: the seam kernel's GEMMs (rqhip/linear.py:chain_*), forward and data gradient
+        aligned = x.data_ptr() % 16 == 0 and M > 0
+        chain = [(_lin.chain_shape(w.shape[0], w.shape[1], M) if aligned else 0) for w in weights]
+        chain = [0 if (k == 1 and relus[i]) else k for i, k in enumerate(chain)]
+        fwd_split = [not chain[i] and _lin.split_shape_ok(M, w.shape[0], w.shape[1]) for i, w in enumerate(weights)]
+        dg_split = [not chain[i] and need_in[i] and _lin.split_shape_ok(M, w.shape[1], w.shape[0]) for i, w in enumerate(weights)]
         wg_f16 = [need_w[i] and _lin.wgrad_f16_ok(w.shape[0], w.shape[1], M) for i, w in enumerate(weights)]
         jobs = [(w, False) for i, w in enumerate(weights) if fwd_split[i]] + [(w, True) for i, w in enumerate(weights) if dg_split[i]]
         imgs = iter(_lin.images(jobs))
@@ -104,7 +108,7 @@ class _MLPStack(torch.autograd.Function):
         f16 = _lin.f16()
         # column maxima the epilogues emit in this forward: of layer i's output when layer i + 1's weight gradient wants them
         # (and of the reconstruction gradient for the last layer's own weight gradient) -- one zeroed arena
-        emit = [f16 and fwd_split[i] and ((i + 1 < n and wg_f16[i + 1]) or (i + 1 == n and target is not None and wg_f16[i]))
+        emit = [f16 and (fwd_split[i] or chain[i] == 2) and ((i + 1 < n and wg_f16[i + 1]) or (i + 1 == n and target is not None and wg_f16[i]))
                 for i in range(n)]
         arena = torch.zeros((sum(w.shape[0] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=x.device) if any(emit) else None
         off = 0
@@ -124,7 +128,9 @@ class _MLPStack(torch.autograd.Function):
                 g_recon, out, g_scales = _lin.gemm(a, img_f[i], w.shape[0], epilogue=_lib.EPI_RECON, aux=target,
                                                    row_scale=ctx.row_scale, a_scales=sc, want_rows=dg_split[i], col_out=col_out)
                 break
-            if fwd_split[i]:
+            if chain[i]:
+                y, ysc = _lin.chain_forward(a, w, relus[i], want_rows=not last and fwd_split[i + 1], col_out=col_out)
+            elif fwd_split[i]:
                 y, _, ysc = _lin.gemm(a, img_f[i], w.shape[0], epilogue=_lib.EPI_RELU if relus[i] else _lib.EPI_STORE,
                                       a_scales=sc, want_rows=not last and fwd_split[i + 1], col_out=col_out)
             else:
@@ -137,7 +143,7 @@ class _MLPStack(torch.autograd.Function):
         ctx.has_target = target is not None
         ctx.save_for_backward(x, *weights, target if ctx.has_target else out)
         ctx.acts_mid, ctx.scs, ctx.relus = (acts[1:] if ctx.has_target else acts[1:-1]), scs, tuple(relus)
-        ctx.img_t, ctx.dg_split, ctx.wg_f16, ctx.need_in, ctx.need_w = img_t, dg_split, wg_f16, need_in, need_w
+        ctx.img_t, ctx.dg_split, ctx.wg_f16, ctx.need_in, ctx.need_w, ctx.chain = img_t, dg_split, wg_f16, need_in, need_w, chain
         ctx.g_recon, ctx.g_scales, ctx.consumed = g_recon, g_scales, False
         return out
 
@@ -149,9 +155,12 @@ class _MLPStack(torch.autograd.Function):
         target = tail if ctx.has_target else None
         acts = [x] + list(ctx.acts_mid) + ([] if ctx.has_target else [tail])
         scs, relus, need_in, need_w = ctx.scs, ctx.relus, ctx.need_in, ctx.need_w
-        dg_split, wg_f16, f16 = ctx.dg_split, ctx.wg_f16, _lin.f16()
+        dg_split, wg_f16, f16, chain = ctx.dg_split, ctx.wg_f16, _lin.f16(), ctx.chain
         g_out = g_out.contiguous()
-        if target is None:
+        handed = _lin.take_grad_handoff(g_out) if target is None else None
+        if handed is not None:       # the node above (modules/rqvae.py's seam) masked this gradient by our last ReLU and took its maxima
+            g, gsc = g_out, handed
+        elif target is None:
             g, gsc = g_out, _lin.Scales()
         elif not ctx.consumed:
             ctx.consumed = True
@@ -162,10 +171,10 @@ class _MLPStack(torch.autograd.Function):
             gsc = _lin.Scales()
         # column maxima the data-gradient epilogues emit: of the gradient wrt layer i - 1's output (masked) when that
         # layer's weight gradient wants them
-        emit = [f16 and dg_split[i] and i > 0 and wg_f16[i - 1] for i in range(n)]
+        emit = [f16 and (dg_split[i] or chain[i] == 1) and i > 0 and wg_f16[i - 1] for i in range(n)]
         arena = torch.zeros((sum(w.shape[1] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=g.device) if any(emit) else None
         off = 0
-        premasked = not relus[n - 1]      # is g already masked by this layer's ReLU (or is there none)?
+        premasked = (not relus[n - 1]) or handed is not None      # is g already masked by this layer's ReLU (or is there none)?
         gws = [None] * n
         # batches below the split kernels' row count: every weight gradient of the stack in ONE launch after the data gradients
         # (csrc/wgrad_jobs.hip; same bits as the per-layer path, which runs the same kernel with one job)
@@ -174,22 +183,39 @@ class _MLPStack(torch.autograd.Function):
         for i in range(n - 1, -1, -1):
             w, a = weights[i], acts[i]
             y = acts[i + 1] if (relus[i] and not premasked) else None
+            # a 32 -> 128 seam layer applies its own ReLU backward on LOAD in its data gradient: the masked gradient is then only
+            # written out when the job-table weight gradient needs it as a tensor
+            mask_on_load = chain[i] == 2 and need_in[i] and y is not None and g.data_ptr() % 16 == 0
+            g_unmasked = g
             if need_w[i] and deferred:
                 if y is not None:
                     g, gsc = torch.ops.aten.threshold_backward(g, y, 0.0), _lin.Scales()
                 pending.append((i, g, a, _grad_sink(w)))
             elif need_w[i]:
                 sink = _grad_sink(w)
-                gw, g, gsc = _lin.weight_grad(g, y, a, w, out=sink, want_masked=need_in[i], g_scales=gsc, x_scales=scs[i],
-                                              premasked=premasked)
+                gw, g, gsc = _lin.weight_grad(g, y, a, w, out=sink, want_masked=need_in[i] and not mask_on_load, g_scales=gsc,
+                                              x_scales=scs[i], premasked=premasked)
                 gws[i] = _adopt(gw, sink)
-            elif y is not None and need_in[i]:
+            elif y is not None and need_in[i] and not mask_on_load:
                 g, gsc = torch.ops.aten.threshold_backward(g, y, 0.0), _lin.Scales()
             if not need_in[i]:
                 g = None
                 break
             lower_relu = i > 0 and relus[i - 1]
-            if dg_split[i]:
+            if chain[i] and (g_unmasked if mask_on_load else g).data_ptr() % 16 == 0:
+                col_out = None
+                if emit[i]:
+                    col_out = arena[off:off + w.shape[1]]
+                    off += w.shape[1]
+                if chain[i] == 2:     # 32 -> 128 layer: gx [M, 32]; its own ReLU backward on load when the gradient is still unmasked
+                    src, msk = (g_unmasked, y) if (mask_on_load and (g is None or g is g_unmasked)) else (g, None)
+                    g, gsc = _lin.chain_input_grad(src, w, g_mask=msk)
+                    premasked = not lower_relu
+                else:                 # 128 -> 32 layer: gx [M, 128], the ReLU backward of the layer below in the epilogue, with its maxima
+                    g, gsc = _lin.chain_input_grad(g, w, out_mask=a if lower_relu else None,
+                                                   want_rows=i > 0 and dg_split[i - 1], col_out=col_out)
+                    premasked = True
+            elif dg_split[i]:
                 col_out = None
                 if emit[i]:
                     col_out = arena[off:off + w.shape[1]]
@@ -276,11 +302,42 @@ class MLP(nn.Module):
                 i += 1
         return x
 
-    def reconstruction_rows(self, z: Tensor, target: Tensor):
+    # ---- the RQ <-> MLP seam (modules/rqvae.py): the stack without its last Linear / without its first Linear + ReLU -----------------
+    def seam_tail_weight(self):
+        """The weight of the LAST Linear when the stack ends `..., ReLU, Linear(128 -> 32, no bias), Identity` (no dropout): the layer
+        the seam kernel runs in front of the quantiser; else None."""
+        layers = list(self.mlp)
+        if (self.dropout == 0 and len(layers) >= 4 and isinstance(layers[-1], nn.Identity) and isinstance(layers[-2], nn.Linear)
+                and layers[-2].bias is None and isinstance(layers[-3], nn.ReLU)
+                and tuple(layers[-2].weight.shape) == (_lin.CHAIN_D, _lin.CHAIN_H)
+                and all((isinstance(l, nn.Linear) and l.bias is None) or isinstance(l, nn.ReLU) for l in layers[:-1])):
+            return layers[-2].weight
+        return None
+
+    def seam_head_weight(self):
+        """The weight of the FIRST Linear when the stack starts `Linear(32 -> 128, no bias), ReLU, Linear, ...` (no dropout); else None."""
+        layers = list(self.mlp)
+        if (self.dropout == 0 and len(layers) >= 4 and isinstance(layers[0], nn.Linear) and layers[0].bias is None
+                and isinstance(layers[1], nn.ReLU) and isinstance(layers[2], nn.Linear)
+                and tuple(layers[0].weight.shape) == (_lin.CHAIN_H, _lin.CHAIN_D)
+                and all((isinstance(l, nn.Linear) and l.bias is None) or isinstance(l, nn.ReLU) for l in layers[:-1])):
+            return layers[0].weight
+        return None
+
+    def run_before_tail(self, x: Tensor) -> Tensor:
+        """The hidden activation in front of the last Linear (through its ReLU)."""
+        return self._run(x if x.is_contiguous() else x.contiguous(), list(self.mlp)[:-2])
+
+    def run_after_head(self, d: Tensor) -> Tensor:
+        """The rest of the stack behind the first Linear + ReLU."""
+        return self._run(d if d.is_contiguous() else d.contiguous(), list(self.mlp)[2:])
+
+    def reconstruction_rows(self, z: Tensor, target: Tensor, first: int = 0):
         """ReconstructionLoss(self(z), target) per row with the last layer and the loss fused (`_MLPStack` with a target), or
         None when that kernel does not apply here (the caller then composes the two, as the reference does).  The fused
-        epilogue writes the gradient matrix the backward is going to ask for, so it only runs when a backward can follow."""
-        layers = list(self.mlp)
+        epilogue writes the gradient matrix the backward is going to ask for, so it only runs when a backward can follow.
+        first: index of the first module of the stack to run (2: z is already behind the first Linear + ReLU -- the seam)."""
+        layers = list(self.mlp)[first:]
         lin = [l for l in layers[:-1]]
         last = layers[-2] if len(layers) >= 2 else None
         chain_ok = all((isinstance(l, nn.Linear) and l.bias is None) or isinstance(l, nn.ReLU) for l in lin) \
@@ -295,5 +352,5 @@ class MLP(nn.Module):
                 and last.out_features % 256 == 0   # (the fused epilogue sums four 64-column waves: 256-column tiles only)
                 and _lin.split_shape_ok(z.shape[0], last.out_features, last.in_features)):
             return None
-        assert z.shape[-1] == self.input_dim, f"Invalid input dim: Expected {self.input_dim}, found {z.shape[-1]}"
+        assert z.shape[-1] == layers[0].in_features, f"Invalid input dim: Expected {layers[0].in_features}, found {z.shape[-1]}"
         return self._run(z if z.is_contiguous() else z.contiguous(), layers[:-1], target)

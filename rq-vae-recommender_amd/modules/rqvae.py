@@ -26,12 +26,18 @@ from modules.loss import CategoricalReconstuctionLoss, ReconstructionLoss
 from modules.normalize import l2norm
 from modules.quantize import Quantize, QuantizeForwardMode
 from rqhip import ops, torch_ops
-from rqhip.autograd import LossMeansFunction, RqStackFunction
+from rqhip import linear as _lin
+from rqhip.autograd import LossMeansFunction, RqSeamFunction, RqStackFunction
 
 # The reference sets "high" here (rqvae.py:19): on its CPU path that is plain fp32 (bit-identical to "highest",
 # SURVEY probe 3), but on ROCm "high" switches the MLP GEMMs to a reduced-precision tf32 class.  Parity is judged
 # against the CPU results, so the GPU path pins true fp32; rqhip/tuning.py recovers the speed by kernel selection.
 torch.set_float32_matmul_precision("highest")
+
+
+# A/B and test switch: False runs the same layers as separate launches (the 128 <-> 32 GEMMs of rqhip/linear.py:chain_*, the stack kernel
+# between them) -- bit-identical results (tests/test_gpu_seam.py), one launch more on either side of the quantiser
+FUSE_SEAM = True
 
 
 class RqVaeOutput(NamedTuple):
@@ -131,6 +137,21 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
                 return False
         return True
 
+    def _seam_weights(self, x: Tensor):
+        """(w_in, w_out) when RqVae.forward can run the encoder's last Linear, every level and the decoder's first Linear + ReLU as ONE
+        launch (rqhip_rq_seam): embed_dim 32 behind a 128-wide hidden layer on both sides (the reference's
+        configs/rqvae_amazon.gin), plain codebooks that fit the LDS beside the two weights, a mode the stack kernel implements, and a
+        batch of 4096 rows or more; else None.  (Smaller batches are launch-bound and keep round 5's path: measured at batch 640, the
+        fused node 0.233 ms per graph step against 0.198 -- its two weight gradients leave the MLP stacks' job tables and every GEMM
+        output is a long chain of dependent fp32 matrix instructions; profiles/r06_seam.txt.)"""
+        if (not FUSE_SEAM or torch_ops.enabled() or not _lin._CHAIN or type(self.encoder) is not MLP or type(self.decoder) is not MLP
+                or not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= _lin._SPLIT_MIN_ROWS)
+                or not self._can_fuse() or not all(layer.plain_codebook for layer in self.layers)
+                or self.embed_dim != _lin.CHAIN_D or not ops.rq_seam_supported(self.embed_dim, _lin.CHAIN_H, len(self.layers), self.codebook_size)):
+            return None
+        w_in, w_out = self.encoder.seam_tail_weight(), self.decoder.seam_head_weight()
+        return None if (w_in is None or w_out is None) else (w_in, w_out)
+
     def _quantize_stack(self, res: Tensor, gumbel_t: float, want_levels: bool) -> _StackResult:
         if self._can_fuse():
             codebooks = torch.stack([layer.codebook() for layer in self.layers])  # [L,K,D], autograd splits it back
@@ -175,20 +196,47 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
     def forward(self, batch: SeqBatch, gumbel_t: float) -> RqVaeComputedLosses:
         x = batch.x
         xin = x.to(next(self.encoder.parameters()).dtype)
-        res0 = self.encode(xin)
         reducer = getattr(self, "_rq_reducer", None)
-        if reducer is not None and res0.requires_grad:
-            # multi-GPU: when this gradient exists, decoder and codebook gradients are final -- their all-reduce starts under
-            # the encoder's backward (rqhip/dist.py:FlatGradReducer.boundary_hook; a no-op with one rank or an unarmed step)
-            res0.register_hook(reducer.boundary_hook)
-        st = self._quantize_stack(res0, gumbel_t, want_levels=False)
         n = self.n_cat_feats
-        reconstruction = None
-        if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and type(self.decoder) is MLP and x.dim() == 2:
-            # large batches: the last decoder layer and the loss are one kernel, x_hat is never stored (modules/encoder.py)
-            reconstruction = self.decoder.reconstruction_rows(st.emb_sum, xin)
+        seam = self._seam_weights(xin)
+        reconstruction = x_hat = None
+        if seam is not None:
+            # the seam: the encoder up to its last hidden activation, then ONE launch for the last encoder Linear, every level and the
+            # first decoder Linear + ReLU (res0 and the sum of the levels' outputs never travel), then the rest of the decoder
+            hidden = self.encoder.run_before_tail(xin)
+            codebooks = torch.stack([layer.codebook() for layer in self.layers])
+            sink = getattr(self, "_rq_cb_grad_sink", None)
+            want_scales = _lin.f16() and xin.shape[0] >= _lin._SPLIT_MIN_ROWS
+            if reducer is not None and hidden.requires_grad:
+                # multi-GPU: when the gradient of `hidden` exists, the decoder's, the codebooks' and every other gradient that is not an
+                # encoder parameter's has been accumulated -- their all-reduce starts under the rest of the encoder's backward
+                # (rqhip/dist.py:FlatGradReducer.boundary_hook; a no-op with one rank or an unarmed step).  The encoder's last weight,
+                # whose gradient the seam node forms, is an encoder parameter: it travels with the late part.
+                hidden.register_hook(reducer.boundary_hook)
+            ids, qloss, norms, d = RqSeamFunction.apply(hidden, seam[0], codebooks, seam[1], self.layers[0].hip_mode(),
+                                                        float(self.commitment_weight), sink, want_scales)
+            if want_scales and RqSeamFunction.last_out_scales is not None:
+                sc = RqSeamFunction.last_out_scales
+                _lin.attach_scales(d, sc.rows, sc.cols)    # the maxima the decoder's split kernels scale by came with the launch
+            RqSeamFunction.last_out_scales = None
+            st = _StackResult(None, None, ids, qloss, None, norms)
+            if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and x.dim() == 2:
+                reconstruction = self.decoder.reconstruction_rows(d, xin, first=2)
+            if reconstruction is None:
+                x_hat = self.decoder.run_after_head(d)
+        else:
+            res0 = self.encode(xin)
+            if reducer is not None and res0.requires_grad:
+                # multi-GPU: when this gradient exists, decoder and codebook gradients are final -- their all-reduce starts under
+                # the encoder's backward (rqhip/dist.py:FlatGradReducer.boundary_hook; a no-op with one rank or an unarmed step)
+                res0.register_hook(reducer.boundary_hook)
+            st = self._quantize_stack(res0, gumbel_t, want_levels=False)
+            if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and type(self.decoder) is MLP and x.dim() == 2:
+                # large batches: the last decoder layer and the loss are one kernel, x_hat is never stored (modules/encoder.py)
+                reconstruction = self.decoder.reconstruction_rows(st.emb_sum, xin)
         if reconstruction is None:
-            x_hat = self.decode(st.emb_sum)                               # embs.sum(axis=-1), rqvae.py:146
+            if x_hat is None:
+                x_hat = self.decode(st.emb_sum)                           # embs.sum(axis=-1), rqvae.py:146
             # rqvae.py:147-150: with n == 0 the `[..., :-0]` slice is EMPTY, so nothing is normalised
             x_hat = torch.cat([l2norm(x_hat[..., :-n]), x_hat[..., -n:]], dim=-1) if n != 0 else x_hat
             # (the kernels are fp32: a float64 / fp16 batch is compared in the model's dtype, as it was encoded)

@@ -69,6 +69,109 @@ class RqStackFunction(torch.autograd.Function):
         return g_res0, (g_cb.view_as(g_cb) if out_cb is not None else g_cb), None, None, None, None
 
 
+class RqSeamFunction(torch.autograd.Function):
+    """The RQ <-> MLP seam as ONE differentiable op and ONE forward launch (rqhip_rq_seam; reference modules/rqvae.py:118-139,146 with the
+    last encoder Linear of modules/encoder.py:25-38 in front and the first decoder Linear + ReLU behind):
+
+        forward(h [B,128], w_in [32,128], codebooks [L,K,32], w_out [128,32], mode, beta, grad_sink, want_scales)
+            -> ids [L,B], loss [B], embs_norm [B,L], d [B,128] = relu((sum of the levels' outputs) w_out^T)
+
+    res0 = h w_in^T and the sum of the levels' outputs stay inside (saved for the backward).  Backward, composed of the same kernels:
+    the decoder-side data gradient with the ReLU backward applied on load, the quantiser's closed-form backward (csrc/rq_backward.hip),
+    the encoder-side data gradient with the ReLU backward of the layer below and its maxima in the epilogue (handed to the encoder
+    stack's node: rqhip/linear.py:handoff_grad), and the two 32-wide weight gradients.  Same bits as running the three pieces as separate
+    launches (tests/test_gpu_seam.py), which is what every other path through these layers does (rqhip/linear.py:chain_*)."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, w_in: Tensor, codebooks: Tensor, w_out: Tensor, mode: int, beta: float, grad_sink, want_scales: bool):
+        from . import _lib
+        from . import linear as _lin
+        # (one zeroed buffer for the column maxima of this launch's output and of the backward's: one fill launch, not two)
+        both = torch.zeros((2 * ops.SEAM_H,), dtype=torch.int32, device=h.device) if want_scales else None
+        cols = both[:ops.SEAM_H] if want_scales else None
+        ctx.bwd_cols = both[ops.SEAM_H:] if (want_scales and torch.is_grad_enabled()) else None
+        r = ops.rq_seam(h=h, w_in=w_in.detach(), codebooks=codebooks.detach(), mode=mode, beta=beta, w_out=w_out.detach(),
+                        epilogue=_lib.EPI_RELU, want_row_max=want_scales, col_max_out=cols)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(h, w_in, codebooks, w_out, r.res0, r.ids, r.emb_sum, r.out)
+        ctx.mode, ctx.beta, ctx.grad_sink, ctx.want_scales = mode, beta, grad_sink, want_scales
+        ctx.mark_non_differentiable(r.ids, r.embs_norm)
+        ctx.out_scales = _lin.Scales(r.out_row_max, cols) if want_scales else None
+        RqSeamFunction.last_out_scales = ctx.out_scales      # (picked up by the caller right after apply: modules/rqvae.py)
+        return r.ids, r.loss, r.embs_norm, r.out
+
+    last_out_scales = None
+
+    @staticmethod
+    def backward(ctx, _g_ids, g_loss, _g_norm, g_d):
+        from . import linear as _lin
+        from .dist import claim_grad_sink
+        h, w_in, codebooks, w_out, res0, ids, emb_sum, d = ctx.saved_tensors
+        need_h, need_win, need_cb, need_wout = ctx.needs_input_grad[:4]
+        g_d, g_loss = _dense(g_d), _dense(g_loss)
+        B = h.shape[0]
+        jobs = _lin.wgrad_jobs_ok(B, [tuple(w_out.shape), tuple(w_in.shape)])     # small batches: both weight gradients in ONE launch, at the end
+        pending = []
+        gw_out = gw_in = None
+        # 1. decoder side: d = relu(s w_out^T)
+        g_es = None
+        if g_d is not None:
+            g_dm = None
+            if need_wout:
+                if jobs:
+                    g_dm = torch.ops.aten.threshold_backward(g_d, d, 0.0)     # (the job-table kernel takes the masked gradient as a tensor)
+                    pending.append(("out", g_dm, emb_sum, claim_grad_sink(w_out), w_out))
+                else:
+                    sink = claim_grad_sink(w_out)
+                    gw, gp, _ = _lin.weight_grad(g_d, d, emb_sum, w_out, out=sink, want_masked=False)
+                    gw_out = gw.view_as(gw) if sink is not None else gw
+                    g_dm = gp if (gp is not None and gp is not g_d) else None
+            if need_h or need_win or need_cb:
+                g_es = (_lin.chain_input_grad(g_dm, w_out)[0] if g_dm is not None
+                        else _lin.chain_input_grad(g_d, w_out, g_mask=d)[0])       # the ReLU backward on load
+        # 2. the quantiser (closed form)
+        g_res0 = g_cb = None
+        if need_h or need_win or need_cb:
+            sink = ctx.grad_sink
+            out_cb = None
+            if need_cb and sink is not None and tuple(sink.view.shape) == tuple(codebooks.shape) and all(
+                    p.grad is None and getattr(p, "_rq_sink_epoch", -1) != sink.owner.epoch for p in sink.params):
+                out_cb = sink.view
+                for p in sink.params:
+                    p._rq_sink_epoch = sink.owner.epoch
+            g_res0, g_cb = ops.rq_backward(res0, codebooks, ctx.mode, ctx.beta, ids, g_embsum=g_es, g_loss=g_loss,
+                                           need_res0=need_h or need_win, need_codebooks=need_cb, out_g_codebooks=out_cb,
+                                           cbgrad=ops.cbgrad_default())
+            if out_cb is not None and g_cb is not None:
+                g_cb = g_cb.view_as(g_cb)
+        # 3. encoder side: res0 = h w_in^T, h = relu(...) of the encoder stack's last layer
+        g_h = None
+        if g_res0 is not None and need_win:
+            if jobs:
+                pending.append(("in", g_res0, h, claim_grad_sink(w_in), w_in))
+            else:
+                sink = claim_grad_sink(w_in)
+                gw, _, _ = _lin.weight_grad(g_res0, None, h, w_in, out=sink)
+                gw_in = gw.view_as(gw) if sink is not None else gw
+        if pending:
+            outs = [sk if sk is not None else torch.empty_like(w) for (_, _, _, sk, w) in pending]
+            for (which, _, _, sk, _), gw in zip(pending, ops.linear_wgrad_jobs([(gm, a) for _, gm, a, _, _ in pending], outs=outs)):
+                gw = gw.view_as(gw) if sk is not None else gw
+                if which == "out":
+                    gw_out = gw
+                else:
+                    gw_in = gw
+        if g_res0 is not None and need_h:
+            cols = None
+            if ctx.want_scales:      # the forward's spare half, once; a second backward through a retained graph zeroes its own
+                cols, ctx.bwd_cols = ctx.bwd_cols, None
+                if cols is None:
+                    cols = torch.zeros((ops.SEAM_H,), dtype=torch.int32, device=h.device)
+            g_h, sc = _lin.chain_input_grad(g_res0, w_in, out_mask=h, want_rows=ctx.want_scales, col_out=cols)
+            _lin.handoff_grad(g_h, sc if ctx.want_scales else _lin.Scales())
+        return g_h, gw_in, g_cb, gw_out, None, None, None, None
+
+
 class GumbelLevelFunction(torch.autograd.Function):
     """One GUMBEL_SOFTMAX level (training): forward(x [B,D], codebook [K,D], U [B,K], T, beta) -> emb, ids, loss."""
 

@@ -81,7 +81,7 @@ def attached_scales(t: Tensor) -> Optional[Scales]:
     sc = getattr(t, "_rq_scales", None)
     if sc is None:
         return None
-    ok_r = sc.rows is None or (sc.rows.dtype == torch.int32 and tuple(sc.rows.shape) == (1, t.shape[0]) and sc.rows.device == t.device)
+    ok_r = sc.rows is None or (sc.rows.dtype == torch.int32 and sc.rows.dim() == 2 and sc.rows.shape[1] == t.shape[0] and sc.rows.device == t.device)
     ok_c = sc.cols is None or (sc.cols.dtype == torch.int32 and tuple(sc.cols.shape) == (t.shape[1],) and sc.cols.device == t.device)
     return Scales(sc.rows if ok_r else None, sc.cols if ok_c else None)
 
@@ -98,6 +98,22 @@ def handoff_scales(sc: Optional[Scales]) -> None:
 def take_scales() -> Optional[Scales]:
     sc, _HANDOFF[0] = _HANDOFF[0], None
     return sc
+
+
+_GRAD_HANDOFF: List[Optional[tuple]] = [None]
+
+
+def handoff_grad(g: Tensor, sc: Scales) -> None:
+    """The NEXT `_MLPStack.backward` that receives `g` (same storage, same shape) as its upstream gradient may take it as already masked by
+    its last layer's ReLU, with these maxima (set by the backward of modules/rqvae.py's seam node, whose epilogue did both)."""
+    _GRAD_HANDOFF[0] = (g.data_ptr(), tuple(g.shape), sc)
+
+
+def take_grad_handoff(g: Tensor) -> Optional[Scales]:
+    slot, _GRAD_HANDOFF[0] = _GRAD_HANDOFF[0], None     # one shot: whoever asks next clears it, match or not
+    if slot is not None and slot[0] == g.data_ptr() and slot[1] == tuple(g.shape):
+        return slot[2]
+    return None
 
 
 def ensure_scales(a: Tensor, sc: Optional[Scales], rows: bool, cols: bool) -> Scales:
@@ -193,6 +209,73 @@ def _tile_code(n_cols: int, n_red: int, epilogue: int) -> int:
     return -5 if (_WIDE_TILES and f16() and n_cols % 512 == 0 and n_red >= _WIDE_MIN_RED and epilogue != _lib.EPI_RECON) else 0
 
 
+# ---- the 32-wide layers either side of the quantiser (the RQ <-> MLP seam) ------------------------------------------------------------
+# The encoder's last Linear (128 -> 32) and the decoder's first (32 -> 128), forward and data gradient, run on csrc/rq_forward.hip's seam
+# kernel (rqhip_rq_seam): every output is ONE fp32 FMA chain over the input features on the fp32 matrix pipe -- no library call, the ReLU /
+# ReLU backward and the maxima the neighbouring split kernels scale by in the same launch, and the same bits in the fused launch
+# RqVae.forward uses (modules/rqvae.py), which is this kernel with the quantisation levels switched on.  Batches of 4096 rows and more.
+_CHAIN = True
+CHAIN_D, CHAIN_H = 32, ops.SEAM_H
+
+
+def use_chain_gemms(on: bool = True) -> bool:
+    """The 128 <-> 32 layers on the seam kernel (default) or on the library / split kernels as in round 5 (A/B: bench.py --no-seam).
+    Returns the previous setting."""
+    global _CHAIN
+    before, _CHAIN = _CHAIN, bool(on)
+    return before
+
+
+def chain_shape(n_out: int, n_in: int, rows: int = _SPLIT_MIN_ROWS) -> int:
+    """0: not a seam layer; 1: 128 -> 32 (rows enter the input GEMM); 2: 32 -> 128 (rows leave through the output GEMM).
+    Batches of 4096 rows and more, like the split kernels: every output of these GEMMs is a 64- or 16-deep chain of dependent fp32
+    matrix instructions over 32 rows at a time -- at the reference's batch 640 that is 20 such chains on 20 SIMDs, 9.3 us per
+    launch against 4.6-5.9 us for the library's 16 x 16 tiles (profiles/r06_seam.txt): small batches keep the library GEMMs."""
+    if not _CHAIN or rows < _SPLIT_MIN_ROWS:
+        return 0
+    return 1 if (n_out, n_in) == (CHAIN_D, CHAIN_H) else 2 if (n_out, n_in) == (CHAIN_H, CHAIN_D) else 0
+
+
+def chain_kind(x: Tensor, n_out: int, n_in: int) -> int:
+    """chain_shape for an operand that exists: a 2-D fp32 ROCm tensor of n_in columns with at least one row, 16-byte aligned rows."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.shape[1] == n_in
+            and x.data_ptr() % 16 == 0):
+        return 0
+    return chain_shape(n_out, n_in, x.shape[0])
+
+
+def _chain_scales(r, col_out) -> "Scales":
+    return Scales(r.out_row_max if r.out_row_max is not None else None, col_out)
+
+
+def chain_forward(x: Tensor, w: Tensor, relu: bool, want_rows: bool = False, col_out: Optional[Tensor] = None):
+    """(y, Scales of y) of y = [relu](x w^T) for a seam layer (chain_kind != 0; a ReLU only behind the 32 -> 128 layer)."""
+    kind = chain_kind(x, w.shape[0], w.shape[1])
+    x = x if x.is_contiguous() else x.contiguous()
+    if kind == 1:
+        assert not relu
+        return ops.rq_seam(h=x, w_in=w.detach()).res0, Scales()
+    r = ops.rq_seam(res0=x, w_out=w.detach(), epilogue=_lib.EPI_RELU if relu else _lib.EPI_STORE, want_row_max=want_rows and f16(),
+                    col_max_out=col_out if f16() else None)
+    return r.out, _chain_scales(r, col_out if f16() else None)
+
+
+def chain_input_grad(g: Tensor, w: Tensor, *, g_mask: Optional[Tensor] = None, out_mask: Optional[Tensor] = None, want_rows: bool = False,
+                     col_out: Optional[Tensor] = None):
+    """(gx, Scales of gx) of gx = g' w for a seam layer with weight w [n_out, n_in]; g' = g where g_mask > 0 (the layer's own ReLU
+    backward, applied on load: 32 -> 128 layers only); gx is kept where out_mask > 0 (the ReLU backward of the layer below, in the
+    epilogue: 128 -> 32 layers only)."""
+    kind = chain_kind(g, w.shape[1], w.shape[0])      # the data gradient maps n_out -> n_in
+    g = g if g.is_contiguous() else g.contiguous()
+    if kind == 1:       # layer 32 -> 128, w [128, 32]: gx [B, 32] = g' [B, 128] . w
+        assert out_mask is None
+        return ops.rq_seam(h=g, h_mask=g_mask, w_in=w.detach(), w_in_transposed=True).res0, Scales()
+    assert kind == 2 and g_mask is None   # layer 128 -> 32, w [32, 128]: gx [B, 128] = g [B, 32] . w
+    r = ops.rq_seam(res0=g, w_out=w.detach(), w_out_transposed=True, epilogue=_lib.EPI_MASK if out_mask is not None else _lib.EPI_STORE,
+                    out_mask=out_mask, want_row_max=want_rows and f16(), col_max_out=col_out if f16() else None)
+    return r.out, _chain_scales(r, col_out if f16() else None)
+
+
 def images(jobs: List[Tuple[Tensor, bool]]) -> List[Tensor]:
     """The weight images of `jobs` = [(w, transpose), ...] in the current arithmetic, one launch.  Rebuilt at EVERY forward:
     a first version cached an image per `w._version` -- and trained on stale weights: the fused AdamW update (and any
@@ -222,6 +305,8 @@ def gemm(a: Tensor, image: Tensor, n_cols: int, *, epilogue: int = _lib.EPI_STOR
 def input_grad(g: Tensor, w: Tensor, *, g_scales: Optional[Scales] = None, image: Optional[Tensor] = None) -> Tensor:
     """g [M, N] . w [N, K]: the split kernel with the image of w^T where it applies, else the library GEMM."""
     g = g if g.is_contiguous() else g.contiguous()
+    if chain_kind(g, w.shape[1], w.shape[0]):
+        return chain_input_grad(g, w)[0]
     if split_ok(g, w.shape[1], w.shape[0], False):
         return gemm(g, image if image is not None else planes(w, True), w.shape[1], a_scales=g_scales)[0]
     return g.mm(w)
@@ -230,6 +315,9 @@ def input_grad(g: Tensor, w: Tensor, *, g_scales: Optional[Scales] = None, image
 def forward(x: Tensor, w: Tensor, relu: bool, zero_bias: Tensor = None) -> Tensor:
     """relu(x w^T) or x w^T for 2-D fp32 ROCm tensors: the split kernel where it applies, else the library GEMM (with
     the ReLU in the hipBLASLt epilogue)."""
+    kind = chain_kind(x, w.shape[0], w.shape[1])
+    if kind == 2 or (kind == 1 and not relu):
+        return chain_forward(x, w, relu)[0]
     if split_ok(x, w.shape[0], w.shape[1], relu):
         return gemm(x, planes(w, False), w.shape[0], epilogue=_lib.EPI_RELU if relu else _lib.EPI_STORE)[0]
     return library_forward(x, w, relu, zero_bias)

@@ -573,7 +573,7 @@ def test_fused_last_layer_and_reconstruction_loss_equals_the_composed_pair(case,
     def run(fused):
         m = _rqvae_768()
         if not fused:
-            monkeypatch.setattr(MLP, "reconstruction_rows", lambda self, z, t: None)
+            monkeypatch.setattr(MLP, "reconstruction_rows", lambda self, z, t, first=0: None)
         else:
             monkeypatch.undo()
             monkeypatch.setattr(_MLPStack, "apply", lambda *a: (calls.append(1) if a[1] is not None else None, real_apply(*a))[1])

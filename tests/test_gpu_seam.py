@@ -121,3 +121,70 @@ def test_unsupported_shapes_are_refused():
                     codebooks=torch.zeros(4, 1024, D, device="cuda"))
     with pytest.raises(_lib.RqHipError):
         ops.rq_seam(h=torch.zeros(4, H), w_in=torch.zeros(D, H))      # host tensors: no fallback
+
+
+# ---- module level: RqVae.forward through the fused seam node == the same layers as separate launches ---------------------------------
+def _model(mode, L=3, K=256):
+    from modules.quantize import QuantizeForwardMode
+    from modules.rqvae import RqVae
+    torch.manual_seed(0)
+    m = RqVae(input_dim=768, embed_dim=32, hidden_dims=[512, 256, 128], codebook_size=K, n_layers=L, n_cat_features=0,
+              codebook_kmeans_init=False, codebook_mode=mode, commitment_weight=0.25).cuda()
+    with torch.no_grad():
+        for l, layer in enumerate(m.layers):
+            layer.embedding.weight.copy_(torch.randn(K, 32, generator=torch.Generator().manual_seed(50 + l)).cuda() * (0.3 / (l + 1)))
+    return m
+
+
+@pytest.mark.parametrize("B", [4096, 4500, 20001])
+@pytest.mark.parametrize("mode_name", ["STE", "ROTATION_TRICK"])
+def test_rqvae_forward_backward_fused_seam_equals_separate_launches(B, mode_name):
+    import modules.rqvae as rqvae_mod
+    from data.schemas import SeqBatch
+    from modules.quantize import QuantizeForwardMode
+    mode = getattr(QuantizeForwardMode, mode_name)
+    g = torch.Generator().manual_seed(11)
+    x = torch.nn.functional.normalize(torch.randn(B, 768, generator=g), dim=-1).cuda()
+    results = []
+    for fuse in (True, False):
+        prev, rqvae_mod.FUSE_SEAM = rqvae_mod.FUSE_SEAM, fuse
+        try:
+            m = _model(mode)
+            m.train()
+            assert (m._seam_weights(x) is not None) == fuse
+            out = m(SeqBatch(None, None, None, x, None, None), 0.2)
+            out.loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            m.eval()
+            with torch.no_grad():
+                ev = m(SeqBatch(None, None, None, x, None, None), 0.2)
+            results.append((out, grads, ev))
+        finally:
+            rqvae_mod.FUSE_SEAM = prev
+    (a, ga, ea), (b, gb, eb) = results
+    for name in ("loss", "reconstruction_loss", "rqvae_loss", "embs_norm", "p_unique_ids"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert torch.equal(getattr(ea, name), getattr(eb, name)), "eval " + name
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+
+
+def test_tokenisation_and_training_forward_agree_on_the_ids():
+    """get_semantic_ids (encode -> stack kernel, per-level outputs) and the fused training forward see the same res0 bits: the encoder's
+    last Linear is the seam kernel's GEMM on every path."""
+    m = _model(__import__("modules.quantize", fromlist=["QuantizeForwardMode"]).QuantizeForwardMode.STE)
+    g = torch.Generator().manual_seed(12)
+    x = torch.nn.functional.normalize(torch.randn(5000, 768, generator=g), dim=-1).cuda()
+    m.eval()
+    with torch.no_grad():
+        sem = m.get_semantic_ids(x)
+        hidden = m.encoder.run_before_tail(x)
+        w_in, w_out = m._seam_weights(x)
+        r = ops.rq_seam(h=hidden, w_in=w_in, codebooks=torch.stack([l.codebook() for l in m.layers]), mode=ops.MODE_EVAL, beta=0.25,
+                        w_out=w_out, epilogue=_lib.EPI_RELU)
+        assert torch.equal(m.encode(x), r.res0)
+        assert torch.equal(sem.sem_ids, r.ids.t()) and torch.equal(sem.quantize_loss, r.loss)
+        # the decoder's first Linear + ReLU through the module stack (the stand-alone launch of the same GEMM) on the stack kernel's sum
+        k = ops.rq_forward(m.encode(x), torch.stack([l.codebook() for l in m.layers]), ops.MODE_EVAL, 0.25, want_embs=False, want_residuals=False)
+        assert torch.equal(m.decoder._run(k.emb_sum, list(m.decoder.mlp)[:2]), r.out)

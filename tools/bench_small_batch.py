@@ -25,7 +25,10 @@ JSON = "--json" in sys.argv
 if "--no-jobs" in sys.argv:      # A/B: round 4's per-layer weight-gradient kernels instead of csrc/wgrad_jobs.hip
     from rqhip import linear as _linear
     _linear.use_wgrad_jobs(False)
-ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs")]
+if "--no-seam" in sys.argv:      # A/B: round 5's library GEMMs for the 128 <-> 32 layers instead of the seam kernel (rqhip_rq_seam)
+    from rqhip import linear as _linear
+    _linear.use_chain_gemms(False)
+ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs", "--no-seam")]
 
 
 def timeit(fn, n=200):
