@@ -281,6 +281,12 @@ int rqhip_recon_loss_backward_spec(const float *x_hat, int64_t ld_hat, const flo
 /* The three batch means of RqVae.forward (modules/rqvae.py:154,171-172) in one launch:
  *   out3[0] = mean(recon + quant), out3[1] = mean(recon), out3[2] = mean(quant);  recon, quant [B] fp32, B >= 1. */
 int rqhip_loss_means(const float *recon, const float *quant, int64_t B, float *out3, rqhip_stream_t stream);
+/* the same means by many workgroups (one launch; block partials met by the last block to arrive, in block order: deterministic).
+ * workspace: rqhip_loss_means_workspace_bytes() bytes, 16-byte aligned, zeroed ONCE by the caller and then reusable launch after launch
+ * on one stream (the kernel re-arms its counter). */
+size_t rqhip_loss_means_workspace_bytes(void);
+int rqhip_loss_means_ws(const float *recon, const float *quant, int64_t B, float *out3, void *workspace, size_t workspace_bytes,
+                        rqhip_stream_t stream);
 /* Its backward (autograd of the three `.mean()`s): g_loss, g_recon_mean, g_quant_mean are device scalars (gradients wrt
  * out3[0..2]; each may be NULL = no gradient).  rows_recon[i] = (g_loss + g_recon_mean) * (1/B) and
  * rows_quant[i] = (g_loss + g_quant_mean) * (1/B) for every i < B, 1/B rounded to fp32 first as PyTorch's mean backward

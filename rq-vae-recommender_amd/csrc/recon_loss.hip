@@ -224,6 +224,62 @@ __global__ __launch_bounds__(1024) void loss_means_kernel(const float *__restric
     if (t < 3) out[t] = red[t][0] / (float)B;
 }
 
+// The same three means by many workgroups (round 6): block b sums rows [b chunk, (b + 1) chunk) -- thread t its float4 groups t, t + 256, ...
+// in order, then a fixed LDS tree -- into partial[b][0..2]; the LAST block to arrive (a counter behind the partials, re-armed for the
+// next launch) adds the partials in block order and divides.  The grid depends on B only: deterministic; another summation order than
+// the one-workgroup kernel's (both are within fp32 rounding of the exact means, tests/test_gpu_parity.py).
+constexpr int kLmChunkRows = 4096;      // rows per block
+constexpr int kLmMaxBlocks = 1024;
+__global__ __launch_bounds__(256) void loss_means_blocks_kernel(const float *__restrict__ recon, const float *__restrict__ quant, long long B,
+                                                               float *__restrict__ partial, unsigned *__restrict__ counter,
+                                                               float *__restrict__ out) {
+    __shared__ float red[3][256];
+    __shared__ bool s_last;
+    const int t = threadIdx.x, nb = gridDim.x;
+    const long long per = ((B + nb - 1) / nb + 3) / 4 * 4;            // rows per block, a multiple of 4
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < B ? lo + per : B;
+    float s_sum = 0.0f, s_r = 0.0f, s_q = 0.0f;
+    const bool vec = ((reinterpret_cast<uintptr_t>(recon) | reinterpret_cast<uintptr_t>(quant)) & 15) == 0;
+    const long long n4 = (vec && hi > lo) ? (hi - lo) / 4 : 0;
+    for (long long i = t; i < n4; i += 256) {
+        const f32x4 a = reinterpret_cast<const f32x4 *>(recon + lo)[i], b = reinterpret_cast<const f32x4 *>(quant + lo)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s_sum = s_sum + (a[j] + b[j]);
+            s_r = s_r + a[j];
+            s_q = s_q + b[j];
+        }
+    }
+    for (long long i = lo + 4 * n4 + t; i < hi; i += 256) {
+        const float a = recon[i], b = quant[i];
+        s_sum = s_sum + (a + b);
+        s_r = s_r + a;
+        s_q = s_q + b;
+    }
+    red[0][t] = s_sum; red[1][t] = s_r; red[2][t] = s_q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c][t] = red[c][t] + red[c][t + s];
+        }
+        __syncthreads();
+    }
+    if (t < 3) partial[(size_t)blockIdx.x * 3 + t] = red[t][0];
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(counter, 1u) == (unsigned)nb - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (t < 3) {
+        float acc = 0.0f;
+        for (int b = 0; b < nb; ++b) acc = acc + __builtin_nontemporal_load(partial + (size_t)b * 3 + t);
+        out[t] = acc / (float)B;
+    }
+    if (t == 0) *counter = 0u;        // re-armed: the workspace stays usable launch after launch without a fill
+}
+
 // Backward of the three means: every row of `recon` receives (g_loss + g_recon_mean) * (1/B), every row of `quant`
 // (g_loss + g_quant_mean) * (1/B) -- the arithmetic of PyTorch's own mean backward on the device, which multiplies by
 // the fp32 reciprocal of a scalar divisor -- written as the two dense [B] vectors the next kernels read, in one launch
@@ -352,6 +408,28 @@ extern "C" int rqhip_loss_means_backward(const float *g_loss, const float *g_rec
     hipLaunchKernelGGL(loss_means_bwd_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g_loss,
                        g_recon_mean, g_quant_mean, (long long)B, rows_recon, rows_quant);
     RQ_CHECK_LAUNCH("loss_means_bwd_kernel");
+    return RQHIP_OK;
+}
+
+extern "C" size_t rqhip_loss_means_workspace_bytes(void) { return (size_t)kLmMaxBlocks * 3 * sizeof(float) + 16; }
+
+extern "C" int rqhip_loss_means_ws(const float *recon, const float *quant, int64_t B, float *out3, void *workspace, size_t workspace_bytes,
+                                   rqhip_stream_t stream) {
+    if (B <= 0 || !recon || !quant || !out3) {
+        set_error("loss_means: bad arguments");
+        return RQHIP_EARG;
+    }
+    if (!workspace || workspace_bytes < rqhip_loss_means_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 15u)) {
+        set_error("loss_means_ws: workspace of rqhip_loss_means_workspace_bytes() bytes, 16-byte aligned, ZEROED once by the caller");
+        return RQHIP_EWORKSPACE;
+    }
+    long long nb = (B + kLmChunkRows - 1) / kLmChunkRows;
+    if (nb > kLmMaxBlocks) nb = kLmMaxBlocks;
+    float *partial = reinterpret_cast<float *>(workspace);
+    unsigned *counter = reinterpret_cast<unsigned *>(partial + (size_t)kLmMaxBlocks * 3);
+    hipLaunchKernelGGL(loss_means_blocks_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), recon, quant,
+                       (long long)B, partial, counter, out3);
+    RQ_CHECK_LAUNCH("loss_means_blocks_kernel");
     return RQHIP_OK;
 }
 

@@ -110,7 +110,7 @@ class _MLPStack(torch.autograd.Function):
         # (and of the reconstruction gradient for the last layer's own weight gradient) -- one zeroed arena
         emit = [f16 and (fwd_split[i] or chain[i] == 2) and ((i + 1 < n and wg_f16[i + 1]) or (i + 1 == n and target is not None and wg_f16[i]))
                 for i in range(n)]
-        arena = torch.zeros((sum(w.shape[0] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=x.device) if any(emit) else None
+        arena = _lin.zeros_i32(sum(w.shape[0] for i, w in enumerate(weights) if emit[i]), x.device) if any(emit) else None
         off = 0
         acts, scs = [x], [given if given is not None else _lin.Scales()]
         if f16 and (fwd_split[0] or wg_f16[0]):   # the input batch: the one maxima pass of the step -- unless its maxima came with it
@@ -172,7 +172,7 @@ class _MLPStack(torch.autograd.Function):
         # column maxima the data-gradient epilogues emit: of the gradient wrt layer i - 1's output (masked) when that
         # layer's weight gradient wants them
         emit = [f16 and (dg_split[i] or chain[i] == 1) and i > 0 and wg_f16[i - 1] for i in range(n)]
-        arena = torch.zeros((sum(w.shape[1] for i, w in enumerate(weights) if emit[i]),), dtype=torch.int32, device=g.device) if any(emit) else None
+        arena = _lin.zeros_i32(sum(w.shape[1] for i, w in enumerate(weights) if emit[i]), g.device) if any(emit) else None
         off = 0
         premasked = (not relus[n - 1]) or handed is not None      # is g already masked by this layer's ReLU (or is there none)?
         gws = [None] * n

@@ -40,6 +40,17 @@ torch.set_float32_matmul_precision("highest")
 FUSE_SEAM = True
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 class RqVaeOutput(NamedTuple):
     embeddings: Tensor     # [B, D, L]
     residuals: Tensor      # [B, D, L]
@@ -199,7 +210,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         reducer = getattr(self, "_rq_reducer", None)
         n = self.n_cat_feats
         seam = self._seam_weights(xin)
-        reconstruction = x_hat = None
+        reconstruction = x_hat = p_unique_ids = side = None
         if seam is not None:
             # the seam: the encoder up to its last hidden activation, then ONE launch for the last encoder Linear, every level and the
             # first decoder Linear + ReLU (res0 and the sum of the levels' outputs never travel), then the rest of the decoder
@@ -220,6 +231,15 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
                 _lin.attach_scales(d, sc.rows, sc.cols)    # the maxima the decoder's split kernels scale by came with the launch
             RqSeamFunction.last_out_scales = None
             st = _StackResult(None, None, ids, qloss, None, norms)
+            if not torch.cuda.is_current_stream_capturing():
+                # the duplicate statistic (rqvae.py:159-167: a debug output nothing in the step consumes) runs on a SIDE stream under the
+                # decoder's GEMMs: a hash pass of CAS inserts + its fills and scalar kernels, 45 us of latency on the step's stream
+                side = _side_stream(ids.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), torch.no_grad():
+                    _, n_distinct = ops.dedup_rank(ids, self.codebook_size, want_rank=False)
+                    p_unique_ids = n_distinct / ids.shape[1]
+                ids.record_stream(side)
             if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and x.dim() == 2:
                 reconstruction = self.decoder.reconstruction_rows(d, xin, first=2)
             if reconstruction is None:
@@ -251,12 +271,16 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
                 loss, recon_mean, rq_mean = LossMeansFunction.apply(reconstruction, rqvae_loss)
         else:
             loss, recon_mean, rq_mean = (reconstruction + rqvae_loss).mean(), reconstruction.mean(), rqvae_loss.mean()
-        with torch.no_grad():
-            if torch_ops.enabled():
-                n_distinct = torch.ops.rqhip.distinct_tuples(st.ids, self.codebook_size)
-            else:
-                _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
-            p_unique_ids = n_distinct / st.ids.shape[1]                   # rqvae.py:159-167
+        if p_unique_ids is None:
+            with torch.no_grad():
+                if torch_ops.enabled():
+                    n_distinct = torch.ops.rqhip.distinct_tuples(st.ids, self.codebook_size)
+                else:
+                    _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
+                p_unique_ids = n_distinct / st.ids.shape[1]                   # rqvae.py:159-167
+        elif side is not None:
+            torch.cuda.current_stream().wait_stream(side)                   # join: the statistic is part of this call's result
+            p_unique_ids.record_stream(torch.cuda.current_stream())
         return RqVaeComputedLosses(
             loss=loss,
             reconstruction_loss=recon_mean,

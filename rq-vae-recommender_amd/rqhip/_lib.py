@@ -94,6 +94,8 @@ SIGNATURES = {
     "rqhip_recon_loss_forward_spec": (_int, [_vp, _i64, _vp, _i64, _i64, _int, _f32, _vp, _vp, _vp]),
     "rqhip_recon_loss_backward_spec": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _f32, _vp, _vp]),
     "rqhip_loss_means": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rqhip_loss_means_workspace_bytes": (_sz, []),
+    "rqhip_loss_means_ws": (_int, [_vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "rqhip_loss_means_backward": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rqhip_linear_wgrad_supported": (_int, [_int, _int]),
     "rqhip_linear_wgrad_plan": (_int, [_i64, _int, _int, C.POINTER(_int)]),

@@ -87,7 +87,7 @@ class RqSeamFunction(torch.autograd.Function):
         from . import _lib
         from . import linear as _lin
         # (one zeroed buffer for the column maxima of this launch's output and of the backward's: one fill launch, not two)
-        both = torch.zeros((2 * ops.SEAM_H,), dtype=torch.int32, device=h.device) if want_scales else None
+        both = _lin.zeros_i32(2 * ops.SEAM_H, h.device) if want_scales else None
         cols = both[:ops.SEAM_H] if want_scales else None
         ctx.bwd_cols = both[ops.SEAM_H:] if (want_scales and torch.is_grad_enabled()) else None
         r = ops.rq_seam(h=h, w_in=w_in.detach(), codebooks=codebooks.detach(), mode=mode, beta=beta, w_out=w_out.detach(),
@@ -166,7 +166,7 @@ class RqSeamFunction(torch.autograd.Function):
             if ctx.want_scales:      # the forward's spare half, once; a second backward through a retained graph zeroes its own
                 cols, ctx.bwd_cols = ctx.bwd_cols, None
                 if cols is None:
-                    cols = torch.zeros((ops.SEAM_H,), dtype=torch.int32, device=h.device)
+                    cols = _lin.zeros_i32(ops.SEAM_H, h.device)
             g_h, sc = _lin.chain_input_grad(g_res0, w_in, out_mask=h, want_rows=ctx.want_scales, col_out=cols)
             _lin.handoff_grad(g_h, sc if ctx.want_scales else _lin.Scales())
         return g_h, gw_in, g_cb, gw_out, None, None, None, None

@@ -100,6 +100,33 @@ def take_scales() -> Optional[Scales]:
     return sc
 
 
+# ---- zeroed int32 slices for column maxima ---------------------------------------------------------------------------------------------
+# Every kernel that emits column maxima accumulates them with atomic maxima into a buffer the caller zeroed; a training step at 100 000
+# rows asked for six such buffers, each a `torch.zeros` = one 4 us fill launch (28 us of a 2.7 ms step).  They are cut from a pool that
+# is zeroed ONCE (64 K words = one fill per ~20 steps); a slice is handed out once and never reused, an exhausted pool is replaced (its
+# slices live on as long as somebody holds them).  Under hipGraph capture a replay would meet non-zero slices: there, plain torch.zeros.
+_ZERO_POOL = {}
+_ZERO_POOL_WORDS = 1 << 16
+
+
+def zeros_i32(n: int, device) -> Tensor:
+    """A zeroed int32 [n] tensor nobody else holds (a 16-byte aligned slice of the device's pool; see above)."""
+    if n <= 0:
+        return torch.zeros((0,), dtype=torch.int32, device=device)
+    if n > _ZERO_POOL_WORDS // 4 or torch.cuda.is_current_stream_capturing():
+        return torch.zeros((n,), dtype=torch.int32, device=device)
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)     # (a pool belongs to the stream its fill ran on)
+    pool = _ZERO_POOL.get(key)
+    need = (n + 3) // 4 * 4
+    if pool is None or pool[1] + need > _ZERO_POOL_WORDS:
+        pool = [torch.zeros((_ZERO_POOL_WORDS,), dtype=torch.int32, device=device), 0]
+        _ZERO_POOL[key] = pool
+    out = pool[0][pool[1]:pool[1] + n]
+    pool[1] += need
+    return out
+
+
 _GRAD_HANDOFF: List[Optional[tuple]] = [None]
 
 

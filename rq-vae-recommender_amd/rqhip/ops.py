@@ -589,9 +589,20 @@ def loss_means(recon: Tensor, quant: Tensor) -> Tensor:
         raise RqHipError(f"loss_means: need two non-empty [B] tensors, got {tuple(recon.shape)}, {tuple(quant.shape)}")
     with torch.cuda.device(recon.device):
         out = torch.empty((3,), dtype=torch.float32, device=recon.device)
-        check(_lib.lib().rqhip_loss_means(_ptr(recon), _ptr(quant), recon.numel(), _ptr(out), _stream()),
-              "rqhip_loss_means")
+        l = _lib.lib()
+        if recon.numel() <= 4096:        # one workgroup's worth: the single-workgroup kernel
+            check(l.rqhip_loss_means(_ptr(recon), _ptr(quant), recon.numel(), _ptr(out), _stream()), "rqhip_loss_means")
+        else:                            # many workgroups; their meeting place is zeroed once per (device, stream) and re-armed by the kernel
+            key = (recon.device.index, _stream())
+            ws = _LOSS_MEANS_WS.get(key)
+            if ws is None:
+                ws = _LOSS_MEANS_WS[key] = torch.zeros((l.rqhip_loss_means_workspace_bytes(),), dtype=torch.uint8, device=recon.device)
+            check(l.rqhip_loss_means_ws(_ptr(recon), _ptr(quant), recon.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+                  "rqhip_loss_means_ws")
     return out
+
+
+_LOSS_MEANS_WS = {}
 
 
 def linear_wgrad_supported(n_out: int, n_in: int) -> bool:

@@ -58,7 +58,10 @@ def test_registered_ops_equal_the_function_path_and_compile_traces_them():
     torch_ops.enable(True)
     try:
         out, g = _step(m, x)
-        assert torch.equal(out.loss, ref_out.loss) and torch.equal(out.p_unique_ids, ref_out.p_unique_ids)
+        # (the two paths form the reconstruction loss rows in different kernels -- fused GEMM epilogue vs decoder + loss kernel: the rows
+        # agree to rounding, their batch mean to an ulp or two; everything that is the same arithmetic is compared bit for bit)
+        assert abs(float(out.loss) - float(ref_out.loss)) <= 3e-7 * abs(float(ref_out.loss))
+        assert torch.equal(out.rqvae_loss, ref_out.rqvae_loss) and torch.equal(out.p_unique_ids, ref_out.p_unique_ids)
         for a, b in zip(g, ref_g):
             assert torch.equal(a, b)
         # a traced training step: dynamo + AOT autograd see the kernels as opaque operators
