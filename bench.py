@@ -9,8 +9,9 @@ Workloads (BASELINE.json `configs`):
   --config c4 (configs[3]): 10 M x 768 items over 8 GPUs = 1 250 000 rows per GPU (seed 1234 + rank), 4 x 1024
       codebooks, D = 32.  One STEP = one pass over the rank's whole shard as 10 micro-batches of 125 000 rows with
       gradient accumulation, then ONE all-reduce and ONE AdamW update.
-A pass = RqVae.forward (encoder GEMMs, fused HIP residual quantisation, decoder GEMMs, losses, id statistics)
-+ backward (HIP closed-form RQ backward, HIP weight-gradient kernels, library data-gradient GEMMs) + one flat-buffer
+A pass = RqVae.forward (encoder GEMMs, the seam launch -- last encoder Linear + every quantisation level + first decoder Linear --,
+decoder GEMMs with the reconstruction loss in the last one's epilogue, loss means, id statistics) + backward (HIP closed-form RQ
+backward, split-fp16 data-gradient GEMMs and weight-gradient kernels) + one flat-buffer
 gradient all-reduce over RCCL (N > 1) + AdamW.  `value` = rows processed by all ranks / wall time of K steps (max over
 ranks, barrier + synchronize on both sides).  Weak scaling: every rank owns its own shard.
 
@@ -18,14 +19,17 @@ ranks, barrier + synchronize on both sides).  Weak scaling: every rank owns its 
 `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL).
 
 Extra objects on the JSON line:
-  roofline     -- the dominant HAND-WRITTEN kernel, rq_forward_kernel: algorithmic fp32 FLOPs per launch
-                  (L*(2DK+5D) per row) / mean launch duration from HIP events recorded on the
-                  launch stream inside the timed region (rqhip_profile_*); peak = 157.3 TFLOP/s dense fp32 MFMA
-                  (`frac_kind` says so: the product scan issues bf16 matrix instructions, `binding_resource` names
-                  what actually limits it).  `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes
-                  (tools/profile_bench.sh), used only when that file carries the sha256 of the librqhip.so loaded here.
-                  `all_fp32_kernel` = the same launch with RQHIP_FWD_SCAN_FP32, timed in this run (untimed region).
-                  `step_frac_of_fp32_peak` prices the WHOLE step (MLP GEMMs included) against the same peak.
+  roofline     -- the dominant kernel FAMILY of the step: the MLP matrix kernels (gemm_f16_kernel / gemm_split_kernel activation GEMMs with
+                  their epilogues + wgrad_split_kernel weight gradients, ~90 % of the step).  `achieved` = ISSUED matrix-instruction TFLOP/s
+                  (three fp16 piece products per fp32 product) over the time of the family's launches, by HIP events recorded on the launch
+                  stream inside the first steps of the timed region (rqhip_profile_*); `peak` = 2 500 TFLOP/s dense fp16; the algorithmic
+                  (fp32-equivalent) figure beside it.  `traffic` = mean HBM bytes per launch over the family, `traffic_ratio` = PMC bytes /
+                  algorithmic bytes (and time-weighted), from separate rocprofv3 --pmc passes matched to launch shapes
+                  (tools/profile_bench.sh, profiles/r0N_pmc_kernels_<cfg>.json), used only when that file carries the sha256 of the
+                  librqhip.so loaded here.
+  roofline_rq  -- the quantisation launch of the step: rq_seam_kernel (128 -> 32 GEMM + all levels + 32 -> 128 GEMM + ReLU in one launch)
+                  where the step takes it, else rq_forward_kernel; algorithmic fp32 FLOPs / launch duration / 157.3 TFLOP/s dense fp32 MFMA.
+                  `all_fp32_kernel` = rq_forward with RQHIP_FWD_SCAN_FP32, timed in this run (untimed region).
   box          -- two fixed library workloads timed after the step (bf16 8192^3 GEMM TFLOP/s, 1 GiB copy GB/s): which kind of box of
                   the pool this line was measured on (the same build spreads 33-38 M items/s across boxes).
   long_run     -- when the K timed steps took less than --min-seconds (default 1 s; the driver's K = 20 is 0.1 s), a
@@ -111,6 +115,8 @@ def parse_args():
     ap.add_argument("--no-seam", action="store_true", help="A/B: the 128 <-> 32 layers either side of the quantiser as in round 5 (library / split GEMMs, "
                                                            "separate maxima and mask passes) instead of the seam kernel (rqhip_rq_seam: fused forward launch, "
                                                            "its GEMMs as the data gradients)")
+    ap.add_argument("--no-trims", action="store_true", help="A/B: without round 6's launch-overhead trims (pooled zero arenas, duplicate statistic on a side "
+                                                            "stream, many-workgroup loss means)")
     ap.add_argument("--lib", default=None, help="developer A/B: another build of librqhip.so (same ABI) instead of the in-tree one")
     ap.add_argument("--no-narrow", action="store_true", help="A/B: layers of 128 (mod 256) columns on the library instead of the split kernel's 128-column tile")
     ap.add_argument("--min-seconds", type=float, default=1.0,
@@ -389,6 +395,7 @@ def main():
     _lin.use_narrow_tiles(not args.no_narrow)
     _lin.use_wide_tiles(args.wide_tiles)
     _lin.use_chain_gemms(not args.no_seam)
+    _lin.use_step_trims(not args.no_trims)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)
     for lo in range(0, B, 250_000):        # generated in host chunks: 1.25 M x 768 fp32 is 3.8 GB
@@ -506,6 +513,13 @@ def main():
     prof_records = ops.profile_read_tagged(n_prof * n_micro * 48 + 64)
     ops.profile_enable(0)
     kernel_ms = [ms for kind, ms, _fl, _by in prof_records if kind == "rq_forward"]   # the scan kernel (`roofline_rq`)
+    # ... or, where RqVae.forward takes the seam node (>= 4096 rows, D = 32 behind a 128-wide hidden layer), the fused launch: the
+    # rq_seam records that carry the levels' FLOPs (the bare-GEMM launches of the backward are the same tag with two GEMMs' FLOPs or fewer)
+    seam_gemm = 2.0 * micro * EMBED * 128
+    seam_recs = [(ms, fl, by) for kind, ms, fl, by in prof_records if kind == "rq_seam" and fl > 2.0 * seam_gemm + 1.0]
+    seam_fused = bool(seam_recs) and not kernel_ms
+    if seam_fused:
+        kernel_ms = [ms for ms, _fl, _by in seam_recs]
 
     def timed(fn):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -603,6 +617,11 @@ def main():
         mean_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = flops_per_row * Bm / (mean_ms * 1e-3) / 1e12 if kernel_ms else float("nan")
         bytes_per_row = 8 * EMBED + 12 * LEVELS + 4                          # fwd: 296 B (c2), 308 B (c4)
+        rq_flops_row = flops_per_row
+        if seam_fused:     # the fused launch: + the two 128 <-> 32 GEMMs; rows of h in, res0 / ids / emb_sum / loss / norms / rows of d out
+            rq_flops_row = flops_per_row + 2 * 2 * EMBED * 128
+            bytes_per_row = 4 * 128 + 4 * EMBED + 8 * LEVELS + 4 * EMBED + 4 + 4 * LEVELS + 4 * 128
+            achieved = rq_flops_row * Bm / (mean_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         from rqhip import _lib as _rqlib
         lib_sha = _sha256_file(os.path.abspath(args.lib) if args.lib else _rqlib.SO_PATH)
@@ -624,7 +643,7 @@ def main():
                                f"{str(pj.get('librqhip_sha256'))[:16]}, this run loaded {lib_sha[:16]}")
             else:
                 pmc_json = pj
-                traffic = pj["rq_forward_kernel"]["hbm_bytes_per_launch_corrected"]
+                traffic = pj.get("rq_forward_kernel", {}).get("hbm_bytes_per_launch_corrected")
                 traffic_src = (os.path.relpath(pmc, ROOT) + " (2*FETCH_SIZE+WRITE_SIZE, bytes/launch; same librqhip.so "
                                f"sha256 {lib_sha[:16]} as this run)")
         f32_mean = float(np.mean(f32_ms)) if f32_ms else float("nan")
@@ -756,7 +775,9 @@ def main():
                        "levels": LEVELS, "codebook_size": CODES, "embed_dim": EMBED,
                        "parallelism": f"row-shard x{world}, 1 flat grad all-reduce per step (RCCL)"},
             "roofline": roofline_family,
-            "roofline_rq": {"kernel": f"rq_forward_kernel<16,STE,filtered> ({LEVELS}x{CODES}, {Bm} rows/launch)", "bound": "mfma",
+            "roofline_rq": {"kernel": (f"rq_seam_kernel<STE> = 128->{EMBED} GEMM + rq_forward's filtered scan ({LEVELS}x{CODES}) + {EMBED}->128 GEMM + ReLU, "
+                                       f"{Bm} rows/launch (csrc/rq_forward.hip)" if seam_fused
+                                       else f"rq_forward_kernel<16,STE,filtered> ({LEVELS}x{CODES}, {Bm} rows/launch)"), "bound": "mfma",
                          "measured": f"HIP events over {n_prof} steps run after the timed region (the timed region's records are the GEMM family's)",
                          "binding_resource": "valu-epilogue: the (best, runner-up, index) tournament on the 16 scores a lane "
                                              "receives per 32 codes -- neither matrix pipe nor HBM limits the kernel; "
@@ -768,7 +789,7 @@ def main():
                                       "bf16 matrix instructions, so values above 1 are possible",
                          "traffic": traffic,
                          "traffic_source": traffic_src, "launch_ms_mean": round(mean_ms, 5),
-                         "launches": len(kernel_ms), "flops_per_row": flops_per_row,
+                         "launches": len(kernel_ms), "flops_per_row": rq_flops_row, "fused_seam": seam_fused,
                          "scan": {"arithmetic": "scores x.c - |c|^2/2 from a 3-term bf16 split of the fp32 operands plus the "
                                                 "exact bf16 pieces of -|c|^2/2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulate); "
                                                 "every row whose two best scores are within the proven error bound "
@@ -820,8 +841,11 @@ def main():
                                   "get_semantic_ids (encoder GEMMs + HIP RQ, eval)"},
             "mlp_gemms": (f"--mlp {args.mlp} (see `arithmetic`); layers of 128 (mod 128) output columns on the split kernels"
                           + (" (128 (mod 256) on the library: --no-narrow)" if args.no_narrow else "")
-                          + "; the 32-wide layers: PyTorch-ROCm fp32 GEMMs (matmul precision highest), TunableOp selections "
-                          + ("loaded" if tuned else "off")),
+                          + ("; the 32-wide layers either side of the quantiser: the seam kernel (rqhip_rq_seam: fused with the levels in the "
+                             "forward, stand-alone with the ReLU backward / maxima epilogues as the data gradients; fp32 FMA chains), their weight "
+                             "gradients fp32-MFMA kernels" if (not args.no_seam and micro >= 4096 and args.mlp != "library") else
+                             "; the 32-wide layers: PyTorch-ROCm fp32 GEMMs (matmul precision highest), TunableOp selections "
+                             + ("loaded" if tuned else "off"))),
             "input_scales": ("the per-row maxima the fp16-split GEMMs scale by come with the resident item matrix (computed once per corpus, "
                              "data/processed.py:ItemData._corpus_maxima; the first layer's weight gradient uses corpus-wide column bounds): no maxima "
                              "pass over the input batch inside the step" if (not args.no_input_scales and args.mlp == "split" and micro >= 4096)

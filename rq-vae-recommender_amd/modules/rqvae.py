@@ -5,8 +5,10 @@ Same constructor, attributes, state_dict keys (`layers.{l}.embedding.weight`, `e
 arithmetic runs: the whole residual-quantisation stack -- every level's distance, argmin, codeword gather,
 STE / rotation-trick output, quantize loss and residual update, plus the emb-sum / emb-norm the loss
 consumes -- is ONE fused HIP kernel (csrc/rq_forward.hip) with a closed-form HIP backward
-(csrc/rq_backward.hip); the O(B^2) duplicate statistic of rqvae.py:159-167 is a hash pass (csrc/ids.hip).
-Encoder/decoder GEMMs and the reconstruction loss stay PyTorch-ROCm.
+(csrc/rq_backward.hip); the O(B^2) duplicate statistic of rqvae.py:159-167 is a hash pass (csrc/ids.hip).  At batches of 4096
+rows and more `forward` runs the encoder's last Linear, every level and the decoder's first Linear + ReLU as ONE launch
+(rqhip_rq_seam: `_seam_weights`, rqhip/autograd.py:RqSeamFunction); the encoder / decoder MLPs around it are
+modules/encoder.py's split-fp16 matrix kernels with the reconstruction loss in the last GEMM's epilogue.
 
 Differences a caller can observe, all deliberate:
   * no `@torch.compile(mode="reduce-overhead")` on forward (rqvae.py:141): the hot path is already a
@@ -231,7 +233,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
                 _lin.attach_scales(d, sc.rows, sc.cols)    # the maxima the decoder's split kernels scale by came with the launch
             RqSeamFunction.last_out_scales = None
             st = _StackResult(None, None, ids, qloss, None, norms)
-            if not torch.cuda.is_current_stream_capturing():
+            if _lin.trims_on() and not torch.cuda.is_current_stream_capturing():
                 # the duplicate statistic (rqvae.py:159-167: a debug output nothing in the step consumes) runs on a SIDE stream under the
                 # decoder's GEMMs: a hash pass of CAS inserts + its fills and scalar kernels, 45 us of latency on the step's stream
                 side = _side_stream(ids.device)

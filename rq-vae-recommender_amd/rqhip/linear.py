@@ -107,13 +107,26 @@ def take_scales() -> Optional[Scales]:
 # slices live on as long as somebody holds them).  Under hipGraph capture a replay would meet non-zero slices: there, plain torch.zeros.
 _ZERO_POOL = {}
 _ZERO_POOL_WORDS = 1 << 16
+_TRIMS = True
+
+
+def use_step_trims(on: bool = True) -> bool:
+    """A/B switch (bench.py --no-trims) for round 6's launch-overhead trims: pooled zero arenas (zeros_i32), the duplicate statistic on a
+    side stream (modules/rqvae.py), the many-workgroup loss means (ops.loss_means).  Returns the previous setting."""
+    global _TRIMS
+    before, _TRIMS = _TRIMS, bool(on)
+    return before
+
+
+def trims_on() -> bool:
+    return _TRIMS
 
 
 def zeros_i32(n: int, device) -> Tensor:
     """A zeroed int32 [n] tensor nobody else holds (a 16-byte aligned slice of the device's pool; see above)."""
     if n <= 0:
         return torch.zeros((0,), dtype=torch.int32, device=device)
-    if n > _ZERO_POOL_WORDS // 4 or torch.cuda.is_current_stream_capturing():
+    if not _TRIMS or n > _ZERO_POOL_WORDS // 4 or torch.cuda.is_current_stream_capturing():
         return torch.zeros((n,), dtype=torch.int32, device=device)
     key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)     # (a pool belongs to the stream its fill ran on)

@@ -590,7 +590,8 @@ def loss_means(recon: Tensor, quant: Tensor) -> Tensor:
     with torch.cuda.device(recon.device):
         out = torch.empty((3,), dtype=torch.float32, device=recon.device)
         l = _lib.lib()
-        if recon.numel() <= 4096:        # one workgroup's worth: the single-workgroup kernel
+        from . import linear as _lin_mod
+        if recon.numel() <= 4096 or not _lin_mod.trims_on():        # one workgroup's worth: the single-workgroup kernel
             check(l.rqhip_loss_means(_ptr(recon), _ptr(quant), recon.numel(), _ptr(out), _stream()), "rqhip_loss_means")
         else:                            # many workgroups; their meeting place is zeroed once per (device, stream) and re-armed by the kernel
             key = (recon.device.index, _stream())

@@ -22,7 +22,9 @@ from conftest import PKG, ROOT
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]   # (spawned ranks import torch again: slow on a cold box)
 
-ROWS, WARM = 2048, 2048
+# (RQ_TEST_ROWS: the second test re-runs the workers at a batch that takes the seam node -- modules/rqvae.py: >= 4096 rows per rank)
+ROWS = int(os.environ.get("RQ_TEST_ROWS", "2048"))
+WARM = 2048
 
 
 def _free_port():
@@ -221,8 +223,23 @@ def test_two_ranks_on_one_gpu_product_step_and_sharded_kmeans():
     print("two ranks on one GPU vs single process:", res)
     assert res["gerr"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9, res       # reduced gradients == full-batch gradients
     assert res["perr"] <= 1e-5, res                                           # parameters after AdamW
-    assert res["gerr4"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9 and res["perr4"] <= 1e-5, res   # the accumulation step
+    # the accumulation step.  (At the seam-sized batch its micro-batches fall BELOW 4096 rows: they run the small-batch kernel family --
+    # library GEMMs, three-piece bf16 job-table weight gradients -- against a full-batch reference on the split-fp16 family; both are
+    # fp32-accurate to 1e-8 absolute on gradients of scale 6e-6, but the FIRST AdamW step moves every parameter by lr * g / (|g| + eps): a
+    # gradient entry of 1e-8 that differs by 1e-8 moves its parameter by half of lr -- the parameters are compared only where both arms run
+    # the same kernel family.)
+    loose = int(os.environ.get("RQ_TEST_ROWS", "2048")) >= 8192
+    assert res["gerr4"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9 and (loose or res["perr4"] <= 1e-5), res
     assert res["ids_differ"] <= 1 and res["dedup_equal"], res                 # sharded tokenisation (a near-tie may flip: tests/parity_gate.py)
+
+
+def test_two_ranks_at_a_batch_that_takes_the_seam_node(monkeypatch):
+    """The same two-rank step at 5120 rows per rank: RqVae.forward then runs the encoder tail / levels / decoder head as ONE node
+    (rqhip/autograd.py:RqSeamFunction) and the early all-reduce hangs on the gradient of the hidden activation in front of it -- the
+    decoder's, the codebooks' and the seam's own decoder-side weight gradient must be final when it starts (also in the accumulation
+    form, where they reach the flat buffer through autograd's accumulation, not in place)."""
+    monkeypatch.setenv("RQ_TEST_ROWS", "10240")
+    test_two_ranks_on_one_gpu_product_step_and_sharded_kmeans()
 
 
 def _graph_worker(port, tmp):

@@ -31,7 +31,7 @@ done
 for f in $(find "$OUT/stats" -name "*kernel_trace.csv"); do
     python - "$f" "$OUT/rq_forward_dispatches.json" <<'PY'
 import csv, json, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rq_forward_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rq_forward_kernel" in r["Kernel_Name"] or "rq_seam_kernel<1>" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [{"kernel": r["Kernel_Name"][:80], "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
       "start_us": int(r["Start_Timestamp"]) / 1e3, "grid": int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)} for r in rows]

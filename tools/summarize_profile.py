@@ -121,14 +121,17 @@ for k, v in sorted(shape_bytes.items(), key=lambda kv: -kv[1]):
     kind, fl, by = k.split(":")
     print(f"  {kind:12s} {float(fl) / 1e9:8.2f} GFLOP  algorithmic {float(by) / 1e6:8.1f} MB  PMC {v / 1e6:8.1f} MB  ratio {v / float(by):.3f}")
 
-fwk = [k for k in pmc["kernels"] if "rq_forward_kernel" in k and "FETCH_SIZE_KB_max" in pmc["kernels"][k]
-       and "WRITE_SIZE_KB_max" in pmc["kernels"][k]]
+# the training step's quantisation launch: the fused seam kernel where the step takes it (rq_seam_kernel<1> / <2>: the modes with levels
+# behind a GEMM; <0> also carries the bare-GEMM launches of the backward), else the forward kernel with the most launches
+_have = lambda k: "FETCH_SIZE_KB_max" in pmc["kernels"][k] and "WRITE_SIZE_KB_max" in pmc["kernels"][k]   # noqa: E731
+fwk = [k for k in pmc["kernels"] if ("rq_seam_kernel<1>" in k or "rq_seam_kernel<2>" in k) and _have(k)] if bench.get("roofline_rq", {}).get("fused_seam") else []
+fwk = fwk or [k for k in pmc["kernels"] if "rq_forward_kernel" in k and _have(k)]
 if fwk:
     v = pmc["kernels"][fwk[0]]
     rows = bench["config"]["micro_batch_rows"]
     corrected = (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024.0
     algorithmic = bench["roofline_rq"]["hbm_view"]["algorithmic_bytes_per_row"] * rows
-    pmc["rq_forward_kernel"] = {"rows_per_launch": rows, "hbm_bytes_per_launch_corrected": corrected,
+    pmc["rq_forward_kernel"] = {"kernel": fwk[0][:60], "rows_per_launch": rows, "hbm_bytes_per_launch_corrected": corrected,
                                 "algorithmic_bytes_per_launch": algorithmic, "ratio": corrected / algorithmic}
 with open(os.path.join(DST, f"{TAG}_pmc_traffic_{cfg_name}.json"), "w") as f:
     json.dump(pmc, f, indent=1)
@@ -160,7 +163,7 @@ if os.path.exists(disp):
         json.dump(out, f, indent=1)
         f.write("\n")
     print("forward kernel dispatches:", json.dumps(out))
-fw = [k for k in pmc["kernels"] if "rq_forward_kernel" in k]
+fw = [k for k in pmc["kernels"] if "rq_forward_kernel" in k or "rq_seam_kernel" in k]
 for k in fw:
     v = pmc["kernels"][k]
     print(k, "-> traffic per launch (2*FETCH+WRITE) =", (2 * v["FETCH_SIZE_KB_max"] + v["WRITE_SIZE_KB_max"]) * 1024 / 1e6, "MB")
