@@ -253,3 +253,27 @@ def test_torch_port_cpu_baseline_program_matches_reference(name):
     for l, c in enumerate(m.codebooks):
         np.testing.assert_allclose(c.grad.numpy(), g[f"train_grad::layers.{l}.embedding.weight"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(m.enc[0].grad.numpy(), g["train_grad::" + enc[0][len("param::"):]], rtol=1e-4, atol=1e-7)
+
+
+def test_linear_chain_orientation_masks_and_epilogues_on_exact_inputs():
+    """rqo_linear_chain (the seam kernel's GEMMs): on small-integer operands every partial sum is exact, so the FMA chain must equal the
+    integer matrix product -- for both weight orientations, with the ReLU backward on load (xmask) and the three epilogues; on real-valued
+    operands it stays within fp32 accumulation error of the fp64 product."""
+    from oracle import rq_oracle as o
+    rng = np.random.default_rng(7)
+    x = rng.integers(-8, 9, size=(37, 128)).astype(np.float32)
+    w = rng.integers(-8, 9, size=(32, 128)).astype(np.float32)
+    want = (x.astype(np.int64) @ w.astype(np.int64).T).astype(np.float32)
+    assert np.array_equal(o.linear_chain(x, w), want)
+    assert np.array_equal(o.linear_chain(x, np.ascontiguousarray(w.T), transposed=True), want)
+    assert np.array_equal(o.linear_chain(x, w, epilogue=1), np.maximum(want, 0.0))
+    xm = rng.standard_normal((37, 128)).astype(np.float32)
+    xm[0, :5] = 0.0                                             # a mask value of exactly 0 drops the entry (threshold_backward: mask <= 0)
+    masked = np.where(xm > 0, x, 0.0).astype(np.float32)
+    assert np.array_equal(o.linear_chain(x, w, xmask=xm), (masked.astype(np.int64) @ w.astype(np.int64).T).astype(np.float32))
+    om = rng.standard_normal((37, 32)).astype(np.float32)
+    assert np.array_equal(o.linear_chain(x, w, epilogue=3, omask=om), np.where(om > 0, want, 0.0).astype(np.float32))
+    xr, wr = rng.standard_normal((64, 128)).astype(np.float32), (rng.standard_normal((32, 128)) / 11.3).astype(np.float32)
+    ref = xr.astype(np.float64) @ wr.astype(np.float64).T
+    bound = 129 * 2.0 ** -24 * (np.abs(xr).astype(np.float64) @ np.abs(wr).astype(np.float64).T)
+    assert (np.abs(o.linear_chain(xr, wr).astype(np.float64) - ref) <= bound).all()
