@@ -434,7 +434,7 @@ def main():
         out = step()
     # the timed region records the kernels that ARE the step -- the MLP GEMM / weight-gradient family -- in its FIRST n_rec steps only:
     # ~21 event pairs per step cost 5 % of a 2.8 ms step (K-step 2.90 ms vs 2.76 ms unrecorded, profiles/r05_bench_n1.json's long_run)
-    n_rec = min(steps, 4)
+    n_rec = min(steps, 4 if steps >= 100 else 2)     # (short regions -- the driver's K = 20 -- record two steps: the pairs are 1 % of such a region)
     n_fam = n_rec * n_micro * 26 + 64
     ops.profile_enable(n_fam)
     ops.profile_select("gemm_split", "wgrad")

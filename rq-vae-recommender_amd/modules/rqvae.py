@@ -226,12 +226,10 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
                 # (rqhip/dist.py:FlatGradReducer.boundary_hook; a no-op with one rank or an unarmed step).  The encoder's last weight,
                 # whose gradient the seam node forms, is an encoder parameter: it travels with the late part.
                 hidden.register_hook(reducer.boundary_hook)
-            ids, qloss, norms, d = RqSeamFunction.apply(hidden, seam[0], codebooks, seam[1], self.layers[0].hip_mode(),
-                                                        float(self.commitment_weight), sink, want_scales)
-            if want_scales and RqSeamFunction.last_out_scales is not None:
-                sc = RqSeamFunction.last_out_scales
-                _lin.attach_scales(d, sc.rows, sc.cols)    # the maxima the decoder's split kernels scale by came with the launch
-            RqSeamFunction.last_out_scales = None
+            ids, qloss, norms, d, d_rows, d_cols = RqSeamFunction.apply(hidden, seam[0], codebooks, seam[1], self.layers[0].hip_mode(),
+                                                                        float(self.commitment_weight), sink, want_scales)
+            if want_scales:
+                _lin.attach_scales(d, d_rows, d_cols)      # the maxima the decoder's split kernels scale by came with the launch
             st = _StackResult(None, None, ids, qloss, None, norms)
             if _lin.trims_on() and not torch.cuda.is_current_stream_capturing():
                 # the duplicate statistic (rqvae.py:159-167: a debug output nothing in the step consumes) runs on a SIDE stream under the

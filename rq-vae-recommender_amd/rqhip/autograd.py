@@ -74,7 +74,8 @@ class RqSeamFunction(torch.autograd.Function):
     last encoder Linear of modules/encoder.py:25-38 in front and the first decoder Linear + ReLU behind):
 
         forward(h [B,128], w_in [32,128], codebooks [L,K,32], w_out [128,32], mode, beta, grad_sink, want_scales)
-            -> ids [L,B], loss [B], embs_norm [B,L], d [B,128] = relu((sum of the levels' outputs) w_out^T)
+            -> ids [L,B], loss [B], embs_norm [B,L], d [B,128] = relu((sum of the levels' outputs) w_out^T),
+               row maxima [4,B] and column maxima [128] of d (int32 bit patterns; empty without want_scales)
 
     res0 = h w_in^T and the sum of the levels' outputs stay inside (saved for the backward).  Backward, composed of the same kernels:
     the decoder-side data gradient with the ReLU backward applied on load, the quantiser's closed-form backward (csrc/rq_backward.hip),
@@ -95,15 +96,14 @@ class RqSeamFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(h, w_in, codebooks, w_out, r.res0, r.ids, r.emb_sum, r.out)
         ctx.mode, ctx.beta, ctx.grad_sink, ctx.want_scales = mode, beta, grad_sink, want_scales
-        ctx.mark_non_differentiable(r.ids, r.embs_norm)
-        ctx.out_scales = _lin.Scales(r.out_row_max, cols) if want_scales else None
-        RqSeamFunction.last_out_scales = ctx.out_scales      # (picked up by the caller right after apply: modules/rqvae.py)
-        return r.ids, r.loss, r.embs_norm, r.out
-
-    last_out_scales = None
+        # the maxima of d the decoder's split kernels scale by travel as two more (non-differentiable) outputs; empty when not wanted
+        rmax = r.out_row_max if want_scales else h.new_empty((0,), dtype=torch.int32)
+        cmax = cols if want_scales else h.new_empty((0,), dtype=torch.int32)
+        ctx.mark_non_differentiable(r.ids, r.embs_norm, rmax, cmax)
+        return r.ids, r.loss, r.embs_norm, r.out, rmax, cmax
 
     @staticmethod
-    def backward(ctx, _g_ids, g_loss, _g_norm, g_d):
+    def backward(ctx, _g_ids, g_loss, _g_norm, g_d, _g_rmax=None, _g_cmax=None):
         from . import linear as _lin
         from .dist import claim_grad_sink
         h, w_in, codebooks, w_out, res0, ids, emb_sum, d = ctx.saved_tensors
