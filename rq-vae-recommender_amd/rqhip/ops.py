@@ -591,10 +591,12 @@ def loss_means(recon: Tensor, quant: Tensor) -> Tensor:
         out = torch.empty((3,), dtype=torch.float32, device=recon.device)
         l = _lib.lib()
         from . import linear as _lin_mod
-        if recon.numel() <= 4096 or not _lin_mod.trims_on():        # one workgroup's worth: the single-workgroup kernel
+        key = (recon.device.index, _stream())
+        # (the meeting place must have been zeroed by an EXECUTED fill: a first use under hipGraph capture takes the one-workgroup kernel)
+        fresh_in_capture = key not in _LOSS_MEANS_WS and torch.cuda.is_current_stream_capturing()
+        if recon.numel() <= 4096 or not _lin_mod.trims_on() or fresh_in_capture:        # one workgroup's worth: the single-workgroup kernel
             check(l.rqhip_loss_means(_ptr(recon), _ptr(quant), recon.numel(), _ptr(out), _stream()), "rqhip_loss_means")
         else:                            # many workgroups; their meeting place is zeroed once per (device, stream) and re-armed by the kernel
-            key = (recon.device.index, _stream())
             ws = _LOSS_MEANS_WS.get(key)
             if ws is None:
                 ws = _LOSS_MEANS_WS[key] = torch.zeros((l.rqhip_loss_means_workspace_bytes(),), dtype=torch.uint8, device=recon.device)
