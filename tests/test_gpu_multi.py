@@ -23,8 +23,8 @@ import torch
 from conftest import PKG, ROOT
 
 N_GPUS = torch.cuda.device_count() if torch.cuda.is_available() else 0
-pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900),
-              pytest.mark.skipif(N_GPUS < 2, reason=f"needs >= 2 GPUs for RCCL peers (this box has {N_GPUS})")]
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+needs_peers = pytest.mark.skipif(N_GPUS < 2, reason=f"needs >= 2 GPUs for RCCL peers (this box has {N_GPUS})")
 
 ROWS = 4096        # rows of the global batch: 2048 per rank
 
@@ -37,6 +37,7 @@ def _clean_env():
     return env
 
 
+@needs_peers
 def test_bench_two_gpus_line():
     """(i) The driver's SCALE command at N = 2 (`python bench.py --gpus 2` relaunches itself under torch.distributed.run)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "16384",
@@ -100,7 +101,7 @@ def _worker_body(rank, world, tmp):
     rparams = torch.cat([p.detach().flatten() for p in ref.parameters()])
 
     # ---- RCCL, one rank per GPU ----------------------------------------------------------------------------------------------------
-    r, dev, w = rqdist.init_from_env("cuda")
+    r, dev, w = rqdist.init_from_env("cuda", force=world == 1)      # (world 1: the rehearsal below; a group of one is still RCCL)
     assert (r, dev, w) == (rank, rank, world) and dist.get_backend() == "nccl" and rqdist.world_size() == world
 
     # (iv) row-sharded Lloyd iterations over RCCL == the plain run; identical on every rank
@@ -166,8 +167,7 @@ def _worker_body(rank, world, tmp):
                    os.path.join(tmp, "out.pt"))
 
 
-def test_two_rccl_ranks_step_graph_and_kmeans():
-    """(ii) + (iii) + (iv) in one pair of processes (one process group, one import of torch per rank)."""
+def _run_ranks(world):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -175,7 +175,7 @@ def test_two_rccl_ranks_step_graph_and_kmeans():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as tmp:
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, tmp)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -185,7 +185,23 @@ def test_two_rccl_ranks_step_graph_and_kmeans():
                 p.kill()
         errs = [open(os.path.join(tmp, f)).read() for f in sorted(os.listdir(tmp)) if f.startswith("error_")]
         assert all(p.exitcode == 0 for p in procs), ([p.exitcode for p in procs], errs)
-        res = torch.load(os.path.join(tmp, "out.pt"))
+        return torch.load(os.path.join(tmp, "out.pt"))
+
+
+def test_the_rccl_worker_with_a_group_of_one():
+    """Rehearsal on a one-GPU box: the very worker the two-GPU test spawns, as ONE rank with an RCCL process group of one -- every line
+    of it runs (references, sharded k-means, the step, the captured step with its all-reduces inside the graph), only the peers are
+    missing; with one rank the "sharded" results must equal the single-rank references to the same tolerances."""
+    res = _run_ranks(1)
+    print("one RCCL rank vs no process group:", res)
+    assert res["km_err"] <= 1e-5 and res["gerr"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9 and res["perr"] <= 1e-5, res
+    assert res["eager"] == res["eager"] and abs(res["eager"] - res["graph"]) <= 2e-3 * max(1.0, abs(res["eager"])), res
+
+
+@needs_peers
+def test_two_rccl_ranks_step_graph_and_kmeans():
+    """(ii) + (iii) + (iv) in one pair of processes (one process group, one import of torch per rank)."""
+    res = _run_ranks(2)
     print("two RCCL ranks vs single rank:", res)
     assert res["km_err"] <= 1e-5, res                                           # (iv)
     assert res["gerr"] <= 1e-5 * max(res["gscale"], 1e-3) + 1e-9, res         # (ii) reduced gradients == full-batch gradients
