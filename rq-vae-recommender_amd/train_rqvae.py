@@ -21,9 +21,11 @@ What is MI355X-native about it:
     modules/rqvae.py:141) -- the whole step (forward, HIP quantisation kernels, backward, all-reduce, fused AdamW) is captured into a
     hipGraph and replayed on full-size batches BY DEFAULT when the batch is below 4096 rows and there is no gradient accumulation
     (`use_hip_graph=None`, the signature's default: auto; `True` / `False` force it; configs/*_graph.gin bind True explicitly):
-    1.24 -> 0.35 ms per step at batch 640 on MI355X (tools/bench_small_batch.py, `secondary.small_batch` of the bench line).  The training schedule is the reference's either way: the short batch that ends an
-    epoch (drop_last=False, train_rqvae.py:82-88) is trained on eagerly, and the graph is re-captured after every eager
-    excursion (epoch tail, eval, tokenisation, checkpoint).
+    1.24 -> 0.35 ms per step at batch 640 on MI355X (tools/bench_small_batch.py, `secondary.small_batch` of the bench line).  The training
+    schedule is the reference's either way: the short batch that ends an epoch (drop_last=False, train_rqvae.py:82-88) has a constant
+    size, so it is a SECOND captured shape replayed from its own graph (round 6; `graph_epoch_tail=False` = round 5's form: tail
+    eager + one re-capture per epoch -- 1194 vs 3258 iterations/s on the reference's 12 101-item corpus, profiles/r06_epoch_tail_ab.txt);
+    both graphs are re-captured (together, all warm-ups first) only after an eval / tokenisation / checkpoint excursion.
 wandb is optional (not installed here): with `wandb_logging=True` and no wandb module, metrics are printed.
 """
 import os
@@ -121,19 +123,18 @@ class _GraphedStep:
         self._opt.step()
         return out
 
-    def capture(self, x: torch.Tensor) -> None:
-        """Capture one step on the current batch.  The two warm-up steps graph capture needs run on that batch too, and
-        their optimizer updates are rolled back (parameters and optimizer state are snapshotted and restored), so a
-        capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
+    def warm_up(self, x: torch.Tensor) -> None:
+        """The two warm-up steps graph capture needs, on batch `x`; their optimizer updates are rolled back (parameters and optimizer state
+        are snapshotted and restored), so a capture -- the first one or a re-capture after an eager excursion -- does not advance training."""
         import copy
         if not self._opt.state:
             raise RuntimeError("_GraphedStep.capture: run a few eager steps first -- the optimizer creates its state lazily in its "
                                "first step, and a creation recorded into the graph would reset the moments at every replay")
         self.x.copy_(x)
         self.captures += 1
-        if self.captures in (2, 10, 100, 1000):     # every eager excursion (a short epoch-tail batch, eval, checkpoint) costs one
-            print(f"use_hip_graph: capture #{self.captures} (two rolled-back warm-up steps + a capture each); with few full batches "
-                  "per epoch this can cost more than the graph saves", flush=True)
+        if self.captures in (10, 100, 1000):     # (every eval pass / corpus tokenisation / checkpoint costs one)
+            print(f"use_hip_graph: capture #{self.captures} of the {self.batch_size}-row step (two rolled-back warm-up steps + a capture each)",
+                  flush=True)
         params = [p.detach().clone() for p in self._model.parameters()]
         opt_state = copy.deepcopy(self._opt.state_dict())
         # the warm-up steps must not advance any random stream either (Gumbel noise, dropout): an eager run and a graphed run
@@ -153,14 +154,22 @@ class _GraphedStep:
             self._opt.load_state_dict(opt_state)
             torch.set_rng_state(rng_cpu)
             torch.cuda.set_rng_state(rng_dev)
+
+    def capture_only(self) -> None:
+        """Record one step on the static batch (nothing executes); `warm_up` must have run since the last eager work."""
         self._reducer.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             out = self._step()
         # keep the static output buffers but not the captured step's autograd graph: its AccumulateGrad nodes are
-        # bound to the capture stream and would poison any later eager step (epoch-tail batches)
+        # bound to the capture stream and would poison any later eager step
         self.out = type(out)(*[v.detach() for v in out])
         del out
+
+    def capture(self, x: torch.Tensor) -> None:
+        """warm_up + capture_only for one step shape."""
+        self.warm_up(x)
+        self.capture_only()
 
     def run(self, x: torch.Tensor):
         self.x.copy_(x)
@@ -176,22 +185,24 @@ class _GraphedStep:
         self.out = None
 
 
-_AUTO_GRAPH_MIN_FULL_BATCHES = 8      # `use_hip_graph=None`: fewer full batches per epoch than this train eagerly
-
-
-def _capture_or_eager(graphed: "_GraphedStep", x: torch.Tensor, world: int):
-    """The first capture (and every re-capture) of the graphed step, or None: a model variant that cannot be captured -- a quantiser
-    shape on the torch-operator path with a host synchronisation, a library that allocates inside the step -- trains eagerly with a
-    message instead of ending the run (it did train eagerly before hipGraph replay became the default).  The rolled-back warm-up
-    steps of `capture` restore parameters, optimizer state and random streams before the capture proper, and a failed capture leaves
-    nothing half-applied: `torch.cuda.graph` ends the capture on the way out.  With several ranks the outcome is agreed on (a rank
-    that fell back while the others replay would issue a different sequence of collectives)."""
+def _capture_or_eager(graphs: dict, batches: dict, world: int) -> dict:
+    """Capture every step shape of `graphs` ({rows: _GraphedStep}; `batches`: {rows: a batch of that many rows}) -- the full batch and,
+    when an epoch ends in a short batch, that size too -- or return {}: a model variant that cannot be captured (a quantiser shape on the
+    torch-operator path with a host synchronisation, a library that allocates inside the step) trains eagerly with a message instead of
+    ending the run.  ALL warm-up steps (eager launches, rolled back) run before the FIRST capture: eager work between a capture and its
+    replays is what made replays fault on ROCm 7.0 (library workspaces move), and the warm-up of one shape is eager work for the other.
+    With several ranks the outcome is agreed on (a rank that fell back while the others replay would issue another sequence of
+    collectives)."""
     ok = True
     try:
-        graphed.capture(x)
+        for rows, g in graphs.items():
+            g.warm_up(batches[rows])
+        for g in graphs.values():
+            g.capture_only()
     except Exception as e:  # noqa: BLE001
         ok = False
-        graphed.invalidate()
+        for g in graphs.values():
+            g.invalidate()
         print(f"use_hip_graph: capturing the training step failed ({type(e).__name__}: {str(e)[:200]}); falling back to the eager step",
               flush=True)
     if world > 1:
@@ -199,7 +210,7 @@ def _capture_or_eager(graphed: "_GraphedStep", x: torch.Tensor, world: int):
         flags = [None] * world
         _dist.all_gather_object(flags, ok)
         ok = all(flags)
-    return graphed if ok else None
+    return graphs if ok else {}
 
 
 @gin.configurable
@@ -236,6 +247,7 @@ def train(
     log_every=100,
     use_hip_graph=None,
     mlp_arith=None,
+    graph_epoch_tail=True,
 ):
     params = dict(locals())
     del split_batches  # every rank always draws its own full batch (reference behaviour with a bare dataloader)
@@ -307,7 +319,6 @@ def train(
     tokenizer.rq_vae = model
 
     t = 0.2  # the reference's constant gumbel temperature (train_rqvae.py:177)
-    graphed = None
     if world > 1:
         # A replayed step issues another sequence of collectives than an eager one (early + late runs vs one whole-buffer all-reduce), so
         # every rank must take the same branch on the same iterations.  That follows from identical batchers -- the same number of rows and
@@ -320,14 +331,18 @@ def train(
             if rank == 0 and any(g for *_x, g in seen):
                 print(f"use_hip_graph: ranks disagree on (rows, batch_size, accumulate, graph) = {seen}; every rank takes the eager step")
             graphable = False
-    if graphable and use_hip_graph is None and len(train_dataset) // max(batch_size, 1) < _AUTO_GRAPH_MIN_FULL_BATCHES:
-        # auto mode: every epoch tail (a short batch, eager) costs a re-capture -- two rolled-back warm-up steps, a snapshot of the
-        # optimizer state and the capture; with only a handful of full batches between two of them the graph cannot pay that back
-        graphable = False
+    # The step shapes of the run: full batches and, when the corpus is not a multiple of the batch size, the short batch that ends every
+    # epoch (always the same size: train_rqvae.py:82-89's BatchSampler(drop_last=False)).  BOTH are captured and replayed (round 6), so an
+    # epoch has no eager step and no re-capture: round 5 trained the tail eagerly and re-captured after it -- two rolled-back warm-up
+    # steps, a snapshot of the optimizer state and a capture per epoch, more than the 18 replays of an Amazon-Beauty epoch cost together.
+    graphs = {}
     if graphable:
-        # several ranks: the RCCL all-reduces of FlatGradReducer are captured with the step (one graph per rank, replayed in
-        # lockstep: every rank runs the same sequence of full batches; the short batch that ends an epoch is eager on all of them)
-        graphed = _GraphedStep(model, optimizer, reducer, batch_size, vae_input_dim, device, t)
+        n_rows = len(train_dataset)
+        # (graph_epoch_tail=False: round 5's form -- only full batches replayed, the tail eager and a re-capture behind it; A/B)
+        sizes = [s for s in ((batch_size, n_rows % batch_size) if graph_epoch_tail or n_rows < batch_size else (batch_size,)) if 0 < s <= n_rows]
+        graphs = {s: _GraphedStep(model, optimizer, reducer, s, vae_input_dim, device, t) for s in dict.fromkeys(sizes)}
+        # several ranks: the RCCL all-reduces of FlatGradReducer are captured with the step (one graph per rank and shape, replayed in
+        # lockstep: every rank runs the same sequence of batch sizes)
     graph_after = start_iter + 3  # a few eager steps first (k-means init, allocator warm-up)
     window: List[torch.Tensor] = []
     shown = (float("nan"),) * 3
@@ -350,17 +365,15 @@ def train(
                     layer.kmeans_rows_sharded = False
 
         data = next(train_batches) if gradient_accumulate_every == 1 else None
-        if graphed is not None and it >= graph_after:
-            if len(train_dataset) < batch_size:
-                # no full batch exists: the graphed step (static batch shape) cannot be used -- train eagerly
-                print(f"use_hip_graph: the training split has {len(train_dataset)} rows < batch_size {batch_size}; "
-                      "falling back to the eager step")
-                graphed = None
-        if graphed is not None and it >= graph_after and data.x.shape[0] == batch_size:
-            if graphed.graph is None:
-                graphed = _capture_or_eager(graphed, data.x, world)
-        if graphed is not None and graphed.graph is not None and it >= graph_after and data.x.shape[0] == batch_size:
-            model_output = graphed.run(data.x)
+        g_step = graphs.get(data.x.shape[0]) if (graphs and it >= graph_after and data is not None) else None
+        if g_step is not None and g_step.graph is None:
+            # (re-)capture every shape at once; a shape whose batch is not at hand warms up on the first rows of the corpus -- the
+            # warm-up steps are rolled back and a capture executes nothing, so which rows they see does not matter
+            at_hand = {rows: (data.x if rows == data.x.shape[0] else train_dataset[torch.arange(rows)].x) for rows in graphs}
+            graphs = _capture_or_eager(graphs, at_hand, world)
+            g_step = graphs.get(data.x.shape[0])
+        if g_step is not None and g_step.graph is not None:
+            model_output = g_step.run(data.x)
             total_loss = model_output.loss.detach()
         else:
             reducer.zero_()
@@ -381,8 +394,8 @@ def train(
                 data = None
             reducer.allreduce_mean()
             optimizer.step()
-            if graphed is not None and graphed.graph is not None:
-                graphed.invalidate()   # an eager step (the short batch that ends an epoch) ran between two replays
+            for g_any in graphs.values():
+                g_any.invalidate()     # an eager step ran between two replays (only the first iterations and accumulation steps are)
 
         window.append(torch.stack([total_loss, model_output.reconstruction_loss.detach(),
                                    model_output.rqvae_loss.detach()]))  # stack copies: safe with graph-static outputs
@@ -426,9 +439,10 @@ def train(
                 state["data"] = "synthetic"   # extra key: a checkpoint trained on noise says so
             torch.save(state, save_dir_root + f"checkpoint_{it}.pt")
 
-        if graphed is not None and ((do_eval and ((it + 1) % eval_every == 0 or last)) or (it + 1) % eval_every == 0
-                                    or last or (it + 1) % save_model_every == 0):
-            graphed.invalidate()
+        if graphs and ((do_eval and ((it + 1) % eval_every == 0 or last)) or (it + 1) % eval_every == 0
+                       or last or (it + 1) % save_model_every == 0):
+            for g_any in graphs.values():
+                g_any.invalidate()
 
         if is_main and log:
             if use_wandb:
@@ -439,7 +453,8 @@ def train(
     if use_wandb:
         wandb.finish()
     rqdist.barrier()
-    return {"loss": shown[0], "reconstruction_loss": shown[1], "rqvae_loss": shown[2]}
+    return {"loss": shown[0], "reconstruction_loss": shown[1], "rqvae_loss": shown[2],
+            "graph_captures": {rows: g.captures for rows, g in graphs.items()}}
 
 
 if __name__ == "__main__":

@@ -60,8 +60,9 @@ def test_train_ml32m_hyperparameters_rotation_trick(tmp_path, monkeypatch):
 
 
 def test_hip_graph_step_matches_eager(tmp_path, monkeypatch):
-    """use_hip_graph=True (also the default below 4096 rows: `None` = auto) replays the captured step, re-capturing after eval / tokenisation / checkpoint
-    excursions; the loss stays on the eager trajectory (graph mode skips epoch-tail batches, so not bit-equal)."""
+    """use_hip_graph=True (also the default below 4096 rows: `None` = auto) replays the captured steps (full batch and epoch-tail batch, one
+    graph each) across eval / tokenisation / checkpoint excursions; the loss stays on the eager trajectory (replayed kernels run in the order of the
+    capture's streams, loss means through the single-launch form: close, not bit-equal)."""
     import numpy as np
     runs = []
     for flag in (False, True):
@@ -84,3 +85,23 @@ def test_hip_graph_survives_hundreds_of_replays_interleaved_with_eager_work(tmp_
     res, _ = _run("rqvae_ml32m.gin", tmp_path, monkeypatch, iterations=600, eval_every=600, save_model_every=10 ** 6,
                   log_every=200, use_hip_graph=True)
     assert res["loss"] == res["loss"] and res["loss"] < 5.0
+
+
+def test_both_step_shapes_of_an_epoch_are_replayed_and_captured_once(tmp_path, monkeypatch):
+    """3000 synthetic items, 95 % of them in the training split = 2850 rows at batch 500: five full batches and one of 350 rows per epoch.
+    Round 6 captures BOTH shapes (all warm-up steps before the first capture) and replays them: 60 iterations = 10 epochs with no eval /
+    checkpoint excursion in between must cost exactly one capture per shape (round 5: one re-capture per epoch), and stay on the eager
+    trajectory."""
+    import numpy as np
+    runs = []
+    for flag in (False, True):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        res, _ = _run("rqvae_amazon.gin", tmp_path, monkeypatch, iterations=60, eval_every=10 ** 6, save_model_every=10 ** 6,
+                      do_eval=True, log_every=1, use_hip_graph=flag, batch_size=500)
+        runs.append(res)
+    assert runs[0]["graph_captures"] == {}
+    caps = runs[1]["graph_captures"]
+    # (two each: the first capture, and one behind the eval / tokenisation pass that precedes the run's final step)
+    assert len(caps) == 2 and 500 in caps and all(v == 2 for v in caps.values()), caps
+    assert abs(runs[0]["loss"] - runs[1]["loss"]) < 2e-3 * max(1.0, abs(runs[0]["loss"])), runs

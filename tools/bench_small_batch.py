@@ -111,6 +111,12 @@ if JSON:
     log = lambda *a: print(*a, file=sys.stderr)   # noqa: E731
     out["batch640_amazon"] = run(False, 640, log)
     out["batch64_ml32m"] = run(True, 64, log)
+    try:     # the gin-driven training LOOP at the reference's corpus size: both step shapes of an epoch replayed vs round 5's form vs eager
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import epoch_tail_ab
+        out["train_loop_amazon"] = epoch_tail_ab.measure(1500, log)
+    except Exception as e:  # noqa: BLE001
+        out["train_loop_amazon"] = {"error": repr(e)[:300]}
     real_stdout.write(json.dumps(out) + "\n")
     real_stdout.flush()
 else:
