@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 450 /* 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 460 /* 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -478,6 +478,22 @@ int rqhip_rq_seam_supported(int D, int H, int L, int K);   /* 1 when rqhip_rq_se
 int rqhip_rq_seam(const rqhip_seam_args *args, rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The encoder / decoder Linear layers at the batch sizes the reference ships (M < 4096 rows: configs/rqvae_amazon.gin:7 batch 640,
+ * rqvae_ml32m.gin:7 batch 64) -- reference modules/encoder.py:25-38 (`relu(x W^T)`) and its autograd data gradient `g W` with the ReLU
+ * backward of the layer below.  out [M, N] = epilogue(a [M, Kr] . B), B = w^T for w [N, Kr] (w_kn = 0: the forward, nn.Linear.weight
+ * as stored) or B = w for w [Kr, N] (w_kn = 1: the data gradient, the same nn.Linear.weight).  N, Kr multiples of 32; a, w, out, aux
+ * 16-byte aligned, contiguous.  epilogue: RQHIP_EPI_STORE / RQHIP_EPI_RELU / RQHIP_EPI_MASK (out where aux [M, N] > 0, else 0).
+ * Arithmetic: exact fp32 on the fp32 matrix instruction.  The reduction runs as `waves` contiguous ranges of 32-term groups (wave v:
+ * groups [v ng / waves, (v + 1) ng / waves), ng = Kr / 32), each ONE fp32 FMA chain from +0 taking a group's terms in the order
+ * 0 8 16 24 1 9 17 25 ... 7 15 23 31; out = ((p_0 + p_1) + ...) + p_{waves-1}, then the epilogue.  (col_blocks, waves) = (0, 0): chosen from the shape
+ * (rqhip_linear_small_plan reports the choice: the same bits on every box, eager or replayed); restated by
+ * oracle/rq_oracle.c:rqo_linear_small.  Valid overrides: col_blocks 1 | 2 (N % 64 == 0), waves 4 | 8 | 16 (16: col_blocks 1). */
+int rqhip_linear_small_supported(int64_t M, int N, int Kr);
+int rqhip_linear_small_plan(int64_t M, int N, int Kr, int *col_blocks, int *waves);
+int rqhip_linear_small(const float *a, const float *w, int w_kn, float *out, int64_t M, int N, int Kr, int epilogue, const float *aux,
+                       int col_blocks, int waves, rqhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The AdamW update of all parameters in one launch (reference train_rqvae.py:136-138: AdamW with decoupled weight decay on every
  * parameter, codebooks included).  Arithmetic of torch's `_fused_adamw_` in fp32 (no amsgrad, no maximize); tensors p / g / m / v of
  * numel[i] contiguous fp32 elements, 16-byte aligned, caller-owned; `step`: device float scalar = steps taken so far, incremented by
@@ -500,6 +516,7 @@ int rqhip_adamw_step(float *const *p, const float *const *g, float *const *m, fl
 #define RQHIP_PROF_MAXIMA 5      /* rqhip_maxima */
 #define RQHIP_PROF_IMAGES 6      /* rqhip_weight_images */
 #define RQHIP_PROF_SEAM 7        /* rqhip_rq_seam: flops = the GEMMs' 2 B D H each + the levels' L (2 D K + 5 D) per row */
+#define RQHIP_PROF_LINEAR_SMALL 8 /* rqhip_linear_small: flops = 2 M N Kr */
 typedef struct {
     int tag;
     float ms;

@@ -706,3 +706,36 @@ int rqo_linear_chain(const float *x, const float *xmask, int64_t B, int n_in, co
     }
     return 0;
 }
+
+/* ---- the encoder / decoder Linear layers below 4096 rows (csrc/mlp_small.hip: lin_small_kernel; reference modules/encoder.py:25-38 and
+ * autograd's data gradient of the same layer) ----------------------------------------------------------------------------------------
+ * out[m][n] = epilogue( ((p_0 + p_1) + ...) + p_{waves-1} ),  p_v = ONE fp32 FMA chain from +0 over the 32-term groups
+ * [v ng / waves, (v + 1) ng / waves) of the reduction (ng = n_red / 32), a group's terms taken in the order 0 8 16 24 1 9 17 25 ... 7 15 23 31
+ * (instruction e of the kernel consumes term 8 kq + e from each of the four k-slots kq of the 16x16x4 fp32 matrix instruction, which
+ * accumulates its slots in ascending order).
+ *   W(r, n) = w_kn ? w[r * n_out + n] : w[n * n_red + r];  epilogue: 0 store, 1 relu (v < 0 -> 0; NaN stays), 3 mask (aux <= 0 -> 0) */
+int rqo_linear_small(const float *a, int64_t M, int n_red, const float *w, int n_out, int w_kn, int waves, int epilogue, const float *aux,
+                     float *out) {
+    if (M < 0 || n_red < 32 || n_red % 32 || n_out < 1 || waves < 1 || !w || (M > 0 && (!a || !out)) || (epilogue == 3 && !aux)) return -1;
+    const int ng = n_red / 32;
+    for (int64_t m = 0; m < M; ++m) {
+        for (int n = 0; n < n_out; ++n) {
+            float tot = 0.0f;
+            for (int v = 0; v < waves; ++v) {
+                const int lo = (int)((int64_t)v * ng / waves), hi = (int)((int64_t)(v + 1) * ng / waves);
+                float part = 0.0f;
+                for (int g = lo; g < hi; ++g)
+                    for (int e = 0; e < 8; ++e)
+                        for (int kq = 0; kq < 4; ++kq) {
+                            const int r = 32 * g + 8 * kq + e;
+                            part = fmaf(a[(size_t)m * n_red + r], w_kn ? w[(size_t)r * n_out + n] : w[(size_t)n * n_red + r], part);
+                        }
+                tot = v == 0 ? part : tot + part;
+            }
+            if (epilogue == 1 && tot < 0.0f) tot = 0.0f;
+            if (epilogue == 3 && aux[(size_t)m * n_out + n] <= 0.0f) tot = 0.0f;
+            out[(size_t)m * n_out + n] = tot;
+        }
+    }
+    return 0;
+}

@@ -269,3 +269,18 @@ def linear_chain(x, w, transposed: bool = False, epilogue: int = 0, xmask=None, 
     _chk(lib().rqo_linear_chain(_p(x), _p(xm), C.c_int64(B), C.c_int(n_in), _p(w), C.c_int(n_out), C.c_int(1 if transposed else 0),
                                 C.c_int(int(epilogue)), _p(om), _p(out)), "linear_chain")
     return out
+
+
+def linear_small(a, w, w_kn: bool = False, waves: int = 4, epilogue: int = 0, aux=None) -> np.ndarray:
+    """out = epilogue(a . B) as csrc/mlp_small.hip sums it (rqo_linear_small): `waves` partial fp32 FMA chains over contiguous ranges of
+    32-term groups, group order 0 8 16 24 1 9 17 25 ..., partials added in wave order.  w: [n_out, n_red], or [n_red, n_out] with `w_kn`;
+    epilogue 0 store / 1 relu / 3 mask by aux > 0."""
+    a, w = _f(a), _f(w)
+    M, n_red = a.shape
+    n_out = w.shape[1] if w_kn else w.shape[0]
+    assert (w.shape[0] if w_kn else w.shape[1]) == n_red
+    ax = None if aux is None else _f(aux)
+    out = np.empty((M, n_out), dtype=np.float32)
+    _chk(lib().rqo_linear_small(_p(a), C.c_int64(M), C.c_int(n_red), _p(w), C.c_int(n_out), C.c_int(1 if w_kn else 0), C.c_int(int(waves)),
+                                C.c_int(int(epilogue)), _p(ax), _p(out)), "linear_small")
+    return out

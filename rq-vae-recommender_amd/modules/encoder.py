@@ -98,6 +98,9 @@ class _MLPStack(torch.autograd.Function):
         aligned = x.data_ptr() % 16 == 0 and M > 0
         chain = [(_lin.chain_shape(w.shape[0], w.shape[1], M) if aligned else 0) for w in weights]
         chain = [0 if (k == 1 and relus[i]) else k for i, k in enumerate(chain)]
+        # batches below 4096 rows: forward and data gradient on csrc/mlp_small.hip (exact fp32; ReLU / ReLU backward in the epilogue)
+        small = [aligned and w.is_contiguous() and w.data_ptr() % 16 == 0 and _lin.small_shape_ok(M, w.shape[0], w.shape[1])
+                 and _lin.small_shape_ok(M, w.shape[1], w.shape[0]) for w in weights]
         fwd_split = [not chain[i] and _lin.split_shape_ok(M, w.shape[0], w.shape[1]) for i, w in enumerate(weights)]
         dg_split = [not chain[i] and need_in[i] and _lin.split_shape_ok(M, w.shape[1], w.shape[0]) for i, w in enumerate(weights)]
         wg_f16 = [need_w[i] and _lin.wgrad_f16_ok(w.shape[0], w.shape[1], M) for i, w in enumerate(weights)]
@@ -133,6 +136,8 @@ class _MLPStack(torch.autograd.Function):
             elif fwd_split[i]:
                 y, _, ysc = _lin.gemm(a, img_f[i], w.shape[0], epilogue=_lib.EPI_RELU if relus[i] else _lib.EPI_STORE,
                                       a_scales=sc, want_rows=not last and fwd_split[i + 1], col_out=col_out)
+            elif small[i]:
+                y, ysc = _lin.small_forward(a, w, relus[i]), _lin.Scales()
             else:
                 y, ysc = _lin.library_forward(a, w, relus[i], zero_bias(w.shape[0], a) if relus[i] else None), _lin.Scales()
             acts.append(y)
@@ -144,6 +149,7 @@ class _MLPStack(torch.autograd.Function):
         ctx.save_for_backward(x, *weights, target if ctx.has_target else out)
         ctx.acts_mid, ctx.scs, ctx.relus = (acts[1:] if ctx.has_target else acts[1:-1]), scs, tuple(relus)
         ctx.img_t, ctx.dg_split, ctx.wg_f16, ctx.need_in, ctx.need_w, ctx.chain = img_t, dg_split, wg_f16, need_in, need_w, chain
+        ctx.small = small
         ctx.g_recon, ctx.g_scales, ctx.consumed = g_recon, g_scales, False
         return out
 
@@ -155,7 +161,7 @@ class _MLPStack(torch.autograd.Function):
         target = tail if ctx.has_target else None
         acts = [x] + list(ctx.acts_mid) + ([] if ctx.has_target else [tail])
         scs, relus, need_in, need_w = ctx.scs, ctx.relus, ctx.need_in, ctx.need_w
-        dg_split, wg_f16, f16, chain = ctx.dg_split, ctx.wg_f16, _lin.f16(), ctx.chain
+        dg_split, wg_f16, f16, chain, small = ctx.dg_split, ctx.wg_f16, _lin.f16(), ctx.chain, ctx.small
         g_out = g_out.contiguous()
         handed = _lin.take_grad_handoff(g_out) if target is None else None
         if handed is not None:       # the node above (modules/rqvae.py's seam) masked this gradient by our last ReLU and took its maxima
@@ -226,6 +232,9 @@ class _MLPStack(torch.autograd.Function):
                                       want_rows=i > 0 and dg_split[i - 1] and (fuse or not lower_relu),
                                       col_out=col_out if (fuse or not lower_relu) else None)
                 premasked = fuse or not lower_relu
+            elif small[i] and g.data_ptr() % 16 == 0:      # the ReLU backward of the layer below in the epilogue: no mask launch
+                g, gsc = _lin.small_input_grad(g, w, a if lower_relu else None), _lin.Scales()
+                premasked = True
             else:
                 g, gsc = g.mm(w), _lin.Scales()
                 premasked = not lower_relu
@@ -345,7 +354,7 @@ class MLP(nn.Module):
         if not (isinstance(last, nn.Linear) and last.bias is None and isinstance(layers[-1], nn.Identity) and chain_ok
                 and isinstance(layers[0], nn.Linear)
                 and not torch_ops.enabled() and z.is_cuda and z.dim() == 2 and z.dtype == torch.float32
-                and torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters()))
+                and torch.is_grad_enabled() and (z.requires_grad or any(l.weight.requires_grad for l in layers if isinstance(l, nn.Linear)))
                 and target.is_cuda and target.dtype == torch.float32 and not target.requires_grad
                 and tuple(target.shape) == (z.shape[0], last.out_features) and target.is_contiguous()
                 and target.data_ptr() % 16 == 0

@@ -118,9 +118,18 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
     def config(self) -> dict:
         return self._config
 
+    def _first_param(self) -> Tensor:
+        """The encoder's first parameter.  `next(self.encoder.parameters())` walks the module tree through three generators (7 us, twice per
+        forward: tools/eager_host_profile.py); the Parameter object itself survives `.to()` / `load_state_dict`, so it is looked up once."""
+        p = self.__dict__.get("_p0")
+        if p is None:
+            p = next(self.encoder.parameters())
+            self.__dict__["_p0"] = p
+        return p
+
     @property
     def device(self) -> torch.device:
-        return next(self.encoder.parameters()).device
+        return self._first_param().device
 
     def load_pretrained(self, path: str) -> None:
         state = torch.load(path, map_location=self.device, weights_only=False)
@@ -196,7 +205,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         return _StackResult(embs_t, torch.stack(residuals), torch.stack(ids), loss, emb_sum, norms)
 
     def get_semantic_ids(self, x: Tensor, gumbel_t: float = 0.001) -> RqVaeOutput:
-        x = x.to(next(self.encoder.parameters()).dtype)
+        x = x.to(self._first_param().dtype)
         res = self.encode(x)
         st = self._quantize_stack(res, gumbel_t, want_levels=True)
         return RqVaeOutput(
@@ -208,7 +217,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
 
     def forward(self, batch: SeqBatch, gumbel_t: float) -> RqVaeComputedLosses:
         x = batch.x
-        xin = x.to(next(self.encoder.parameters()).dtype)
+        xin = x.to(self._first_param().dtype)
         reducer = getattr(self, "_rq_reducer", None)
         n = self.n_cat_feats
         seam = self._seam_weights(xin)

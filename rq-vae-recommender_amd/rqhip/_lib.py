@@ -23,7 +23,7 @@ WGRAD_FP32 = 0x1   # rqhip_linear_wgrad_ex
 BWD_CBGRAD_MATRIX = 0x1   # rqhip_rq_backward_ex
 SPLIT_F16X2, SPLIT_BF16X3 = 0, 1                       # arithmetic of the split GEMM kernels (include/rqhip.h)
 EPI_STORE, EPI_RELU, EPI_RECON, EPI_MASK = 0, 1, 2, 3  # rqhip_gemm_split_ex epilogues
-PROF_TAGS = {1: "rq_forward", 2: "rq_backward", 3: "gemm_split", 4: "wgrad", 5: "maxima", 6: "weight_images", 7: "rq_seam"}
+PROF_TAGS = {1: "rq_forward", 2: "rq_backward", 3: "gemm_split", 4: "wgrad", 5: "maxima", 6: "weight_images", 7: "rq_seam", 8: "linear_small"}
 
 
 class ImageJob(C.Structure):          # rqhip_image_job
@@ -119,6 +119,9 @@ SIGNATURES = {
     "rqhip_recon_rescale_rows_ex": (_int, [_vp, _i64, _int, _f32, _vp, _vp, _int, _vp, _vp]),
     "rqhip_rq_seam_supported": (_int, [_int, _int, _int, _int]),
     "rqhip_rq_seam": (_int, [C.POINTER(SeamArgs), _vp]),
+    "rqhip_linear_small_supported": (_int, [_i64, _int, _int]),
+    "rqhip_linear_small_plan": (_int, [_i64, _int, _int, C.POINTER(_int), C.POINTER(_int)]),
+    "rqhip_linear_small": (_int, [_vp, _vp, _int, _vp, _i64, _int, _int, _int, _vp, _int, _int, _vp]),
     "rqhip_adamw_step": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "rqhip_profile_enable": (_int, [_int]),
     "rqhip_profile_select": (_int, [C.c_uint]),

@@ -316,6 +316,40 @@ def chain_input_grad(g: Tensor, w: Tensor, *, g_mask: Optional[Tensor] = None, o
     return r.out, _chain_scales(r, col_out if f16() else None)
 
 
+# ---- batches below 4096 rows: the layers' forward and data gradient on csrc/mlp_small.hip (rqhip_linear_small) -----------------------
+# Exact fp32 on the fp32 matrix instruction, the ReLU / the ReLU backward of the layer below in the epilogue: at the reference's batch
+# sizes (640 / 64 rows) a training step has no library GEMM and no threshold_backward launch left (rounds 1-5: 16 + 6 of its 39 launches).
+_SMALL = True
+
+
+def use_small_kernels(on: bool = True) -> bool:
+    """rqhip_linear_small below 4096 rows (default) or the library GEMMs as in round 5 (A/B: tools/bench_small_batch.py --no-small).
+    Returns the previous setting."""
+    global _SMALL
+    before, _SMALL = _SMALL, bool(on)
+    return before
+
+
+def small_shape_ok(rows: int, n_out: int, n_red: int) -> bool:
+    """Does out [rows, n_out] = a [rows, n_red] . B run on rqhip_linear_small?  (Not in the strict-fp32 arm, which means "library".)"""
+    return bool(_SMALL and _ARITH != _FP32 and 0 < rows < _SPLIT_MIN_ROWS and n_out % 32 == 0 and n_red % 32 == 0)
+
+
+def small_ok(a: Tensor, n_out: int, n_red: int) -> bool:
+    return bool(a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[1] == n_red and a.data_ptr() % 16 == 0
+                and small_shape_ok(a.shape[0], n_out, n_red))
+
+
+def small_forward(x: Tensor, w: Tensor, relu: bool) -> Tensor:
+    """[relu](x w^T), small_ok(x, *w.shape)."""
+    return ops.linear_small(x, w.detach(), epilogue=_lib.EPI_RELU if relu else _lib.EPI_STORE)
+
+
+def small_input_grad(g: Tensor, w: Tensor, below: Optional[Tensor] = None) -> Tensor:
+    """g w for w [n_out, n_in], kept where `below` [M, n_in] > 0 (the ReLU backward of the layer below) when given."""
+    return ops.linear_small(g, w.detach(), w_kn=True, epilogue=_lib.EPI_MASK if below is not None else _lib.EPI_STORE, aux=below)
+
+
 def images(jobs: List[Tuple[Tensor, bool]]) -> List[Tensor]:
     """The weight images of `jobs` = [(w, transpose), ...] in the current arithmetic, one launch.  Rebuilt at EVERY forward:
     a first version cached an image per `w._version` -- and trained on stale weights: the fused AdamW update (and any
@@ -349,6 +383,8 @@ def input_grad(g: Tensor, w: Tensor, *, g_scales: Optional[Scales] = None, image
         return chain_input_grad(g, w)[0]
     if split_ok(g, w.shape[1], w.shape[0], False):
         return gemm(g, image if image is not None else planes(w, True), w.shape[1], a_scales=g_scales)[0]
+    if small_ok(g, w.shape[1], w.shape[0]) and w.is_contiguous() and w.data_ptr() % 16 == 0:
+        return small_input_grad(g, w)
     return g.mm(w)
 
 
@@ -360,6 +396,8 @@ def forward(x: Tensor, w: Tensor, relu: bool, zero_bias: Tensor = None) -> Tenso
         return chain_forward(x, w, relu)[0]
     if split_ok(x, w.shape[0], w.shape[1], relu):
         return gemm(x, planes(w, False), w.shape[0], epilogue=_lib.EPI_RELU if relu else _lib.EPI_STORE)[0]
+    if small_ok(x, w.shape[0], w.shape[1]) and x.is_contiguous() and w.is_contiguous() and w.data_ptr() % 16 == 0:
+        return small_forward(x, w, relu)
     return library_forward(x, w, relu, zero_bias)
 
 

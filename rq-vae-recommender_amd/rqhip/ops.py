@@ -44,7 +44,15 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The current stream's handle.  `torch.cuda.current_stream().cuda_stream` builds a Stream object per call (11 us of host time, five
+    times per eager small-batch step: tools/eager_host_profile.py); the raw getter behind it returns the same handle in well under 1 us."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -102,6 +110,47 @@ class RqSeamOut(NamedTuple):
 
 
 SEAM_H = 128
+
+
+def linear_small_supported(M: int, N: int, Kr: int) -> bool:
+    """Does rqhip_linear_small take out [M, N] = a [M, Kr] . B (N, Kr multiples of 32)?  Host-side query."""
+    return bool(_lib.lib().rqhip_linear_small_supported(int(M), int(N), int(Kr)))
+
+
+def linear_small_plan(M: int, N: int, Kr: int):
+    """(col_blocks, waves) rqhip_linear_small chooses for a shape: `waves` is the number of partial chains an output is summed from."""
+    cb, ks = C.c_int(0), C.c_int(0)
+    check(_lib.lib().rqhip_linear_small_plan(int(M), int(N), int(Kr), C.byref(cb), C.byref(ks)), "linear_small_plan")
+    return cb.value, ks.value
+
+
+def linear_small(a: Tensor, w: Tensor, *, w_kn: bool = False, epilogue: int = _lib.EPI_STORE, aux: Optional[Tensor] = None,
+                 col_blocks: int = 0, waves: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """epilogue(a . w^T) for w [N, Kr] (the forward of a bias-free nn.Linear) or, with w_kn, epilogue(a . w) for w [Kr, N] (its data
+    gradient) -- csrc/mlp_small.hip, exact fp32, for batches below 4096 rows (any M is computed correctly).  epilogue: EPI_STORE /
+    EPI_RELU / EPI_MASK (out where aux > 0 else 0: the ReLU backward of the layer below).  reference modules/encoder.py:25-38."""
+    _need_gpu(a, w, aux, out)
+    a, w = _f32c(a, "a"), _f32c(w, "w")
+    M, Kr = a.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    if (w.shape[0] if w_kn else w.shape[1]) != Kr:
+        raise RqHipError(f"linear_small: a {tuple(a.shape)} and w {tuple(w.shape)} (w_kn={w_kn}) do not share the reduction dimension")
+    if aux is not None:
+        aux = _f32c(aux, "aux")
+        if tuple(aux.shape) != (M, N):
+            raise RqHipError(f"linear_small: aux must be [{M}, {N}], got {tuple(aux.shape)}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+
+    def launch():
+        check(_lib.lib().rqhip_linear_small(_ptr(a), _ptr(w), 1 if w_kn else 0, _ptr(out), M, N, Kr, int(epilogue), _ptr(aux),
+                                            int(col_blocks), int(waves), _stream()), "rqhip_linear_small")
+    if _RAW_DEVICE is not None and a.device.index == _RAW_DEVICE():     # (the device context manager costs more host time than the launch)
+        launch()
+    else:
+        with torch.cuda.device(a.device):
+            launch()
+    return out
 
 
 def rq_seam_supported(D: int, H: int, L: int, K: int) -> bool:

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import RqHipError, check
+from .ops import _RAW_DEVICE, _stream as ops_stream
 
 
 class FlatAdamW(torch.optim.Optimizer):
@@ -64,37 +65,47 @@ class FlatAdamW(torch.optim.Optimizer):
             dev = ps[0].device
             if dev.type != "cuda":
                 raise RqHipError("FlatAdamW updates ROCm device parameters (csrc/adamw.hip); use torch.optim.AdamW for host tensors")
-            for p in ps:
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.is_sparse:
-                    raise RqHipError("FlatAdamW: parameters and gradients must be contiguous float32 tensors")
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["step"] = self._steps.get(gi, torch.zeros((), dtype=torch.float32, device=dev))
-                    self._steps.setdefault(gi, st["step"])
-            step = self._shared_step(gi, group)
-            # (the kernel reads 16 bytes at a time: a gradient that is a misaligned view of someone's packed buffer is copied once;
-            # rqhip.dist.FlatGradReducer pads its slices, so its views never take this branch)
-            grads = [p.grad if (p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0) else p.grad.clone(memory_format=torch.contiguous_format)
-                     for p in ps]
-            key = (gi, tuple(p.data_ptr() for p in ps), tuple(g.data_ptr() for g in grads),
-                   tuple(self.state[p]["exp_avg"].data_ptr() for p in ps), tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in ps))
+            # the same parameters and the same (aligned) gradient buffers as last step -- every step of a training loop whose gradients
+            # live in rqhip.dist.FlatGradReducer's flat buffer: the argument arrays, the validation and the state lookups of the first
+            # such step stand (load_state_dict drops them); 11 parameters x 5 Python loops were a third of an eager step's optimizer time
+            fast = (tuple([p.data_ptr() for p in ps]), tuple([p.grad.data_ptr() for p in ps]))
             arrs = self._cache.get(gi)
-            if arrs is None or arrs[0] != key:
+            step = self._steps.get(gi)
+            if arrs is None or arrs[0] != fast or step is None:
+                for p in ps:
+                    if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                        raise RqHipError("FlatAdamW: parameters and gradients must be contiguous float32 tensors")
+                    st = self.state[p]
+                    if "exp_avg" not in st:
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["step"] = self._steps.get(gi, torch.zeros((), dtype=torch.float32, device=dev))
+                        self._steps.setdefault(gi, st["step"])
+                step = self._shared_step(gi, group)
+                # (the kernel reads 16 bytes at a time: a gradient that is a misaligned view of someone's packed buffer is copied once
+                # per step; rqhip.dist.FlatGradReducer pads its slices, so its views never take this branch)
+                direct = all(p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0 for p in ps)
+                grads = [p.grad if (p.grad.is_contiguous() and p.grad.data_ptr() % 16 == 0) else p.grad.clone(memory_format=torch.contiguous_format)
+                         for p in ps]
                 n = len(ps)
                 vp = C.c_void_p * n
-                arrs = (key, vp(*[p.data_ptr() for p in ps]), vp(*[g.data_ptr() for g in grads]),
+                arrs = (fast if direct else None, vp(*[p.data_ptr() for p in ps]), vp(*[g.data_ptr() for g in grads]),
                         vp(*[self.state[p]["exp_avg"].data_ptr() for p in ps]), vp(*[self.state[p]["exp_avg_sq"].data_ptr() for p in ps]),
-                        (C.c_int64 * n)(*[p.numel() for p in ps]), n)
+                        (C.c_int64 * n)(*[p.numel() for p in ps]), n, grads)      # (grads: keeps copies alive until the launch)
                 self._cache[gi] = arrs
             if self._scratch is None or self._scratch.device != dev:
                 self._scratch = torch.zeros((2,), dtype=torch.float32, device=dev)
             b1, b2 = group["betas"]
-            with torch.cuda.device(dev):
+
+            def launch():
                 check(l.rqhip_adamw_step(arrs[1], arrs[2], arrs[3], arrs[4], arrs[5], arrs[6], step.data_ptr(), self._scratch.data_ptr(),
                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                         torch.cuda.current_stream().cuda_stream), "rqhip_adamw_step")
+                                         ops_stream()), "rqhip_adamw_step")
+            if _RAW_DEVICE is not None and dev.index == _RAW_DEVICE():     # (the device context manager costs more than the launch)
+                launch()
+            else:
+                with torch.cuda.device(dev):
+                    launch()
         return loss
 
     def state_dict(self):

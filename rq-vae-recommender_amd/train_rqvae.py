@@ -347,109 +347,116 @@ def train(
     window: List[torch.Tensor] = []
     shown = (float("nan"),) * 3
     t0 = time.time()
-    for it in range(start_iter, start_iter + 1 + iterations):
-        model.train()
-        if it == 0 and use_kmeans_init:
-            # lazy k-means init of every level on its own residuals of the first <= 20 000 items
-            # (train_rqvae.py:178-183).  With several ranks each takes its block of those rows through the model and the
-            # Lloyd iterations all-reduce the [K, D+1] sums || counts (init/kmeans.py): every rank
-            # ends with the same codebooks -- unlike the reference, whose ranks would each seed their own
-            n_warm = min(20000, len(train_dataset))
-            lo, hi = rqdist.shard_bounds(n_warm)
-            for layer in model.layers:
-                layer.kmeans_rows_sharded = world > 1
-            try:
-                model(train_dataset[torch.arange(lo, hi)], t)  # output (and its autograd graph) dropped at once
-            finally:
+    # One process drives one GPU: the autograd engine's per-device worker thread buys nothing here and costs a thread hand-off per
+    # backward (0.13 ms of a 0.9 ms eager batch-640 step, tools/eager_host_profile.py) -- the backward runs on this thread.
+    engine_threads = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(False)
+    try:
+        for it in range(start_iter, start_iter + 1 + iterations):
+            model.train()
+            if it == 0 and use_kmeans_init:
+                # lazy k-means init of every level on its own residuals of the first <= 20 000 items
+                # (train_rqvae.py:178-183).  With several ranks each takes its block of those rows through the model and the
+                # Lloyd iterations all-reduce the [K, D+1] sums || counts (init/kmeans.py): every rank
+                # ends with the same codebooks -- unlike the reference, whose ranks would each seed their own
+                n_warm = min(20000, len(train_dataset))
+                lo, hi = rqdist.shard_bounds(n_warm)
                 for layer in model.layers:
-                    layer.kmeans_rows_sharded = False
+                    layer.kmeans_rows_sharded = world > 1
+                try:
+                    model(train_dataset[torch.arange(lo, hi)], t)  # output (and its autograd graph) dropped at once
+                finally:
+                    for layer in model.layers:
+                        layer.kmeans_rows_sharded = False
 
-        data = next(train_batches) if gradient_accumulate_every == 1 else None
-        g_step = graphs.get(data.x.shape[0]) if (graphs and it >= graph_after and data is not None) else None
-        if g_step is not None and g_step.graph is None:
-            # (re-)capture every shape at once; a shape whose batch is not at hand warms up on the first rows of the corpus -- the
-            # warm-up steps are rolled back and a capture executes nothing, so which rows they see does not matter
-            at_hand = {rows: (data.x if rows == data.x.shape[0] else train_dataset[torch.arange(rows)].x) for rows in graphs}
-            graphs = _capture_or_eager(graphs, at_hand, world)
-            g_step = graphs.get(data.x.shape[0])
-        if g_step is not None and g_step.graph is not None:
-            model_output = g_step.run(data.x)
-            total_loss = model_output.loss.detach()
-        else:
-            reducer.zero_()
-            total_loss = 0
-            for micro in range(gradient_accumulate_every):
-                data = data if data is not None else next(train_batches)
-                if micro + 1 == gradient_accumulate_every:
-                    reducer.arm()      # the last backward of the step: finished gradients go on the wire under the encoder's
-                with loss_scale(1.0 / gradient_accumulate_every):   # hint for the speculative recon-loss gradient
-                    model_output = model(data, gumbel_t=t)
-                loss = model_output.loss / gradient_accumulate_every
-                loss.backward()
-                total_loss = total_loss + loss.detach()
-                # keep only detached values: a live autograd graph from an eager step would pin AccumulateGrad
-                # nodes to the default stream and break the hipGraph capture of a later step
-                model_output = type(model_output)(*[v.detach() for v in model_output])
-                del loss
-                data = None
-            reducer.allreduce_mean()
-            optimizer.step()
-            for g_any in graphs.values():
-                g_any.invalidate()     # an eager step ran between two replays (only the first iterations and accumulation steps are)
+            data = next(train_batches) if gradient_accumulate_every == 1 else None
+            g_step = graphs.get(data.x.shape[0]) if (graphs and it >= graph_after and data is not None) else None
+            if g_step is not None and g_step.graph is None:
+                # (re-)capture every shape at once; a shape whose batch is not at hand warms up on the first rows of the corpus -- the
+                # warm-up steps are rolled back and a capture executes nothing, so which rows they see does not matter
+                at_hand = {rows: (data.x if rows == data.x.shape[0] else train_dataset[torch.arange(rows)].x) for rows in graphs}
+                graphs = _capture_or_eager(graphs, at_hand, world)
+                g_step = graphs.get(data.x.shape[0])
+            if g_step is not None and g_step.graph is not None:
+                model_output = g_step.run(data.x)
+                total_loss = model_output.loss.detach()
+            else:
+                reducer.zero_()
+                total_loss = 0
+                for micro in range(gradient_accumulate_every):
+                    data = data if data is not None else next(train_batches)
+                    if micro + 1 == gradient_accumulate_every:
+                        reducer.arm()      # the last backward of the step: finished gradients go on the wire under the encoder's
+                    with loss_scale(1.0 / gradient_accumulate_every):   # hint for the speculative recon-loss gradient
+                        model_output = model(data, gumbel_t=t)
+                    loss = model_output.loss / gradient_accumulate_every
+                    loss.backward()
+                    total_loss = total_loss + loss.detach()
+                    # keep only detached values: a live autograd graph from an eager step would pin AccumulateGrad
+                    # nodes to the default stream and break the hipGraph capture of a later step
+                    model_output = type(model_output)(*[v.detach() for v in model_output])
+                    del loss
+                    data = None
+                reducer.allreduce_mean()
+                optimizer.step()
+                for g_any in graphs.values():
+                    g_any.invalidate()     # an eager step ran between two replays (only the first iterations and accumulation steps are)
 
-        window.append(torch.stack([total_loss, model_output.reconstruction_loss.detach(),
-                                   model_output.rqvae_loss.detach()]))  # stack copies: safe with graph-static outputs
-        window = window[-1000:]
-        if it % log_every == 0:
-            shown = tuple(torch.stack(window).mean(dim=0).tolist())  # the only host sync of a normal step
-            if is_main:
-                rate = (it - start_iter + 1) / max(time.time() - t0, 1e-9)
-                print(f"iter {it}: loss: {shown[0]:.4f}, rl: {shown[1]:.4f}, vl: {shown[2]:.4f} ({rate:.1f} it/s)")
+            window.append(torch.stack([total_loss, model_output.reconstruction_loss.detach(),
+                                       model_output.rqvae_loss.detach()]))  # stack copies: safe with graph-static outputs
+            window = window[-1000:]
+            if it % log_every == 0:
+                shown = tuple(torch.stack(window).mean(dim=0).tolist())  # the only host sync of a normal step
+                if is_main:
+                    rate = (it - start_iter + 1) / max(time.time() - t0, 1e-9)
+                    print(f"iter {it}: loss: {shown[0]:.4f}, rl: {shown[1]:.4f}, vl: {shown[2]:.4f} ({rate:.1f} it/s)")
 
-        log = {}
-        last = it + 1 == iterations
-        if use_wandb or (wandb_logging and is_main and it % log_every == 0):
-            norms = model_output.embs_norm.mean(dim=0)
-            log.update({f"emb_avg_norm_{i}": norms[i].item() for i in range(vae_n_layers)})
-            log.update({"learning_rate": optimizer.param_groups[0]["lr"], "total_loss": float(total_loss),
-                        "reconstruction_loss": model_output.reconstruction_loss.item(),
-                        "rqvae_loss": model_output.rqvae_loss.item(), "temperature": t,
-                        "p_unique_ids": model_output.p_unique_ids.item()})
+            log = {}
+            last = it + 1 == iterations
+            if use_wandb or (wandb_logging and is_main and it % log_every == 0):
+                norms = model_output.embs_norm.mean(dim=0)
+                log.update({f"emb_avg_norm_{i}": norms[i].item() for i in range(vae_n_layers)})
+                log.update({"learning_rate": optimizer.param_groups[0]["lr"], "total_loss": float(total_loss),
+                            "reconstruction_loss": model_output.reconstruction_loss.item(),
+                            "rqvae_loss": model_output.rqvae_loss.item(), "temperature": t,
+                            "p_unique_ids": model_output.p_unique_ids.item()})
 
-        if do_eval and ((it + 1) % eval_every == 0 or last):
-            model.eval()
-            rows = []
-            with torch.no_grad():
-                for batch in eval_batches.epoch():
-                    out = model(batch, gumbel_t=t)
-                    rows.append(torch.stack([out.loss, out.reconstruction_loss, out.rqvae_loss]))
-            if rows:
-                ev = torch.stack(rows).mean(dim=0).tolist()
-                log.update({"eval_total_loss": ev[0], "eval_reconstruction_loss": ev[1], "eval_rqvae_loss": ev[2]})
+            if do_eval and ((it + 1) % eval_every == 0 or last):
+                model.eval()
+                rows = []
+                with torch.no_grad():
+                    for batch in eval_batches.epoch():
+                        out = model(batch, gumbel_t=t)
+                        rows.append(torch.stack([out.loss, out.reconstruction_loss, out.rqvae_loss]))
+                if rows:
+                    ev = torch.stack(rows).mean(dim=0).tolist()
+                    log.update({"eval_total_loss": ev[0], "eval_reconstruction_loss": ev[1], "eval_rqvae_loss": ev[2]})
 
-        if (it + 1) % eval_every == 0 or last:
-            model.eval()
-            log.update(_id_diversity(tokenizer, index_dataset, vae_n_layers, vae_codebook_size))  # collective
+            if (it + 1) % eval_every == 0 or last:
+                model.eval()
+                log.update(_id_diversity(tokenizer, index_dataset, vae_n_layers, vae_codebook_size))  # collective
 
-        if is_main and ((it + 1) % save_model_every == 0 or last):
-            os.makedirs(save_dir_root, exist_ok=True)
-            state = {"iter": it, "model": model.state_dict(), "model_config": model.config,
-                     "optimizer": optimizer.state_dict()}
-            if getattr(train_dataset, "synthetic", False):
-                state["data"] = "synthetic"   # extra key: a checkpoint trained on noise says so
-            torch.save(state, save_dir_root + f"checkpoint_{it}.pt")
+            if is_main and ((it + 1) % save_model_every == 0 or last):
+                os.makedirs(save_dir_root, exist_ok=True)
+                state = {"iter": it, "model": model.state_dict(), "model_config": model.config,
+                         "optimizer": optimizer.state_dict()}
+                if getattr(train_dataset, "synthetic", False):
+                    state["data"] = "synthetic"   # extra key: a checkpoint trained on noise says so
+                torch.save(state, save_dir_root + f"checkpoint_{it}.pt")
 
-        if graphs and ((do_eval and ((it + 1) % eval_every == 0 or last)) or (it + 1) % eval_every == 0
-                       or last or (it + 1) % save_model_every == 0):
-            for g_any in graphs.values():
-                g_any.invalidate()
+            if graphs and ((do_eval and ((it + 1) % eval_every == 0 or last)) or (it + 1) % eval_every == 0
+                           or last or (it + 1) % save_model_every == 0):
+                for g_any in graphs.values():
+                    g_any.invalidate()
 
-        if is_main and log:
-            if use_wandb:
-                wandb.log(log)
-            elif wandb_logging:
-                print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in log.items()})
+            if is_main and log:
+                if use_wandb:
+                    wandb.log(log)
+                elif wandb_logging:
+                    print({k: (round(v, 6) if isinstance(v, float) else v) for k, v in log.items()})
 
+    finally:
+        torch.autograd.set_multithreading_enabled(engine_threads)
     if use_wandb:
         wandb.finish()
     rqdist.barrier()

@@ -4,6 +4,7 @@ same step replayed from a hipGraph (torch.cuda.CUDAGraph).
   python tools/bench_small_batch.py            # rqvae_amazon.gin: batch 640, D = 32, STE
   python tools/bench_small_batch.py c3         # rqvae_ml32m.gin (BASELINE config 3): batch 64, D = 64, rotation trick, lr 1e-4
   python tools/bench_small_batch.py --no-jobs  # A/B: the per-layer weight-gradient kernels instead of the job table (csrc/wgrad_jobs.hip)
+  python tools/bench_small_batch.py --no-small # A/B: the library GEMMs + mask launches instead of the layers' own kernels (csrc/mlp_small.hip)
   python tools/bench_small_batch.py --json     # both, one JSON line on stdout (bench.py's `secondary.small_batch` runs this in a
                                                # subprocess with a time limit: a graph replay that hangs cannot take the bench line with it)"""
 import json
@@ -21,6 +22,7 @@ from modules.rqvae import RqVae  # noqa: E402
 from rqhip import tuning  # noqa: E402
 
 tuning.enable_tuned_gemms()
+torch.autograd.set_multithreading_enabled(False)     # as train_rqvae.train: one GPU per process, the backward on the calling thread
 JSON = "--json" in sys.argv
 if "--no-jobs" in sys.argv:      # A/B: round 4's per-layer weight-gradient kernels instead of csrc/wgrad_jobs.hip
     from rqhip import linear as _linear
@@ -28,7 +30,10 @@ if "--no-jobs" in sys.argv:      # A/B: round 4's per-layer weight-gradient kern
 if "--no-seam" in sys.argv:      # A/B: round 5's library GEMMs for the 128 <-> 32 layers instead of the seam kernel (rqhip_rq_seam)
     from rqhip import linear as _linear
     _linear.use_chain_gemms(False)
-ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs", "--no-seam")]
+if "--no-small" in sys.argv:     # A/B: round 5's library GEMMs + threshold_backward launches instead of csrc/mlp_small.hip
+    from rqhip import linear as _linear
+    _linear.use_small_kernels(False)
+ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs", "--no-seam", "--no-small")]
 
 
 def timeit(fn, n=200):
