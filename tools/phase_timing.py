@@ -23,7 +23,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--build":
 
 import torch  # noqa: E402
 
-B, D, K, L = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "65536,32,256,3").split(","))
+B, D, K, L, *rest = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "65536,32,256,3").split(","))
+MODE = rest[0] if rest else 0      # 0 eval / 1 STE / 2 rotation trick (B,D,K,L,mode)
 lib = C.CDLL(SO)
 lib.rqhip_rq_forward_workspace_bytes.restype = C.c_size_t
 g = torch.Generator().manual_seed(0)
@@ -37,7 +38,7 @@ wsb = lib.rqhip_rq_forward_workspace_bytes(L, K)
 ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
 vp = C.c_void_p
 for _ in range(3):
-    rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, 0, C.c_float(0.25),
+    rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, MODE, C.c_float(0.25),
                               vp(ids.data_ptr()), None, None, vp(es.data_ptr()), vp(loss.data_ptr()),
                               vp(norm.data_ptr()), None, vp(ws.data_ptr()), C.c_size_t(wsb), None)
     assert rc == 0, rc
@@ -60,7 +61,7 @@ import numpy as np  # noqa: E402
 
 lib.rqhip_debug_trace(None, 1)
 torch.cuda.synchronize()
-rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, 0, C.c_float(0.25),
+rc = lib.rqhip_rq_forward(vp(x.data_ptr()), C.c_int64(B), D, vp(cb.data_ptr()), L, K, MODE, C.c_float(0.25),
                           vp(ids.data_ptr()), None, None, vp(es.data_ptr()), vp(loss.data_ptr()),
                           vp(norm.data_ptr()), None, vp(ws.data_ptr()), C.c_size_t(wsb), None)
 torch.cuda.synchronize()
