@@ -4,9 +4,12 @@ On ROCm tensors the whole run of Linear (+ ReLU) layers is ONE autograd node (`_
 multiple of 256, batches of 4096 rows and more) run on the 16-bit matrix cores with fp32's accuracy (csrc/gemm_split.hip,
 csrc/wgrad_split.hip: two fp16 pieces per operand under exact power-of-two row / column scales, three piece products, fp32
 accumulation; no less exact than the library's fp32 GEMM, tests/test_gpu_gemm_split.py, tests/test_gpu_wgrad.py) with the
-ReLU, the ReLU backward and the reconstruction loss in their epilogues; the narrow layers stay library GEMMs on PyTorch-ROCm
-(fp32, `rqhip/tuning.py` picks the kernels), where a Linear followed by a ReLU is ONE hipBLASLt call with the ReLU in the
-GEMM epilogue (`torch._addmm_activation` with a zero bias).  Weight gradients: csrc/wgrad_split.hip / csrc/wgrad.hip
+ReLU, the ReLU backward and the reconstruction loss in their epilogues; the 128 <-> 32 layers either side of the quantiser are the seam
+kernel's GEMMs (csrc/rq_forward.hip).  Batches below 4096 rows -- the reference's 640 / 64 -- run every layer's forward and data gradient
+on csrc/mlp_small.hip (exact fp32 on the fp32 matrix instruction, ReLU / ReLU backward of the layer below in the epilogue) and all weight
+gradients of a stack as one job-table launch (csrc/wgrad_jobs.hip).  Library GEMMs on PyTorch-ROCm (fp32, `rqhip/tuning.py` picks the
+kernels; a Linear followed by a ReLU is ONE hipBLASLt call, `torch._addmm_activation` with a zero bias) are left for shapes no kernel
+tiles (a width that is not a multiple of 32) and for the strict-fp32 arm.  Large-batch weight gradients: csrc/wgrad_split.hip / csrc/wgrad.hip
 (SURVEY section 8 row f2).  Parameter names are `mlp.{0,2,4,...}.weight`, as in the reference, so checkpoints load in both
 directions."""
 from typing import List

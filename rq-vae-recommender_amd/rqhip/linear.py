@@ -270,7 +270,8 @@ def chain_shape(n_out: int, n_in: int, rows: int = _SPLIT_MIN_ROWS) -> int:
     """0: not a seam layer; 1: 128 -> 32 (rows enter the input GEMM); 2: 32 -> 128 (rows leave through the output GEMM).
     Batches of 4096 rows and more, like the split kernels: every output of these GEMMs is a 64- or 16-deep chain of dependent fp32
     matrix instructions over 32 rows at a time -- at the reference's batch 640 that is 20 such chains on 20 SIMDs, 9.3 us per
-    launch against 4.6-5.9 us for the library's 16 x 16 tiles (profiles/r06_seam.txt): small batches keep the library GEMMs."""
+    launch against 4.6-5.9 us for the library's 16 x 16 tiles (profiles/r06_seam.txt): small batches take rqhip_linear_small (below),
+    which splits every reduction over four waves per tile."""
     if not _CHAIN or rows < _SPLIT_MIN_ROWS:
         return 0
     return 1 if (n_out, n_in) == (CHAIN_D, CHAIN_H) else 2 if (n_out, n_in) == (CHAIN_H, CHAIN_D) else 0
