@@ -253,7 +253,8 @@ def small_batch_secondary(cpu):
         out["batch640_vs_cpu_port"] = {"cpu_port_items_per_s": c640,
                                        "eager_ratio": round(a.get("eager_items_per_s", 0.0) / c640, 2),
                                        "graph_ratio": round(a.get("graph_items_per_s", 0.0) / c640, 2) if "graph_items_per_s" in a else None}
-    out["note"] = ("one fwd+bwd+AdamW step at the reference's shipped batch sizes; `graph` = the same step captured once and replayed "
+    out["note"] = ("one fwd+bwd+AdamW step at the reference's shipped batch sizes (every layer on csrc/mlp_small.hip; `library_gemms` = the "
+                   "same step on round 5's library GEMMs + mask launches); `graph` = the same step captured once and replayed "
                    "(train_rqvae.py does this by default below 4096 rows, for the full batch and for the short batch that ends an epoch: "
                    "`train_loop_amazon` = iterations/s of that gin-driven loop on a 12 101-item synthetic corpus, both shapes replayed vs round 5's "
                    "eager tail + re-capture vs eager); cpu port at batch 640: cpu_baseline.batch640_items_per_s")

@@ -116,6 +116,15 @@ if JSON:
     log = lambda *a: print(*a, file=sys.stderr)   # noqa: E731
     out["batch640_amazon"] = run(False, 640, log)
     out["batch64_ml32m"] = run(True, 64, log)
+    # the same two steps on round 5's library GEMMs + mask launches (rqhip.linear.use_small_kernels(False)): the A/B of csrc/mlp_small.hip
+    from rqhip import linear as _linear
+    was = _linear.use_small_kernels(False)
+    try:
+        for key, args in (("batch640_amazon", (False, 640)), ("batch64_ml32m", (True, 64))):
+            r = run(*args, log)
+            out[key]["library_gemms"] = {k: r[k] for k in ("eager_ms", "graph_ms", "launches_per_step", "hand_written_launches") if k in r}
+    finally:
+        _linear.use_small_kernels(was)
     try:     # the gin-driven training LOOP at the reference's corpus size: both step shapes of an epoch replayed vs round 5's form vs eager
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import epoch_tail_ab
