@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 460 /* 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 461 /* 461: rqhip_unique_fraction; 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -227,6 +227,10 @@ size_t rqhip_dedup_workspace_bytes(int64_t B);
 int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int64_t *rank,
                      int64_t *n_distinct, void *workspace, size_t workspace_bytes,
                      rqhip_stream_t stream);
+/* p_unique_ids of RqVae.forward (modules/rqvae.py:159-167) as the reference returns it: *p_unique = float(n_distinct) / float(B), a device
+ * fp32 scalar (torch: int64 tensor / int -> both to fp32, IEEE division); B >= 1; one fill + one kernel; workspace as rqhip_dedup_rank. */
+int rqhip_unique_fraction(const int64_t *ids, int64_t B, int L, float *p_unique, void *workspace, size_t workspace_bytes,
+                          rqhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Decoder-side consumers of semantic ids: exact integer tuple matching.

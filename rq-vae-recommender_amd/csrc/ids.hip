@@ -24,9 +24,13 @@ __device__ __forceinline__ unsigned mix32(unsigned h, unsigned v) {
     return h;
 }
 
+// n_distinct / ticket: two counters behind the table, cleared with it by ONE fill to all-ones (count = -1, ticket = -1): the leaders of a
+// wave add their number to `count`, the last workgroup to take a ticket writes count + 1 to `out` -- the statistic of a training step is two
+// launches (fill, this kernel) instead of four (two fills, this kernel, a one-thread store).
 __global__ void ids_group_kernel(const int64_t *__restrict__ ids, long long B, int L, int *__restrict__ table,
                                  unsigned mask, unsigned *__restrict__ group,
-                                 unsigned long long *__restrict__ n_distinct) {
+                                 unsigned long long *__restrict__ n_distinct, unsigned *__restrict__ ticket, int64_t *__restrict__ out,
+                                 float *__restrict__ frac) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool leader = false;
     if (i < B) {
@@ -47,7 +51,19 @@ __global__ void ids_group_kernel(const int64_t *__restrict__ ids, long long B, i
         if (group) group[i] = s;
     }
     const unsigned long long m = __ballot(leader);
-    if ((threadIdx.x & 63) == 0 && m && n_distinct) atomicAdd(n_distinct, (unsigned long long)__builtin_popcountll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_distinct, (unsigned long long)__builtin_popcountll(m));
+    if (!out && !frac) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(ticket, 1u);          // -1, 0, 1, ...: the last of gridDim.x workgroups sees gridDim.x - 2
+        if (old + 1u == gridDim.x - 1u) {
+            __threadfence();
+            const unsigned long long n = atomicAdd(n_distinct, 0ull) + 1ull;
+            if (out) *out = (int64_t)n;
+            if (frac) *frac = (float)(long long)n / (float)B;      // int64 tensor / int in torch: both to fp32, IEEE divide
+        }
+    }
 }
 
 __global__ void ids_store_count_kernel(const unsigned long long *__restrict__ n, int64_t *__restrict__ out) {
@@ -199,7 +215,7 @@ static DedupLayout dedup_layout(long long B) {
     if (d.nblocks < 1) d.nblocks = 1;
     size_t o = 0;
     d.off_table = o; o = al(o + d.table_slots * 4);
-    d.off_count = o; o = al(o + 8);
+    d.off_count = o; o = al(o + 16);     // count (8 bytes), ticket (4)
     d.off_keys0 = o; o = al(o + (size_t)(B > 0 ? B : 1) * 4);
     d.off_vals0 = o; o = al(o + (size_t)(B > 0 ? B : 1) * 4);
     d.off_keys1 = o; o = al(o + (size_t)(B > 0 ? B : 1) * 4);
@@ -214,6 +230,29 @@ static DedupLayout dedup_layout(long long B) {
 using namespace rqhip;
 
 extern "C" size_t rqhip_dedup_workspace_bytes(int64_t B) { return dedup_layout(B).total; }
+
+extern "C" int rqhip_unique_fraction(const int64_t *ids, int64_t B, int L, float *p_unique, void *workspace, size_t workspace_bytes,
+                                     rqhip_stream_t stream) {
+    if (B < 1 || B >= (1ll << 30) || L < 1 || !ids || !p_unique) {
+        set_error("unique_fraction: bad arguments (B=%lld, L=%d): 1 <= B < 2^30 rows, non-null pointers", (long long)B, L);
+        return RQHIP_EARG;
+    }
+    const DedupLayout lay = dedup_layout(B);
+    if (!workspace || workspace_bytes < lay.total) {
+        set_error("unique_fraction: workspace too small (%zu < %zu: rqhip_dedup_workspace_bytes)", workspace_bytes, lay.total);
+        return RQHIP_EWORKSPACE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char *ws = reinterpret_cast<char *>(workspace);
+    int *table = reinterpret_cast<int *>(ws + lay.off_table);
+    unsigned long long *count = reinterpret_cast<unsigned long long *>(ws + lay.off_count);
+    if (int rc = fill_words(table, 0xffffffffu, lay.off_count + 16 - lay.off_table, s)) return rc;
+    const int gb = (int)((B + 255) / 256);
+    hipLaunchKernelGGL(ids_group_kernel, dim3(gb), dim3(256), 0, s, ids, (long long)B, L, table, (unsigned)(lay.table_slots - 1),
+                       (unsigned *)nullptr, count, reinterpret_cast<unsigned *>(count + 1), (int64_t *)nullptr, p_unique);
+    RQ_CHECK_LAUNCH("ids_group_kernel");
+    return RQHIP_OK;
+}
 
 extern "C" int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int64_t *rank, int64_t *n_distinct,
                                 void *workspace, size_t workspace_bytes, rqhip_stream_t stream) {
@@ -241,24 +280,22 @@ extern "C" int rqhip_dedup_rank(const int64_t *ids, int64_t B, int L, int K, int
     unsigned *vals1 = reinterpret_cast<unsigned *>(ws + lay.off_vals1);
     unsigned *hist = reinterpret_cast<unsigned *>(ws + lay.off_hist);
 
-    if (int rc = fill_words(count, 0u, 8, s)) return rc;
     if (B == 0) {
+        if (int rc = fill_words(count, 0u, 8, s)) return rc;
         if (n_distinct) {
             hipLaunchKernelGGL(ids_store_count_kernel, dim3(1), dim3(1), 0, s, count, n_distinct);
             RQ_CHECK_LAUNCH("ids_store_count_kernel");
         }
         return RQHIP_OK;
     }
-    if (int rc = fill_words(table, 0xffffffffu, lay.table_slots * 4, s)) return rc;
+    // the table (empty = -1) and, right behind it, the two counters (count - 1, ticket - 1): one fill
+    unsigned *ticket = reinterpret_cast<unsigned *>(count + 1);
+    if (int rc = fill_words(table, 0xffffffffu, lay.off_count + 16 - lay.off_table, s)) return rc;
     const int tb = 256;
     const int gb = (int)((B + tb - 1) / tb);
     hipLaunchKernelGGL(ids_group_kernel, dim3(gb), dim3(tb), 0, s, ids, (long long)B, L, table,
-                       (unsigned)(lay.table_slots - 1), rank ? keys0 : nullptr, count);
+                       (unsigned)(lay.table_slots - 1), rank ? keys0 : nullptr, count, ticket, n_distinct, (float *)nullptr);
     RQ_CHECK_LAUNCH("ids_group_kernel");
-    if (n_distinct) {
-        hipLaunchKernelGGL(ids_store_count_kernel, dim3(1), dim3(1), 0, s, count, n_distinct);
-        RQ_CHECK_LAUNCH("ids_store_count_kernel");
-    }
     if (!rank) return RQHIP_OK;
 
     hipLaunchKernelGGL(iota_kernel, dim3(gb), dim3(tb), 0, s, vals0, (long long)B);

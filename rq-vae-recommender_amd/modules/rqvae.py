@@ -246,8 +246,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
                 side = _side_stream(ids.device)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side), torch.no_grad():
-                    _, n_distinct = ops.dedup_rank(ids, self.codebook_size, want_rank=False)
-                    p_unique_ids = n_distinct / ids.shape[1]
+                    p_unique_ids = ops.unique_fraction(ids)
                 ids.record_stream(side)
             if n == 0 and type(self.reconstruction_loss) is ReconstructionLoss and x.dim() == 2:
                 reconstruction = self.decoder.reconstruction_rows(d, xin, first=2)
@@ -284,9 +283,12 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
             with torch.no_grad():
                 if torch_ops.enabled():
                     n_distinct = torch.ops.rqhip.distinct_tuples(st.ids, self.codebook_size)
+                    p_unique_ids = n_distinct / st.ids.shape[1]               # rqvae.py:159-167
+                elif st.ids.is_cuda and st.ids.shape[1] > 0:
+                    p_unique_ids = ops.unique_fraction(st.ids)                # the count and the division in one kernel
                 else:
                     _, n_distinct = ops.dedup_rank(st.ids, self.codebook_size, want_rank=False)
-                p_unique_ids = n_distinct / st.ids.shape[1]                   # rqvae.py:159-167
+                    p_unique_ids = n_distinct / st.ids.shape[1]
         elif side is not None:
             torch.cuda.current_stream().wait_stream(side)                   # join: the statistic is part of this call's result
             p_unique_ids.record_stream(torch.cuda.current_stream())

@@ -85,6 +85,7 @@ SIGNATURES = {
     "rqhip_kmeans_apply_sums": (_int, [_vp, _int, _int, _vp, _vp, _vp, _f32, _vp]),
     "rqhip_dedup_workspace_bytes": (_sz, [_i64]),
     "rqhip_dedup_rank": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_unique_fraction": (_int, [_vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "rqhip_prefix_index_bytes": (_sz, [_i64, _int]),
     "rqhip_prefix_index_build": (_int, [_vp, _i64, _int, _i64, _vp, _sz, _vp]),
     "rqhip_prefix_lookup": (_int, [_vp, _sz, _vp, _i64, _int, _i64, _vp, _i64, _int, _i64, _vp, _vp]),

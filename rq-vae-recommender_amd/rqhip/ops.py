@@ -397,6 +397,31 @@ def dedup_rank(ids: Tensor, codebook_size: int = 0, *, want_rank: bool = True):
     return rank, n
 
 
+_DEDUP_WS = {}      # (device index, B) -> workspace: one allocation per batch size instead of one per step
+
+
+def unique_fraction(ids: Tensor) -> Tensor:
+    """p_unique_ids of reference modules/rqvae.py:159-167 for ids [L,B] int64 (B >= 1): the fraction of rows without a later duplicate,
+    a device fp32 scalar with torch's `int64 tensor / int` rounding -- one fill + one kernel (rqhip_unique_fraction)."""
+    _need_gpu(ids)
+    if ids.dtype != torch.int64 or ids.dim() != 2 or ids.shape[1] < 1:
+        raise RqHipError("ids must be an int64 [L,B] tensor with B >= 1")
+    ids = ids.contiguous()
+    L, B = ids.shape
+    dev = ids.device
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        key = (dev.index, B)
+        ws = _DEDUP_WS.get(key)
+        if ws is None or torch.cuda.is_current_stream_capturing():
+            ws = torch.empty((l.rqhip_dedup_workspace_bytes(B),), dtype=torch.uint8, device=dev)
+            if not torch.cuda.is_current_stream_capturing() and len(_DEDUP_WS) < 16:
+                _DEDUP_WS[key] = ws        # (stream-ordered reuse: every use starts with the fill that clears it)
+        check(l.rqhip_unique_fraction(_ptr(ids), B, L, _ptr(out), _ptr(ws), ws.numel(), _stream()), "rqhip_unique_fraction")
+    return out
+
+
 def _i64_rows(t: Tensor, name: str) -> Tensor:
     """int64 [rows, cols] with unit column stride (a column slice of a wider table is taken as is)."""
     if t.dtype != torch.int64 or t.dim() != 2:

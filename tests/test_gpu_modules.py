@@ -167,6 +167,41 @@ def test_dedup_rank_vs_definition(B, L, K):
     assert int(n) == int(start.sum())
 
 
+@pytest.mark.parametrize("B,L,K", [(1, 3, 4), (64, 3, 4), (640, 3, 256), (700, 3, 4), (100_000, 3, 256), (300_000, 4, 6)])
+def test_unique_fraction_is_the_references_statistic(B, L, K):
+    """p_unique_ids as reference modules/rqvae.py:159-167 forms it (rows without a later duplicate / B), bit for bit in fp32; twice through the
+    same cached workspace and once more under a hipGraph replay (the training step's form)."""
+    from rqhip import ops
+    g = torch.Generator().manual_seed(7 * B + L + K)
+    ids = torch.randint(0, K, (L, B), generator=g)
+    if B <= 1000:                                                    # rqvae.py:159-167 on [B, L], as written there
+        t = ids.t()
+        dup = (t.unsqueeze(1) == t.unsqueeze(0)).all(dim=-1)
+        want = (~torch.triu(dup, diagonal=1)).all(dim=1).sum() / B
+    else:                                                            # the same count without the B x B matrix
+        want = torch.tensor(torch.unique(ids.t(), dim=0).shape[0]) / B
+    dev = ids.cuda()
+    for _ in range(2):
+        got = ops.unique_fraction(dev)
+        assert got.dtype == torch.float32 and got.dim() == 0
+        assert got.cpu().item() == want.to(torch.float32).item()
+    n = ops.dedup_rank(dev, K, want_rank=False)[1]
+    assert int(n) == round(want.item() * B)
+    if B <= 1000:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            ops.unique_fraction(dev)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = ops.unique_fraction(dev)
+        for _ in range(3):
+            out.fill_(-1.0)
+            graph.replay()
+            assert out.cpu().item() == want.to(torch.float32).item()
+
+
 def test_dedup_all_rows_identical():
     from rqhip import ops
     ids = torch.zeros((3, 70_000), dtype=torch.int64).cuda()
