@@ -294,9 +294,6 @@ struct GemmSplitParams {
 #ifndef GS_PROBE
 #define GS_PROBE 0
 #endif
-#ifndef GS_PROLOGUE_ORDER
-#define GS_PROLOGUE_ORDER 1
-#endif
 // pad between the (piece, half) regions of gs_tile2's A stage, dwords (developer A/B: tools/ab_build.sh pad16 gemm_split.hip -DGS_REGION_PAD=16)
 #ifndef GS_REGION_PAD
 #define GS_REGION_PAD 32
@@ -489,30 +486,28 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- BQ
     // 16-byte elements of the stage's weight image per thread
     const int arow = tid >> 2, akq = tid & 3;
-    constexpr bool kAllLive = (ROWS * 4) % kGsThreads == 0;
-    bool a_live[AQ];
+    bool a_live[AQ], arow_ok[AQ];
     const float *asrc[AQ];
     int a_e[AQ];                                           // NP == 2: exponents of this thread's rows of A
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
-        a_live[q] = kAllLive || arow + APASS * q < ROWS;
-        // rows past M (and the slots of a short tile) re-read row M - 1 and are never stored: every load of the stage loop is
-        // unconditional (as gs_tile2), the loop body one basic block without a drain of the vector-memory counter
-        long long arow_g = m0 + arow + APASS * q;
-        arow_g = arow_g < p.M ? arow_g : p.M - 1;
-        asrc[q] = p.A + (size_t)arow_g * p.R + 4 * akq;
+        a_live[q] = arow + APASS * q < ROWS;
+        const long long arow_g = m0 + arow + APASS * q;
+        arow_ok[q] = a_live[q] && arow_g < p.M;
+        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
         a_e[q] = 0;
         if (NP == 2) {
             // (four parts per round, their loads independent of one another: a dependent load per part put a_parts memory
             // latencies in front of every tile -- 12 parts x 2 rows x ~0.7 us on a 768-column producer)
             unsigned mx = 0u;
-            const unsigned *am = p.a_max + arow_g;
+            const unsigned *am = p.a_max + (arow_ok[q] ? arow_g : 0);
             for (int part = 0; part < p.a_parts; part += 4) {
                 unsigned v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = am[(size_t)(part + j < p.a_parts ? part + j : part) * p.M];
                 mx = gs_umax(gs_umax(mx, gs_umax(v[0], v[1])), gs_umax(v[2], v[3]));
             }
+            if (!arow_ok[q]) mx = 0u;
             a_e[q] = gs_exp_of_bits(mx);
             if (a_live[q] && akq == 0) s_aexp[arow + APASS * q] = a_e[q];   // (read by the epilogue, many barriers later)
         }
@@ -533,7 +528,9 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     auto fetchA = [&](int stage, gs_f32x4 *dst) {
         stage = stage < n_stage ? stage : n_stage - 1;
 #pragma unroll
-        for (int q = 0; q < AQ; ++q) dst[q] = *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK);   // (non-temporal loads of A: +3 ... +4 %)
+        for (int q = 0; q < AQ; ++q)
+            dst[q] = !arow_ok[q] ? gs_f32x4{0.f, 0.f, 0.f, 0.f}   // (non-temporal loads of A: +3 ... +4 %)
+                                 : *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK);
     };
     auto fetchB = [&](int stage) {
         stage = stage < n_stage ? stage : n_stage - 1;
@@ -551,7 +548,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
-            if (!kAllLive && !a_live[q]) continue;
+            if (!a_live[q]) continue;
             unsigned h01, m01, l01 = 0u, h23, m23, l23 = 0u;
             if (NP == 2) {
                 gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
@@ -634,22 +631,6 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // drained the A rows of the stage after -- their latency had ONE iteration to hide in, not two.
     // A rows are requested TWO iterations before they are split (scattered 64-byte pieces of 256 rows: their latency is
     // longer than one iteration's matrix work), the weight image (L2-resident) one iteration before.
-#if GS_PROLOGUE_ORDER
-    // (the requests in the order of one loop iteration -- B, A1 | B, A0 -- behind stage 0's: see gs_tile2)
-    gs_f32x4 rp[AQ];
-    fetchA(0, rp);
-    fetchB(0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchA(1, ra1);
-    __builtin_amdgcn_sched_barrier(0);
-    stash(0, rp);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchB(1);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchA(2, ra0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-#else
     fetchA(0, ra0);
     fetchB(0);
     fetchA(1, ra1);
@@ -657,7 +638,6 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     fetchB(1);
     fetchA(2, ra0);
     __syncthreads();
-#endif
     // Every wave stages the next stage first, then multiplies the current one.
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
@@ -808,26 +788,6 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
         }
     };
 
-#if GS_PROLOGUE_ORDER
-    // The prologue's requests in the ORDER OF ONE LOOP ITERATION (A1, B0, A0, B1), behind the rows of stage 0: vector-memory results arrive in
-    // request order and the compiler's s_waitcnt on a loop header is the minimum over the edges into it -- with the prologue's own order
-    // (A0 B0 A1 | B1 A0) the header got vmcnt(5/4) and the middle of the first half vmcnt(3/2), i.e. every half iteration waited for the rows
-    // requested ONE half iteration earlier (HBM latency) and for image blocks requested a few hundred cycles earlier (L2 latency), where
-    // the steady state allows vmcnt(11/10) and (7/6): two stages for the rows, one for the image.
-    gs_f32x4 rp[AQ];
-    fetchA(0, rp);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchA(1, ra1);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchB(0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchA(2, ra0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetchB(1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    stash(0, rp);
-    __syncthreads();
-#else
     fetchA(0, ra0);
     fetchB(0, fb0);
     fetchA(1, ra1);
@@ -835,7 +795,6 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
     fetchB(1, fb1);
     fetchA(2, ra0);
     __syncthreads();
-#endif
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
         stash(1, ra1);                             // stage c + 1
