@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 462 /* 462: rqhip_gemm_args sign bits; 461: rqhip_unique_fraction; 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 461 /* 461: rqhip_unique_fraction; 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -415,12 +415,6 @@ typedef struct {
     unsigned *c_row_max; /* optional output [column tiles][M] (Nc / 256 tiles when Nc % 256 == 0, else Nc / 128): largest |value| of
                             each row of C per column tile (plain stores) */
     unsigned *c_col_max; /* optional output [Nc]: largest |value| of each column of C, maxed into atomically (zero it first) */
-    /* sign bits (ABI 462; RQHIP_SPLIT_F16X2, Nc % 64 == 0): [M][Nc / 64][2] words, 8-byte aligned -- word j >> 1, bit 16 (j & 1) + q of row m's
-     * group G = !(value <= 0) of column 64 G + 4 q + j (q < 16, j < 4).  c_sign_bits: optional output of any epilogue, the bits of C as stored
-     * (after a ReLU: of the activation); aux_sign_bits: RQHIP_EPI_MASK takes them INSTEAD of aux (aux may then be NULL) -- the ReLU backward
-     * `threshold_backward(g, y, 0)` of reference modules/encoder.py:25-38 needs y's sign only: 1/32 of the bytes of y */
-    unsigned *c_sign_bits;
-    const unsigned *aux_sign_bits;
 } rqhip_gemm_args;
 int rqhip_gemm_split_supported(int Nc, int R);
 size_t rqhip_weight_image_bytes(int Nc, int R, int arith);

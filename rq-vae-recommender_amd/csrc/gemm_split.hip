@@ -285,11 +285,6 @@ struct GemmSplitParams {
     // optional outputs of every epilogue: c_rowmax [column tiles][M] (part = column tile; plain stores), c_colmax [Nc]
     // (atomic maxima: zeroed by the caller) -- the scales of the kernels that read C next
     unsigned *c_rowmax, *c_colmax;
-    // sign bits (round 6): of C as stored (c_bits, optional output of any epilogue) and of Y instead of X for EPI == 3 (x_bits): per row and
-    // 64-column group two words -- word j >> 1, bit 16 (j & 1) + q = !(value <= 0) of column 64 G + 4 q + j -- [M][Nc / 64][2]: what a lane of
-    // the transposing epilogue holds (four consecutive columns 4 q + j of one row) is bit q of the four 16-bit masks
-    unsigned *c_bits;
-    const unsigned *x_bits;
 };
 
 // developer-only phase-skipping probes of gs_tile2 (tools/ab_build.sh <name> gemm_split.hip -DGS_PROBE=<bits>; results are WRONG
@@ -360,28 +355,14 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
     // aux values (X of EPI 2, Y of EPI 3) are requested kAux row quads ahead of their use
     constexpr int kAux = 4, NQ = 8 * TA;
     gs_f32x4 xa[kAux];
-    gs_u32x2 xb[kAux];
-    const bool from_bits = EPI == 3 && p.x_bits != nullptr;  // (uniform) the ReLU mask as sign bits: 8 bytes per row and 64 columns instead of 256
-    const size_t bit_groups = (size_t)(p.Nc >> 6);
-    const int bit_group = colw >> 6;
     auto aux_of = [&](int q) {
         long long r = m0 + 32 * TA * wm + 4 * q + rl;        // (q = 8 t + k: the row quads of the wave's tile in order)
         r = r < p.M ? r : p.M - 1;
         return *reinterpret_cast<const gs_f32x4 *>(p.X + (size_t)r * p.Nc + colw);
     };
-    auto bits_of = [&](int q) {
-        long long r = m0 + 32 * TA * wm + 4 * q + rl;
-        r = r < p.M ? r : p.M - 1;
-        return *reinterpret_cast<const gs_u32x2 *>(p.x_bits + ((size_t)r * bit_groups + bit_group) * 2);   // (the 16 lanes of a row: one address)
-    };
     if (EPI >= 2) {
-        if (from_bits) {
 #pragma unroll
-            for (int q = 0; q < kAux; ++q) xb[q] = bits_of(q);
-        } else {
-#pragma unroll
-            for (int q = 0; q < kAux; ++q) xa[q] = aux_of(q);
-        }
+        for (int q = 0; q < kAux; ++q) xa[q] = aux_of(q);
     }
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
@@ -407,17 +388,8 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
             }
             gs_f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
             if (EPI >= 2) {
-                if (from_bits) {     // 1.0 where the bit is set, 0.0 where it is not: the test below stays `x <= 0`
-                    const gs_u32x2 w2 = xb[q % kAux];
-                    if (q + kAux < NQ) xb[q % kAux] = bits_of(q + kAux);
-                    x4.x = (w2.x >> cl) & 1u ? 1.0f : 0.0f;
-                    x4.y = (w2.x >> (16 + cl)) & 1u ? 1.0f : 0.0f;
-                    x4.z = (w2.y >> cl) & 1u ? 1.0f : 0.0f;
-                    x4.w = (w2.y >> (16 + cl)) & 1u ? 1.0f : 0.0f;
-                } else {
-                    x4 = xa[q % kAux];
-                    if (q + kAux < NQ) xa[q % kAux] = aux_of(q + kAux);
-                }
+                x4 = xa[q % kAux];
+                if (q + kAux < NQ) xa[q % kAux] = aux_of(q + kAux);
             }
             if (EPI == 1) {   // (a NaN stays a NaN, as torch.relu)
                 v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
@@ -435,15 +407,6 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
             if (EPI == 3) {   // threshold_backward(g, y, 0): 0 where y <= 0
                 v.x = x4.x <= 0.0f ? 0.0f : v.x; v.y = x4.y <= 0.0f ? 0.0f : v.y;
                 v.z = x4.z <= 0.0f ? 0.0f : v.z; v.w = x4.w <= 0.0f ? 0.0f : v.w;
-            }
-            if (p.c_bits) {          // (uniform) sign bits of what is stored: four ballots, lanes 16 rl + q of each are row rl's 16 bits
-                const unsigned long long b0 = __ballot(!(v.x <= 0.0f)), b1 = __ballot(!(v.y <= 0.0f));
-                const unsigned long long b2 = __ballot(!(v.z <= 0.0f)), b3 = __ballot(!(v.w <= 0.0f));
-                const int sh = lane & 48;
-                const unsigned w0 = ((unsigned)(b0 >> sh) & 0xffffu) | ((unsigned)(b1 >> sh) << 16);
-                const unsigned w1 = ((unsigned)(b2 >> sh) & 0xffffu) | ((unsigned)(b3 >> sh) << 16);
-                if (cl == 0 && grow < p.M)
-                    *reinterpret_cast<gs_u32x2 *>(p.c_bits + ((size_t)grow * bit_groups + bit_group) * 2) = gs_u32x2{w0, w1};
             }
             unsigned rmx = 0u;
             if (grow < p.M) {
@@ -1129,14 +1092,8 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         set_error("gemm_split: RQHIP_SPLIT_F16X2 needs the row maxima of A (a_row_max from rqhip_maxima or from the epilogue that wrote A)");
         return RQHIP_EARG;
     }
-    if (M > 0 && epi >= RQHIP_EPI_RECON && !a->aux && !(epi == RQHIP_EPI_MASK && a->aux_sign_bits)) {
-        set_error("gemm_split: epilogue %d needs aux (X / Y, [M, Nc]; RQHIP_EPI_MASK: or aux_sign_bits)", epi);
-        return RQHIP_EARG;
-    }
-    if ((a->c_sign_bits || a->aux_sign_bits) && (np != 2 || Nc % 64 != 0 || (a->aux_sign_bits && epi != RQHIP_EPI_MASK) ||
-                                                  (reinterpret_cast<uintptr_t>(a->c_sign_bits) & 7u) || (reinterpret_cast<uintptr_t>(a->aux_sign_bits) & 7u))) {
-        set_error("gemm_split: sign bits need RQHIP_SPLIT_F16X2, Nc %% 64 == 0 (Nc = %d), 8-byte aligned [M, Nc / 64, 2] word arrays; "
-                  "aux_sign_bits belongs to RQHIP_EPI_MASK", Nc);
+    if (M > 0 && epi >= RQHIP_EPI_RECON && !a->aux) {
+        set_error("gemm_split: epilogue %d needs aux (X / Y, [M, Nc])", epi);
         return RQHIP_EARG;
     }
     const int cols = gs_cols(Nc);
@@ -1153,7 +1110,6 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.X = a->aux; p.rowsum = reinterpret_cast<float *>(a->workspace); p.row_scale = a->row_scale;
     p.a_max = a->a_row_max; p.a_parts = a->a_row_parts;
     p.c_rowmax = a->c_row_max; p.c_colmax = a->c_col_max;
-    p.c_bits = a->c_sign_bits; p.x_bits = a->aux_sign_bits;
     p.n_queues = a->tile_rows == -8 ? kGsQueues : 1;   // (tools: tile_rows = -8 selects the per-XCD dispensers, A/B)
     p.rt_fastest = a->tile_rows == -2 ? 1 : 0;         // (tools: tile_rows = -2: row tile fastest, A/B)
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
@@ -1195,8 +1151,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         static LdsGrant grant;
         RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), (int)lds));   // (+ the static LDS)
         // algorithmic work of the launch: 2 M Nc R FLOP; bytes: A once, C once (+ the aux matrix)
-        profile_begin(s, RQHIP_PROF_GEMM_SPLIT, 2.0 * (double)M * Nc * R,
-                      4.0 * (double)M * (R + Nc * ((epi >= 2 && !p.x_bits) ? 2 : 1)) + (double)M * (Nc / 8) * ((p.x_bits ? 1 : 0) + (p.c_bits ? 1 : 0)));
+        profile_begin(s, RQHIP_PROF_GEMM_SPLIT, 2.0 * (double)M * Nc * R, 4.0 * (double)M * (R + Nc * (epi >= 2 ? 2 : 1)));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, s, p);
         profile_end(s);
         RQ_CHECK_LAUNCH("gemm_split_kernel");

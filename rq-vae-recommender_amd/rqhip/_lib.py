@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):          # rqhip_gemm_args
                 ("arith", C.c_int), ("epilogue", C.c_int), ("tile_rows", C.c_int), ("C", C.c_void_p), ("aux", C.c_void_p),
                 ("row_scale", C.c_float), ("loss_rows", C.c_void_p), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t), ("a_row_max", C.c_void_p), ("a_row_parts", C.c_int),
-                ("c_row_max", C.c_void_p), ("c_col_max", C.c_void_p), ("c_sign_bits", C.c_void_p), ("aux_sign_bits", C.c_void_p)]
+                ("c_row_max", C.c_void_p), ("c_col_max", C.c_void_p)]
 
 
 class ProfileRecord(C.Structure):     # rqhip_profile_record
