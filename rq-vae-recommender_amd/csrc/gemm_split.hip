@@ -297,6 +297,9 @@ struct GemmSplitParams {
 #ifndef GS_PROLOGUE_ORDER
 #define GS_PROLOGUE_ORDER 1
 #endif
+#ifndef GS_FAST_EPILOGUE
+#define GS_FAST_EPILOGUE 1
+#endif
 // pad between the (piece, half) regions of gs_tile2's A stage, dwords (developer A/B: tools/ab_build.sh pad16 gemm_split.hip -DGS_REGION_PAD=16)
 #ifndef GS_REGION_PAD
 #define GS_REGION_PAD 32
@@ -352,6 +355,97 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
     gs_i32x4 ec = {0, 0, 0, 0};
     if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + colw);
     unsigned cmx[4] = {0u, 0u, 0u, 0u};
+#if GS_FAST_EPILOGUE
+    // ---- the straight-line form (round 6): a FULL tile (no row past M) whose launch wants both maxima -- every launch of a training step but
+    // the last row tile's.  The general loop below is 3 basic blocks per row quad (the row test around the store, the uniform tests of the two
+    // maxima pointers, the one-lane LDS store of a row statistic), each starting with its own LDS read and ending in a drain
+    // (`s_waitcnt vmcnt(0) lgkmcnt(0)`): ~400 cycles per quad, 32 quads per 128-row tile, 8 % of a 768-deep tile and a third of a 128-deep
+    // one.  Here a 32-row block is ONE basic block: its 8 + 8 LDS reads and (EPI 2 / 3) the NEXT block's 8 aux loads are issued up front,
+    // stores leave without a wait, the one-lane LDS stores of the row statistics become 64-lane stores whose other lanes hit the
+    // transposition block's padding columns, result addresses are one per-lane base + uniform offsets.  Same arithmetic per element, same
+    // (order-free) maxima, same fixed-order row sums: identical result bits.
+    if (NP == 2 && want_rowmax && want_colmax && m0 + ROWS <= p.M) {
+        const size_t row0 = (size_t)(m0 + 32 * TA * wm + rl);
+        float *cbase = p.C + row0 * p.Nc + colw;
+        const float *xbase = EPI >= 2 ? p.X + row0 * p.Nc + colw : nullptr;
+        unsigned *pad = reinterpret_cast<unsigned *>(tb) + il * kGsTS + 64 + h;       // this lane's own padding word of the block
+        gs_f32x4 xn[8];
+        if (EPI >= 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xn[k] = *reinterpret_cast<const gs_f32x4 *>(xbase + (size_t)(4 * k) * p.Nc);
+        }
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<gs_f32x4 *>(tb + il * kGsTS + 32 * u + 8 * g + 4 * h) =
+                        gs_f32x4{acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gs_f32x4 v8[8], x8[8];
+            int er8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v8[k] = *reinterpret_cast<const gs_f32x4 *>(tb + (4 * k + rl) * kGsTS + 4 * cl);
+                er8[k] = s_aexp[32 * TA * wm + 32 * t + 4 * k + rl];
+            }
+            if (EPI >= 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x8[k] = xn[k];
+                if (t + 1 < TA) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) xn[k] = *reinterpret_cast<const gs_f32x4 *>(xbase + (size_t)(32 * (t + 1) + 4 * k) * p.Nc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rloc = 32 * TA * wm + 32 * t + 4 * k + rl;
+                gs_f32x4 v = v8[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er8[k] + ec[j]);
+                const gs_f32x4 x4 = EPI >= 2 ? x8[k] : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == 1) {
+                    v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
+                    v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+                }
+                float sq = 0.0f;
+                if (EPI == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = v[j] - x4[j];
+                        sq = sq + d * d;
+                        v[j] = (2.0f * d) * p.row_scale;
+                    }
+                }
+                if (EPI == 3) {
+                    v.x = x4.x <= 0.0f ? 0.0f : v.x; v.y = x4.y <= 0.0f ? 0.0f : v.y;
+                    v.z = x4.z <= 0.0f ? 0.0f : v.z; v.w = x4.w <= 0.0f ? 0.0f : v.w;
+                }
+                unsigned rmx = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned bb = gs_abs_bits(v[j]);
+                    rmx = gs_umax(rmx, bb);
+                    cmx[j] = gs_umax(cmx[j], bb);
+                }
+                *reinterpret_cast<gs_f32x4 *>(cbase + (size_t)(32 * t + 4 * k) * p.Nc) = v;
+                if (EPI == 2) {
+                    const float s16 = gs_row16_sum(sq);
+                    float *dst = cl == 15 ? red + wn * ROWS + rloc : reinterpret_cast<float *>(pad);
+                    *dst = s16;
+                }
+                const unsigned m16 = gs_row16_umax(rmx);
+                unsigned *dstm = cl == 15 ? mred + wn * ROWS + rloc : pad;
+                *dstm = m16;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else
+#endif
+    {
     // aux values (X of EPI 2, Y of EPI 3) are requested kAux row quads ahead of their use
     constexpr int kAux = 4, NQ = 8 * TA;
     gs_f32x4 xa[kAux];
@@ -432,6 +526,7 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();            // (the block is rewritten by the next t)
+    }
     }
     if (want_colmax) {   // a lane's four columns over all its rows; the four lanes that share them (rl = 0 .. 3), then one atomic per column
 #pragma unroll

@@ -191,6 +191,31 @@ def test_maxima_and_epilogue_emitted_scales():
         ops.gemm_split_ex(a, i1, 768)                                  # the fp16 arithmetic needs the row maxima of A
 
 
+@pytest.mark.parametrize("M,R,Nc", [(4224, 768, 512), (5003, 256, 512), (4099, 128, 256), (4160, 256, 128), (640, 512, 768)])
+def test_straight_line_epilogue_equals_the_general_one(M, R, Nc):
+    """csrc/gemm_split.hip:gs_epilogue takes a straight-line form for full tiles of launches that want both maxima (every GEMM of a training
+    step) and the general loop otherwise: same result bits for every epilogue, the emitted maxima are the stored matrix's, the row losses of
+    the reconstruction epilogue are the same -- full tiles only, ragged last tiles, 128- and 256-column tiles."""
+    from rqhip import _lib, ops
+    g = torch.Generator().manual_seed(M * 3 + R + Nc)
+    a = torch.randn(M, R, generator=g).cuda() * torch.pow(10.0, torch.randint(-3, 4, (M, 1), generator=g).float()).cuda()
+    w = (torch.randn(Nc, R, generator=g) / R ** 0.5).cuda()
+    aux = torch.randn(M, Nc, generator=g).cuda()
+    img = ops.weight_images([(w, False)])[0]
+    rows_a = ops.maxima(a, cols=False)[0]
+    epis = [_lib.EPI_STORE, _lib.EPI_RELU, _lib.EPI_MASK] + ([_lib.EPI_RECON] if Nc % 256 == 0 else [])
+    for epi in epis:
+        kw = dict(epilogue=epi, a_row_max=rows_a, aux=aux if epi >= _lib.EPI_RECON else None, row_scale=1e-5)
+        c0, l0, _ = ops.gemm_split_ex(a, img, Nc, **kw)                                           # general loop (no maxima wanted)
+        col = torch.zeros(Nc, dtype=torch.int32, device="cuda")
+        c1, l1, rm = ops.gemm_split_ex(a, img, Nc, want_row_max=True, col_max_out=col, **kw)       # straight-line form on full tiles
+        assert torch.equal(c0.view(torch.int32), c1.view(torch.int32)), epi
+        if epi == _lib.EPI_RECON:
+            assert torch.equal(l0.view(torch.int32), l1.view(torch.int32))
+        assert torch.equal(rm.view(torch.float32).amax(dim=0), c1.abs().amax(dim=1))
+        assert torch.equal(col.view(torch.float32), c1.abs().amax(dim=0))
+
+
 @pytest.mark.parametrize("R", [1536, 2048, 1028])
 def test_maxima_wide_rows_and_wide_mlp_layer(R):
     """rqhip_maxima took at most 1024 columns while the f16x2 layer selection has no width limit -- an MLP
