@@ -294,6 +294,12 @@ struct GemmSplitParams {
 #ifndef GS_PROBE
 #define GS_PROBE 0
 #endif
+#ifndef GS_PROLOGUE_ORDER
+#define GS_PROLOGUE_ORDER 1
+#endif
+#ifndef GS_FAST_EPILOGUE
+#define GS_FAST_EPILOGUE 1
+#endif
 // pad between the (piece, half) regions of gs_tile2's A stage, dwords (developer A/B: tools/ab_build.sh pad16 gemm_split.hip -DGS_REGION_PAD=16)
 #ifndef GS_REGION_PAD
 #define GS_REGION_PAD 32
@@ -349,6 +355,97 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
     gs_i32x4 ec = {0, 0, 0, 0};
     if (NP == 2) ec = *reinterpret_cast<const gs_i32x4 *>(p.b_exp + colw);
     unsigned cmx[4] = {0u, 0u, 0u, 0u};
+#if GS_FAST_EPILOGUE
+    // ---- the straight-line form (round 6): a FULL tile (no row past M) whose launch wants both maxima -- every launch of a training step but
+    // the last row tile's.  The general loop below is 3 basic blocks per row quad (the row test around the store, the uniform tests of the two
+    // maxima pointers, the one-lane LDS store of a row statistic), each starting with its own LDS read and ending in a drain
+    // (`s_waitcnt vmcnt(0) lgkmcnt(0)`): ~400 cycles per quad, 32 quads per 128-row tile, 8 % of a 768-deep tile and a third of a 128-deep
+    // one.  Here a 32-row block is ONE basic block: its 8 + 8 LDS reads and (EPI 2 / 3) the NEXT block's 8 aux loads are issued up front,
+    // stores leave without a wait, the one-lane LDS stores of the row statistics become 64-lane stores whose other lanes hit the
+    // transposition block's padding columns, result addresses are one per-lane base + uniform offsets.  Same arithmetic per element, same
+    // (order-free) maxima, same fixed-order row sums: identical result bits.
+    if (NP == 2 && want_rowmax && want_colmax && m0 + ROWS <= p.M) {
+        const size_t row0 = (size_t)(m0 + 32 * TA * wm + rl);
+        float *cbase = p.C + row0 * p.Nc + colw;
+        const float *xbase = EPI >= 2 ? p.X + row0 * p.Nc + colw : nullptr;
+        unsigned *pad = reinterpret_cast<unsigned *>(tb) + il * kGsTS + 64 + h;       // this lane's own padding word of the block
+        gs_f32x4 xn[8];
+        if (EPI >= 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xn[k] = *reinterpret_cast<const gs_f32x4 *>(xbase + (size_t)(4 * k) * p.Nc);
+        }
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<gs_f32x4 *>(tb + il * kGsTS + 32 * u + 8 * g + 4 * h) =
+                        gs_f32x4{acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gs_f32x4 v8[8], x8[8];
+            int er8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v8[k] = *reinterpret_cast<const gs_f32x4 *>(tb + (4 * k + rl) * kGsTS + 4 * cl);
+                er8[k] = s_aexp[32 * TA * wm + 32 * t + 4 * k + rl];
+            }
+            if (EPI >= 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x8[k] = xn[k];
+                if (t + 1 < TA) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) xn[k] = *reinterpret_cast<const gs_f32x4 *>(xbase + (size_t)(32 * (t + 1) + 4 * k) * p.Nc);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rloc = 32 * TA * wm + 32 * t + 4 * k + rl;
+                gs_f32x4 v = v8[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ldexpf(v[j], er8[k] + ec[j]);
+                const gs_f32x4 x4 = EPI >= 2 ? x8[k] : gs_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == 1) {
+                    v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
+                    v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
+                }
+                float sq = 0.0f;
+                if (EPI == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = v[j] - x4[j];
+                        sq = sq + d * d;
+                        v[j] = (2.0f * d) * p.row_scale;
+                    }
+                }
+                if (EPI == 3) {
+                    v.x = x4.x <= 0.0f ? 0.0f : v.x; v.y = x4.y <= 0.0f ? 0.0f : v.y;
+                    v.z = x4.z <= 0.0f ? 0.0f : v.z; v.w = x4.w <= 0.0f ? 0.0f : v.w;
+                }
+                unsigned rmx = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned bb = gs_abs_bits(v[j]);
+                    rmx = gs_umax(rmx, bb);
+                    cmx[j] = gs_umax(cmx[j], bb);
+                }
+                *reinterpret_cast<gs_f32x4 *>(cbase + (size_t)(32 * t + 4 * k) * p.Nc) = v;
+                if (EPI == 2) {
+                    const float s16 = gs_row16_sum(sq);
+                    float *dst = cl == 15 ? red + wn * ROWS + rloc : reinterpret_cast<float *>(pad);
+                    *dst = s16;
+                }
+                const unsigned m16 = gs_row16_umax(rmx);
+                unsigned *dstm = cl == 15 ? mred + wn * ROWS + rloc : pad;
+                *dstm = m16;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else
+#endif
+    {
     // aux values (X of EPI 2, Y of EPI 3) are requested kAux row quads ahead of their use
     constexpr int kAux = 4, NQ = 8 * TA;
     gs_f32x4 xa[kAux];
@@ -430,6 +527,7 @@ __device__ __forceinline__ void gs_epilogue(const GemmSplitParams &p, gs_f32x16 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();            // (the block is rewritten by the next t)
     }
+    }
     if (want_colmax) {   // a lane's four columns over all its rows; the four lanes that share them (rl = 0 .. 3), then one atomic per column
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -486,28 +584,30 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // staging roles: A -- thread (row = tid >> 2 (+ APASS q), kq = tid & 3) owns 4 consecutive r of one row; B -- BQ
     // 16-byte elements of the stage's weight image per thread
     const int arow = tid >> 2, akq = tid & 3;
-    bool a_live[AQ], arow_ok[AQ];
+    constexpr bool kAllLive = (ROWS * 4) % kGsThreads == 0;
+    bool a_live[AQ];
     const float *asrc[AQ];
     int a_e[AQ];                                           // NP == 2: exponents of this thread's rows of A
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
-        a_live[q] = arow + APASS * q < ROWS;
-        const long long arow_g = m0 + arow + APASS * q;
-        arow_ok[q] = a_live[q] && arow_g < p.M;
-        asrc[q] = p.A + (size_t)(arow_ok[q] ? arow_g : 0) * p.R + 4 * akq;
+        a_live[q] = kAllLive || arow + APASS * q < ROWS;
+        // rows past M (and the slots of a short tile) re-read row M - 1 and are never stored: every load of the stage loop is
+        // unconditional (as gs_tile2), the loop body one basic block without a drain of the vector-memory counter
+        long long arow_g = m0 + arow + APASS * q;
+        arow_g = arow_g < p.M ? arow_g : p.M - 1;
+        asrc[q] = p.A + (size_t)arow_g * p.R + 4 * akq;
         a_e[q] = 0;
         if (NP == 2) {
             // (four parts per round, their loads independent of one another: a dependent load per part put a_parts memory
             // latencies in front of every tile -- 12 parts x 2 rows x ~0.7 us on a 768-column producer)
             unsigned mx = 0u;
-            const unsigned *am = p.a_max + (arow_ok[q] ? arow_g : 0);
+            const unsigned *am = p.a_max + arow_g;
             for (int part = 0; part < p.a_parts; part += 4) {
                 unsigned v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = am[(size_t)(part + j < p.a_parts ? part + j : part) * p.M];
                 mx = gs_umax(gs_umax(mx, gs_umax(v[0], v[1])), gs_umax(v[2], v[3]));
             }
-            if (!arow_ok[q]) mx = 0u;
             a_e[q] = gs_exp_of_bits(mx);
             if (a_live[q] && akq == 0) s_aexp[arow + APASS * q] = a_e[q];   // (read by the epilogue, many barriers later)
         }
@@ -528,9 +628,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     auto fetchA = [&](int stage, gs_f32x4 *dst) {
         stage = stage < n_stage ? stage : n_stage - 1;
 #pragma unroll
-        for (int q = 0; q < AQ; ++q)
-            dst[q] = !arow_ok[q] ? gs_f32x4{0.f, 0.f, 0.f, 0.f}   // (non-temporal loads of A: +3 ... +4 %)
-                                 : *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK);
+        for (int q = 0; q < AQ; ++q) dst[q] = *reinterpret_cast<const gs_f32x4 *>(asrc[q] + stage * kGsK);   // (non-temporal loads of A: +3 ... +4 %)
     };
     auto fetchB = [&](int stage) {
         stage = stage < n_stage ? stage : n_stage - 1;
@@ -548,7 +646,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
         unsigned *dA = sbuf + buf * (PA + PB), *dB = dA + PA;
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
-            if (!a_live[q]) continue;
+            if (!kAllLive && !a_live[q]) continue;
             unsigned h01, m01, l01 = 0u, h23, m23, l23 = 0u;
             if (NP == 2) {
                 gs_split2_f16(ldexpf(ra[q].x, -a_e[q]), ldexpf(ra[q].y, -a_e[q]), h01, m01);
@@ -631,6 +729,22 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     // drained the A rows of the stage after -- their latency had ONE iteration to hide in, not two.
     // A rows are requested TWO iterations before they are split (scattered 64-byte pieces of 256 rows: their latency is
     // longer than one iteration's matrix work), the weight image (L2-resident) one iteration before.
+#if GS_PROLOGUE_ORDER
+    // (the requests in the order of one loop iteration -- B, A1 | B, A0 -- behind stage 0's: see gs_tile2)
+    gs_f32x4 rp[AQ];
+    fetchA(0, rp);
+    fetchB(0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchA(1, ra1);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(0, rp);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchB(1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchA(2, ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#else
     fetchA(0, ra0);
     fetchB(0);
     fetchA(1, ra1);
@@ -638,6 +752,7 @@ __device__ __forceinline__ void gs_tile(const GemmSplitParams &p, unsigned *sbuf
     fetchB(1);
     fetchA(2, ra0);
     __syncthreads();
+#endif
     // Every wave stages the next stage first, then multiplies the current one.
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
@@ -788,6 +903,26 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
         }
     };
 
+#if GS_PROLOGUE_ORDER
+    // The prologue's requests in the ORDER OF ONE LOOP ITERATION (A1, B0, A0, B1), behind the rows of stage 0: vector-memory results arrive in
+    // request order and the compiler's s_waitcnt on a loop header is the minimum over the edges into it -- with the prologue's own order
+    // (A0 B0 A1 | B1 A0) the header got vmcnt(5/4) and the middle of the first half vmcnt(3/2), i.e. every half iteration waited for the rows
+    // requested ONE half iteration earlier (HBM latency) and for image blocks requested a few hundred cycles earlier (L2 latency), where
+    // the steady state allows vmcnt(11/10) and (7/6): two stages for the rows, one for the image.
+    gs_f32x4 rp[AQ];
+    fetchA(0, rp);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchA(1, ra1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchB(0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchA(2, ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetchB(1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(0, rp);
+    __syncthreads();
+#else
     fetchA(0, ra0);
     fetchB(0, fb0);
     fetchA(1, ra1);
@@ -795,6 +930,7 @@ __device__ __forceinline__ void gs_tile2(const GemmSplitParams &p, unsigned *sbu
     fetchB(1, fb1);
     fetchA(2, ra0);
     __syncthreads();
+#endif
     const int n_pair = n_stage & ~1;
     for (int c = 0; c < n_pair; c += 2) {
         stash(1, ra1);                             // stage c + 1
