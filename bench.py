@@ -112,6 +112,8 @@ def parse_args():
                          "gradients (round 2's step)")
     ap.add_argument("--wide-tiles", action="store_true", help="A/B (round 6, slower): the 512-column layers on 128 x 512 tiles of 8 waves, one workgroup "
                                                               "per CU, instead of 128 x 256 tiles of two workgroups per CU (profiles/r06_gemm_wide_ab.txt)")
+    ap.add_argument("--dispenser", action="store_true", help="A/B: the product GEMM's tiles from the atomic dispenser of rounds 4-5 instead of the static schedule")
+    ap.add_argument("--tiny-tiles", action="store_true", help="A/B (neutral): the product GEMM's leftover tiles 32 rows high where the launch plan prices them cheaper")
     ap.add_argument("--no-seam", action="store_true", help="A/B: the 128 <-> 32 layers either side of the quantiser as in round 5 (library / split GEMMs, "
                                                            "separate maxima and mask passes) instead of the seam kernel (rqhip_rq_seam: fused forward launch, "
                                                            "its GEMMs as the data gradients)")
@@ -398,6 +400,8 @@ def main():
     _lin.use_narrow_tiles(not args.no_narrow)
     _lin.use_wide_tiles(args.wide_tiles)
     _lin.use_chain_gemms(not args.no_seam)
+    _lin.use_tiny_tiles(args.tiny_tiles)
+    _lin.use_static_tiles(not args.dispenser)
     _lin.use_step_trims(not args.no_trims)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)

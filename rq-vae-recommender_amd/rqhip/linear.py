@@ -244,9 +244,34 @@ def use_wide_tiles(on: bool = True) -> bool:
     return before
 
 
+_TINY_TILES = False
+_STATIC_TILES = True
+
+
+def use_static_tiles(on: bool = True) -> bool:
+    """A/B (round 6): the product GEMM's tiles dealt statically (workgroup b: tiles b, b + grid, ...; default) or handed out by the
+    atomic dispenser of rounds 4-5.  Returns the previous setting."""
+    global _STATIC_TILES
+    before, _STATIC_TILES = _STATIC_TILES, bool(on)
+    return before
+
+
+def use_tiny_tiles(on: bool = True) -> bool:
+    """A/B (round 6, neutral in the step, off by default): the product GEMM's leftover behind the whole rounds of 128-row tiles as 32-row
+    tiles where the launch plan prices them cheaper, instead of round 5's plan (64-row leftover tiles / all big).  Returns the previous
+    setting."""
+    global _TINY_TILES
+    before, _TINY_TILES = _TINY_TILES, bool(on)
+    return before
+
+
 def _tile_code(n_cols: int, n_red: int, epilogue: int) -> int:
-    """rqhip_gemm_args.tile_rows for a layer: -5 selects the 128 x 512 tile (csrc/gemm_split.hip), 0 the default."""
-    return -5 if (_WIDE_TILES and f16() and n_cols % 512 == 0 and n_red >= _WIDE_MIN_RED and epilogue != _lib.EPI_RECON) else 0
+    """rqhip_gemm_args.tile_rows for a layer: -5 selects the 128 x 512 tile (csrc/gemm_split.hip), -9 allows 32-row leftover tiles, -12 the atomic tile dispenser, 0 the default."""
+    if _WIDE_TILES and f16() and n_cols % 512 == 0 and n_red >= _WIDE_MIN_RED and epilogue != _lib.EPI_RECON:
+        return -5
+    if not _STATIC_TILES:
+        return -12
+    return -9 if _TINY_TILES else 0
 
 
 # ---- the 32-wide layers either side of the quantiser (the RQ <-> MLP seam) ------------------------------------------------------------
