@@ -402,7 +402,7 @@ typedef struct {
     int Nc;
     int arith;           /* RQHIP_SPLIT_* the image was built with */
     int epilogue;        /* RQHIP_EPI_* */
-    int tile_rows;       /* 0 (tools only: staged-B kernels 256 / 128 force big tiles, 64 / 32 small ones; -8: gemm_f16_kernel with one
+    int tile_rows;       /* 0 (tools only: staged-B kernels 256 / 128 force big tiles, 64 / 32 small ones; -9: 32-row leftover tiles allowed (A/B); -12: the atomic tile dispenser of rounds 4-5 instead of the static schedule (A/B); -8: gemm_f16_kernel with one
                             tile dispenser per XCD instead of one for the chip -- measured slower, profiles/r05_gemm_xcd_dispenser_ab.txt) */
     float *C;            /* [M, Nc] */
     const float *aux;    /* RQHIP_EPI_RECON: X [M, Nc]; RQHIP_EPI_MASK: Y [M, Nc]; else NULL */

@@ -272,6 +272,7 @@ struct GemmSplitParams {
     unsigned *counter;       // the tile dispensers behind the weight image (kGsTailWords words, zero between launches)
     int n_queues;            // gemm_f16_kernel: 1 (chip-wide dispenser) or 8 (one per XCD)
     int rt_fastest;          // gemm_f16_kernel, one queue: tiles in row-tile-fastest order (A/B)
+    int static_tiles;        // gemm_f16_kernel: workgroup b takes tiles b, b + grid, ... (no dispenser: see the kernel)
     // EPI == 2 (the last decoder layer fused with the reconstruction loss): C receives (2 (A.B^T - X)) * row_scale, and
     // rowsum[ct][m] the squared error of row m over column tile ct.  EPI == 3: X is Y, the activation whose ReLU is undone
     const float *X;
@@ -1015,9 +1016,13 @@ __global__ __launch_bounds__(64 * WAVES, BIGROWS ? 4 : 2) void gemm_split_kernel
 // [16] workgroups that have left (the last one re-arms all of them).  (Round 4 also tried starting the second workgroup of
 // every CU half a tile late: neutral to -7 %, tools/experiments/gemm_split_r04_variants.hip.)
 constexpr int kGsQueues = 8;
-template <int EPI, int COLS = 256>
+// SMALL_TA: height of the leftover tiles in 32-row blocks -- 2 (64 rows) or 1 (32 rows: round 6).  Whole rounds of the chip run 128-row
+// tiles; what is left is a fraction f of a round, and costs one more 128-row tile time as big tiles, ceil(2 f) x 64 as 64-row tiles,
+// ceil(4 f) x 32 as 32-row tiles.  At 100 000 rows (781.25 row tiles on 512 slots) the one-column-tile layers leave f = 0.53 (two rounds
+// of 128 became 128 + 3 x 32), the two-column-tile layers f = 0.05 (3 x 128 + 64 became 3 x 128 + 32), the three-column-tile layer f = 0.58.
+template <int EPI, int COLS = 256, int SMALL_TA = 2>
 __global__ __launch_bounds__(COLS, COLS == 256 ? 2 : 1) void gemm_f16_kernel(const GemmSplitParams p) {
-    constexpr int kThreads = COLS, kBigRows = 128, kSmallRows = 64;
+    constexpr int kThreads = COLS, kBigRows = 128, kSmallRows = 32 * SMALL_TA;
     constexpr unsigned kSmallBit = 0x80000000u, kNone = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];
     unsigned *sbuf = reinterpret_cast<unsigned *>(gs_smem);
@@ -1033,6 +1038,30 @@ __global__ __launch_bounds__(COLS, COLS == 256 ? 2 : 1) void gemm_f16_kernel(con
     // p.n_queues: 8 = one queue per XCD; 1 (the default, see rqhip_gemm_split_ex) = a single queue for the chip
     const int nq = p.n_queues;
     const int xcd = (int)(blockIdx.x % (unsigned)nq);
+    // Static schedule (round 6, the default): workgroup b takes tiles b, b + grid, b + 2 grid, ... -- the whole rounds of big tiles give
+    // every workgroup the same number of them, the leftover tiles go one each to the first workgroups, which is what the dispenser
+    // hands out when all workgroups run alike; no device-scope atomic (three per workgroup and launch: first ticket, the ticket
+    // that says "none left", the leave counter that re-arms the dispenser -- serialised on one address, 512 workgroups at once at
+    // the start of every launch), no barrier pair around a ticket in LDS, and the tile's row and column are scalar registers.
+    if (p.static_tiles) {
+        for (unsigned tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+            __syncthreads();                   // (the previous tile's LDS reads are done)
+            if (tile < p.n_big) {
+                const int ct = (int)(tile % nct), rt = (int)(tile / nct);
+                gs_tile2<EPI, kBigRows / 32, COLS>(p, sbuf, s_aexp, s_colmax, (long long)rt * kBigRows, ct * COLS);
+            } else {
+                const unsigned st = tile - p.n_big;
+                const int ct = (int)(st % nct), rt = (int)(st / nct);
+                gs_tile2<EPI, kSmallRows / 32, COLS>(p, sbuf, s_aexp, s_colmax, (long long)p.rt_big * kBigRows + (long long)rt * kSmallRows, ct * COLS);
+            }
+        }
+        if (lds_colmax) {
+            __syncthreads();
+            for (int c = tid; c < p.Nc; c += kThreads)
+                if (s_colmax[c]) atomicMax(p.c_colmax + c, s_colmax[c]);
+        }
+        return;
+    }
     int big_skip = 0, small_skip = 0;          // (thread 0) queues found empty so far, in this workgroup's visiting order
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
@@ -1207,6 +1236,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.c_rowmax = a->c_row_max; p.c_colmax = a->c_col_max;
     p.n_queues = a->tile_rows == -8 ? kGsQueues : 1;   // (tools: tile_rows = -8 selects the per-XCD dispensers, A/B)
     p.rt_fastest = a->tile_rows == -2 ? 1 : 0;         // (tools: tile_rows = -2: row tile fastest, A/B)
+    p.static_tiles = (a->tile_rows == 0 || a->tile_rows == -9 || a->tile_rows == -10 || a->tile_rows == -11) ? 1 : 0;   // (-12: the dispenser of rounds 4-5, A/B)
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
@@ -1220,7 +1250,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     const bool occ4 = tile2 && a->tile_rows == -6 && epi != RQHIP_EPI_RECON;                    // (A/B arm: 128 x 256 tiles, 8 waves of 64 x 64, two workgroups per CU)
     const int waves = (np == 3 || wide || occ4) ? 8 : 4;
     const int big_rows = (wide || occ4) ? 128 : 32 * waves;
-    const int small_rows = tile2 ? 64 : (waves / (cols / 64)) * 32;
+    int small_rows = tile2 ? 64 : (waves / (cols / 64)) * 32;
     p.n_col_tiles = Nc / (wide ? 512 : cols);
     const long long slots = (long long)cus * ((waves == 4 || occ4) ? 2 : 1);
     // whole rounds of big tiles, the remainder as small tiles (see the kernels)
@@ -1229,7 +1259,28 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     if (rt_big * big_rows > M) rt_big = M / big_rows;
     // (measured at 100 000 rows: cutting the leftover into small tiles is worth it when it is a small part of a round -- Nc = 512:
     // 14 of 256 slots, 517 -> 456 us; a leftover of half a round runs as fast in big tiles -- Nc = 256 / 768: 135 / 149 slots)
-    if ((rt_all * p.n_col_tiles) % slots > (3 * slots) / 10 && rt_all * p.n_col_tiles >= slots) rt_big = rt_all;
+    bool all_big = (rt_all * p.n_col_tiles) % slots > (3 * slots) / 10 && rt_all * p.n_col_tiles >= slots;
+    bool tiny = false;
+    if (tile2 && !wide && a->tile_rows == -9) {   // (A/B arm, neutral in the step: profiles/r06_step_ab.txt)
+        // the product kernel also has 32-row leftover tiles (gemm_f16_kernel<EPI, 256, 1>).  A round of tiles does not get shorter in
+        // proportion to its height -- a stage has a floor of barrier and memory latency whatever its matrix work, prologue and epilogue
+        // do not shrink: measured (tools/tile_time.py, profiles/r06_tile_time.txt) one round of 64-row tiles takes 0.65-0.9 of a round of
+        // 128-row tiles, one of 32-row tiles 0.5-0.78 (deep to shallow reductions).  Priced at 1 : 0.72 : 0.56.
+        const long long left_rows = M - rt_big * big_rows;
+        if (left_rows > 0) {
+            auto rounds = [&](int h) { return ((left_rows + h - 1) / h * p.n_col_tiles + slots - 1) / slots; };
+            const double c_big = (double)rounds(128) * 1.0, c_small = (double)rounds(64) * 0.72, c_tiny = (double)rounds(32) * 0.56;
+            tiny = c_tiny < c_small && c_tiny < c_big;
+            all_big = !tiny && c_big <= c_small && rt_all * p.n_col_tiles >= slots;
+            if (tiny) small_rows = 32;
+        }
+    }
+    if (all_big) rt_big = rt_all;
+    if (tile2 && !wide && (a->tile_rows == -10 || a->tile_rows == -11)) {   // (tools: the whole matrix in 64-row / 32-row tiles -- tile-time calibration)
+        rt_big = 0;
+        tiny = a->tile_rows == -11;
+        small_rows = tiny ? 32 : 64;
+    }
     if (!tile2 && (a->tile_rows == 256 || a->tile_rows == 128)) rt_big = rt_all;
     if (!tile2 && (a->tile_rows == 64 || a->tile_rows == 32)) rt_big = 0;
     const long long rem_rows = M - rt_big * big_rows > 0 ? M - rt_big * big_rows : 0;
@@ -1257,6 +1308,9 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
         rc = epi == 3 ? go(gemm_split_kernel<3, 256, 2, 8, 128>) : epi == 1 ? go(gemm_split_kernel<1, 256, 2, 8, 128>) : go(gemm_split_kernel<0, 256, 2, 8, 128>);
     } else if (wide) {
         rc = epi == 3 ? go(gemm_f16_kernel<3, 512>) : epi == 1 ? go(gemm_f16_kernel<1, 512>) : go(gemm_f16_kernel<0, 512>);
+    } else if (tile2 && tiny) {
+        rc = epi == 3 ? go(gemm_f16_kernel<3, 256, 1>) : epi == 2 ? go(gemm_f16_kernel<2, 256, 1>) : epi == 1 ? go(gemm_f16_kernel<1, 256, 1>)
+                                                                                                          : go(gemm_f16_kernel<0, 256, 1>);
     } else if (tile2) {
         rc = epi == 3 ? go(gemm_f16_kernel<3>) : epi == 2 ? go(gemm_f16_kernel<2>) : epi == 1 ? go(gemm_f16_kernel<1>) : go(gemm_f16_kernel<0>);
     } else if (np == 2) {

@@ -1397,7 +1397,19 @@ __device__ __forceinline__ void seam_out(const RqFwdParams &p, const float *wout
     const f32x4 *img = reinterpret_cast<const f32x4 *>(wout_s);
     int hv = h;
     asm volatile("" : "+v"(hv));
-    for (int blk = blk0; blk < kSeamH / 32; blk += bstep) {
+    // (the ReLU-backward mask of the whole row is requested in front of the first matrix instruction: a load behind the stores of the block
+    // before it waits for those stores -- stores count in vmcnt -- and for its own memory latency, four times per tile)
+    f32x4 msk[kSeamH / 32][4];
+    if (p.sm_epi == 3) {
+#pragma unroll
+        for (int b = 0; b < kSeamH / 32; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                msk[b][g] = *reinterpret_cast<const f32x4 *>(p.sm_omask + (size_t)rowc * kSeamH + 32 * b + 4 * hv + 8 * g);
+    }
+#pragma unroll
+    for (int blk = 0; blk < kSeamH / 32; ++blk) {
+        if (blk < blk0 || (blk - blk0) % bstep != 0) continue;
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < KSTEPS / 4; ++q) {
@@ -1415,7 +1427,7 @@ __device__ __forceinline__ void seam_out(const RqFwdParams &p, const float *wout
                 v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y;
                 v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w;
             } else if (p.sm_epi == 3) {   // threshold_backward(out, omask, 0)
-                const f32x4 m = *reinterpret_cast<const f32x4 *>(p.sm_omask + at + 8 * g);
+                const f32x4 m = msk[blk][g];
                 v.x = m.x <= 0.0f ? 0.0f : v.x; v.y = m.y <= 0.0f ? 0.0f : v.y;
                 v.z = m.z <= 0.0f ? 0.0f : v.z; v.w = m.w <= 0.0f ? 0.0f : v.w;
             }

@@ -446,14 +446,18 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     int ek[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) ek[u] = (NP == 2 && p.x_max) ? ws_exp_of_bits(p.x_max[k0 + wb * 32 * TB + 32 * u + il]) : 0;
+    // (every exponent load in front of the first store: stores count in vmcnt like loads, so a load behind the stores of the block before
+    // it made each 32-row block wait for those 32 stores to be acknowledged -- four write latencies at the end of every workgroup)
+    typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
+    ws_u32x4 gb[TA][4];
 #pragma unroll
-    for (int t = 0; t < TA; ++t) {
-        typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
-        ws_u32x4 gb[4];
+    for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
-            gb[g4] = (NP == 2 && p.g_max) ? *reinterpret_cast<const ws_u32x4 *>(p.g_max + n0 + wa * 32 * TA + 32 * t + 8 * g4 + 4 * h)
-                                          : ws_u32x4{0u, 0u, 0u, 0u};
+            gb[t][g4] = (NP == 2 && p.g_max) ? *reinterpret_cast<const ws_u32x4 *>(p.g_max + n0 + wa * 32 * TA + 32 * t + 8 * g4 + 4 * h)
+                                             : ws_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
 #pragma unroll
         for (int u = 0; u < TB; ++u)
 #pragma unroll
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
                 const int n = n0 + wa * 32 * TA + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
                 const int k = k0 + wb * 32 * TB + 32 * u + il;
                 float v = acc[t][u][r];
-                if constexpr (NP == 2) v = ldexpf(v, ws_exp_of_bits(gb[r >> 2][r & 3]) + ek[u]);   // undo the column scales (exact)
+                if constexpr (NP == 2) v = ldexpf(v, ws_exp_of_bits(gb[t][r >> 2][r & 3]) + ek[u]);   // undo the column scales (exact)
                 dst[(size_t)n * p.K + k] = v;
             }
     }
