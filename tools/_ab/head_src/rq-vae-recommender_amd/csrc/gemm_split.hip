@@ -971,18 +971,27 @@ __global__ __launch_bounds__(64 * WAVES, BIGROWS ? 4 : 2) void gemm_split_kernel
     const bool lds_colmax = p.c_colmax != nullptr && p.Nc <= kGsColmaxLds;
     if (lds_colmax)
         for (int c = tid; c < p.Nc; c += kGsThreads) s_colmax[c] = 0u;
+    // static schedule (round 6, as gemm_f16_kernel; p.static_tiles == 0: the dispenser of rounds 3-5, A/B)
+    unsigned static_next = blockIdx.x;
     for (;;) {
         __syncthreads();                       // (the previous tile's LDS reads are done; s_tile may be rewritten)
-        if (tid == 0) s_tile = atomicAdd(p.counter, 1u);
-        __syncthreads();
-        const unsigned tile = s_tile;
-        if (tile >= p.n_tiles) {
-            // the last workgroup to leave re-arms the dispenser for the next launch (nobody takes a ticket after it)
-            if (tid == 0 && atomicAdd(p.counter + 1, 1u) == gridDim.x - 1) {
-                p.counter[0] = 0u;
-                p.counter[1] = 0u;
+        unsigned tile;
+        if (p.static_tiles) {
+            tile = static_next;
+            static_next += gridDim.x;
+            if (tile >= p.n_tiles) break;
+        } else {
+            if (tid == 0) s_tile = atomicAdd(p.counter, 1u);
+            __syncthreads();
+            tile = s_tile;
+            if (tile >= p.n_tiles) {
+                // the last workgroup to leave re-arms the dispenser for the next launch (nobody takes a ticket after it)
+                if (tid == 0 && atomicAdd(p.counter + 1, 1u) == gridDim.x - 1) {
+                    p.counter[0] = 0u;
+                    p.counter[1] = 0u;
+                }
+                break;
             }
-            break;
         }
         // column tile fastest: the workgroups that share a row tile's A strip run at the same time (L2).  Whole rounds of
         // the chip take big tiles (fewest LDS reads per matrix instruction); what is left over after the last whole
@@ -998,6 +1007,7 @@ __global__ __launch_bounds__(64 * WAVES, BIGROWS ? 4 : 2) void gemm_split_kernel
         }
     }
     if (lds_colmax) {   // (every wave of the workgroup passed the loop's barriers after its last LDS maximum)
+        __syncthreads();
         for (int c = tid; c < p.Nc; c += kGsThreads)
             if (s_colmax[c]) atomicMax(p.c_colmax + c, s_colmax[c]);
     }
@@ -1236,7 +1246,7 @@ extern "C" int rqhip_gemm_split_ex(const rqhip_gemm_args *a, rqhip_stream_t stre
     p.c_rowmax = a->c_row_max; p.c_colmax = a->c_col_max;
     p.n_queues = a->tile_rows == -8 ? kGsQueues : 1;   // (tools: tile_rows = -8 selects the per-XCD dispensers, A/B)
     p.rt_fastest = a->tile_rows == -2 ? 1 : 0;         // (tools: tile_rows = -2: row tile fastest, A/B)
-    p.static_tiles = (a->tile_rows == 0 || a->tile_rows == -9 || a->tile_rows == -10 || a->tile_rows == -11) ? 1 : 0;   // (-12: the dispenser of rounds 4-5, A/B)
+    p.static_tiles = (a->tile_rows == -12 || a->tile_rows == -8 || a->tile_rows == -2) ? 0 : 1;   // (-12: the dispenser of rounds 4-5, A/B)
     // the tile dispenser lives behind the weight image (zeroed by rqhip_weight_images, re-armed by every launch): one
     // GEMM at a time per image, i.e. launches on one stream
     p.counter = const_cast<unsigned *>(p.planes) + (size_t)(R / kGsK) * 2 * np * Nc * 4;
