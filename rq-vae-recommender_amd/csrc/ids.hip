@@ -53,7 +53,8 @@ __global__ void ids_group_kernel(const int64_t *__restrict__ ids, long long B, i
     const unsigned long long m = __ballot(leader);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_distinct, (unsigned long long)__builtin_popcountll(m));
     if (!out && !frac) return;
-    __syncthreads();                                         // (the leaders' atomics of this workgroup are issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's atomics are PERFORMED (acknowledged), not merely issued ...
+    __syncthreads();                                         // ... in every wave of the workgroup, before thread 0 takes the ticket
     if (threadIdx.x == 0) {
         __threadfence();                                     // ONE device-scope release per workgroup, not one per wave
         const unsigned old = atomicAdd(ticket, 1u);          // -1, 0, 1, ...: the last of gridDim.x workgroups sees gridDim.x - 2

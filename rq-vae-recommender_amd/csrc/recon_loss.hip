@@ -265,13 +265,17 @@ __global__ __launch_bounds__(256) void loss_means_blocks_kernel(const float *__r
         }
         __syncthreads();
     }
-    if (t < 3) partial[(size_t)blockIdx.x * 3 + t] = red[t][0];
-    __threadfence();
-    __syncthreads();
-    if (t == 0) s_last = atomicAdd(counter, 1u) == (unsigned)nb - 1;
+    // one device-scope release per WORKGROUP (thread 0: its three stores, the fence, the ticket), one acquire in the last block: a
+    // __threadfence() executed by every wave of every block is a cache write-back + invalidate per wave
+    if (t == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) partial[(size_t)blockIdx.x * 3 + c] = red[c][0];
+        __threadfence();
+        s_last = atomicAdd(counter, 1u) == (unsigned)nb - 1;
+        if (s_last) __threadfence();
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (t < 3) {
         float acc = 0.0f;
         for (int b = 0; b < nb; ++b) acc = acc + __builtin_nontemporal_load(partial + (size_t)b * 3 + t);
