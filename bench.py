@@ -424,6 +424,8 @@ def main():
         for bi, lo in enumerate(range(0, B, micro)):
             _lin.attach_scales(batches[bi].x, x_rows[:, lo:min(B, lo + micro)].contiguous(), x_cols)
 
+    seed_one = torch.ones((), dtype=torch.float32, device=device)
+
     def step():
         reducer.zero_()
         for bi, b in enumerate(batches):
@@ -432,7 +434,8 @@ def main():
             share = b.x.shape[0] / B            # this micro-batch's share of the step's mean loss
             with rq_autograd.loss_scale(share):  # (hint for the speculative reconstruction-loss gradient)
                 out = model(b, gumbel_t=0.2)
-            (out.loss if n_micro == 1 else out.loss * share).backward()
+            # (the seed of the backward as a cached tensor: `backward()` without one fills a fresh ones_like(loss) every step -- a launch)
+            (out.loss if n_micro == 1 else out.loss * share).backward(gradient=seed_one)
         reducer.allreduce_mean()
         opt.step()
         return out

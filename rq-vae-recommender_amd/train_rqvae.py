@@ -111,6 +111,7 @@ class _GraphedStep:
         self.graph = None
         self.captures = 0
         self._model, self._opt, self._reducer, self._t = model, optimizer, reducer, gumbel_t
+        self._seed = torch.ones((), dtype=torch.float32, device=device)
         self.out = None
 
     def _step(self):
@@ -118,7 +119,7 @@ class _GraphedStep:
         self._reducer.zero_()
         out = self._model(SeqBatch(None, None, None, self.x, None, None), gumbel_t=self._t)
         self._reducer.arm()
-        out.loss.backward()
+        out.loss.backward(gradient=self._seed)      # (a cached ones(): `backward()` fills a fresh one every step -- a launch)
         self._reducer.allreduce_mean()     # (one rank: nothing; several: the RCCL all-reduces are part of the captured graph)
         self._opt.step()
         return out
@@ -310,6 +311,7 @@ def train(
 
     rqdist.broadcast_module(model)
     reducer = rqdist.FlatGradReducer(model.parameters()).attach(model)
+    seed_one = None      # the backward's seed, created once on the loss's device
 
     tokenizer = SemanticIdTokenizer(
         input_dim=vae_input_dim, hidden_dims=vae_hidden_dims, output_dim=vae_embed_dim,
@@ -390,7 +392,9 @@ def train(
                     with loss_scale(1.0 / gradient_accumulate_every):   # hint for the speculative recon-loss gradient
                         model_output = model(data, gumbel_t=t)
                     loss = model_output.loss / gradient_accumulate_every
-                    loss.backward()
+                    if seed_one is None or seed_one.device != loss.device:
+                        seed_one = torch.ones((), dtype=torch.float32, device=loss.device)
+                    loss.backward(gradient=seed_one)     # (a cached ones(): `backward()` fills a fresh one every step -- a launch)
                     total_loss = total_loss + loss.detach()
                     # keep only detached values: a live autograd graph from an eager step would pin AccumulateGrad
                     # nodes to the default stream and break the hipGraph capture of a later step
