@@ -13,6 +13,8 @@ and not the bits a fresh maxima pass would give.  No shipped training loop takes
 `use_arith("bf16x3")` keeps round 3's three-piece bf16 kernels for A/B (bench.py --mlp split6)."""
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -245,6 +247,7 @@ def use_wide_tiles(on: bool = True) -> bool:
 
 
 _TINY_TILES = False
+_ROWS_WITH_COLS = True     # (the note in `gemm` below; A/B on one box: 2.5385 vs 2.5456 ms, profiles/r06_step_ab.txt)
 _STATIC_TILES = True
 
 
@@ -396,10 +399,12 @@ def gemm(a: Tensor, image: Tensor, n_cols: int, *, epilogue: int = _lib.EPI_STOR
     `a_scales` or from a pass; the Scales of C hold the row maxima when `want_rows` and `col_out` (a zeroed int32 [n_cols]
     slice that receives the column maxima) when given -- both only in the f16x2 arithmetic (the bf16 path needs none)."""
     rows_in = ensure_scales(a, a_scales, True, False).rows if f16() else None
+    # (a launch that emits column maxima also emits row maxima, wanted or not: the kernel's straight-line epilogue is the form with both --
+    # csrc/gemm_split.hip:gs_epilogue -- and the general loop costs such a launch ~10 %; the extra [column tiles, M] words are dropped)
     c, loss_rows, crm = ops.gemm_split_ex(a, image, n_cols, arith=_ARITH, epilogue=epilogue, aux=aux, row_scale=row_scale,
-                                          a_row_max=rows_in, want_row_max=want_rows and f16(),
+                                          a_row_max=rows_in, want_row_max=(want_rows or (col_out is not None and _ROWS_WITH_COLS)) and f16(),
                                           col_max_out=col_out if f16() else None, tile_rows=_tile_code(n_cols, a.shape[1], epilogue))
-    return c, loss_rows, Scales(crm, col_out if f16() else None)
+    return c, loss_rows, Scales(crm if want_rows else None, col_out if f16() else None)
 
 
 def input_grad(g: Tensor, w: Tensor, *, g_scales: Optional[Scales] = None, image: Optional[Tensor] = None) -> Tensor:
