@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Developer tool: the split-GEMM launches of one configuration-2 training step with their epilogue and maxima flags.
+Usage (GPU box): python tools/gemm_count_launches.py"""
 import sys, os
-ROOT="/root/repo"; sys.path[:0]=[ROOT, ROOT+"/rq-vae-recommender_amd"]
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0]=[ROOT, ROOT+"/rq-vae-recommender_amd"]
 import torch, bench
 from data.schemas import SeqBatch
 from rqhip import ops, dist as rqdist, tuning

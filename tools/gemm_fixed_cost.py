@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Developer tool: what a product-GEMM launch costs beyond its rows -- K = 128 (8 stages), ReLU epilogue, by row count (16 / 128 / 512
+workgroups of one tile each) and by which maxima are emitted.  What pointed at the tile dispenser (profiles/r06_step_ab.txt).
+Usage (GPU box): python tools/gemm_fixed_cost.py"""
 import os, sys, torch
-ROOT = "/root/repo"; sys.path[:0] = [ROOT, ROOT + "/rq-vae-recommender_amd"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, ROOT + "/rq-vae-recommender_amd"]
 from rqhip import _lib, ops
 def timed(fn, n=50):
     for _ in range(5): fn()
