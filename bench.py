@@ -112,6 +112,8 @@ def parse_args():
                          "gradients (round 2's step)")
     ap.add_argument("--wide-tiles", action="store_true", help="A/B (round 6, slower): the 512-column layers on 128 x 512 tiles of 8 waves, one workgroup "
                                                               "per CU, instead of 128 x 256 tiles of two workgroups per CU (profiles/r06_gemm_wide_ab.txt)")
+    ap.add_argument("--no-wgrad-batch", action="store_true", help="A/B: one weight-gradient launch per layer (rounds 3-5) instead of one per MLP stack for the "
+                    "layers tiled 256 x 256")
     ap.add_argument("--dispenser", action="store_true", help="A/B: the product GEMM's tiles from the atomic dispenser of rounds 4-5 instead of the static schedule")
     ap.add_argument("--tiny-tiles", action="store_true", help="A/B (neutral): the product GEMM's leftover tiles 32 rows high where the launch plan prices them cheaper")
     ap.add_argument("--no-seam", action="store_true", help="A/B: the 128 <-> 32 layers either side of the quantiser as in round 5 (library / split GEMMs, "
@@ -402,6 +404,7 @@ def main():
     _lin.use_chain_gemms(not args.no_seam)
     _lin.use_tiny_tiles(args.tiny_tiles)
     _lin.use_static_tiles(not args.dispenser)
+    _lin.use_wgrad_batch(not args.no_wgrad_batch)
     _lin.use_step_trims(not args.no_trims)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)

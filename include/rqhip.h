@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQHIP_VERSION 461 /* 461: rqhip_unique_fraction; 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
+#define RQHIP_VERSION 462 /* 462: rqhip_linear_wgrad_f16_batch; 461: rqhip_unique_fraction; 460: rqhip_linear_small; 450: rqhip_rq_seam (round 6); major*10000 + minor*100 + patch; 200: rqhip_rq_forward gained tie_margin; 300: rqhip_rq_forward_ex; 301: rqhip_gemm_split_recon;
                             400: RQHIP_SPLIT_F16X2 (rqhip_gemm_split_ex, rqhip_weight_images, rqhip_maxima, rqhip_linear_wgrad_f16), tagged profile records */
 
 #define RQHIP_OK 0
@@ -339,6 +339,23 @@ int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_
 int rqhip_linear_wgrad_f16(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                            const unsigned *g_col_max, const unsigned *x_col_max, float *g_masked, float *dW,
                            void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
+/* Several layers' weight gradients in ONE launch (ABI 462): dW_j [N_j, K_j] = g_j^T x_j for 2..4 layers over the same M rows, every dW tiled
+ * 256 x 256 (N_j, K_j multiples of 256), g_j ALREADY masked by its layer's ReLU, f16x2 arithmetic under the column maxima (as
+ * rqhip_linear_wgrad_f16).  The jobs share one number of row ranges (rqhip_linear_wgrad_f16_batch_plan: CUs / tiles of all jobs; 0 = not
+ * batchable), so the launch writes and reduces one workgroup's worth of partial blocks per CU for ALL its layers instead of per layer --
+ * the weight gradients of reference modules/encoder.py:25-38's Linear layers, which autograd forms one by one.  Results are those of
+ * rqhip_linear_wgrad_f16 run with that number of ranges (bit-reproducible; another balanced tree than the per-layer call's). */
+typedef struct {
+    const float *g;              /* [M, N] */
+    const float *x;              /* [M, K] */
+    int N, K;
+    const unsigned *g_col_max;   /* [N] */
+    const unsigned *x_col_max;   /* [K] */
+    float *dW;                   /* [N, K] */
+} rqhip_wgrad_job;
+int rqhip_linear_wgrad_f16_batch_plan(int64_t M, const int *N, const int *K, int n);
+size_t rqhip_linear_wgrad_f16_batch_workspace_bytes(int64_t M, const int *N, const int *K, int n);
+int rqhip_linear_wgrad_f16_batch(const rqhip_wgrad_job *jobs, int n, int64_t M, void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
 
 /* The weight gradients of SEVERAL layers in one launch, for the batch sizes the reference's gin files train with (64-640 rows:
  * configs/rqvae_ml32m.gin, rqvae_amazon.gin), where the kernels above are latency and launches (csrc/wgrad_jobs.hip).  Job i:

@@ -335,6 +335,8 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
 }
 
 int wgrad_split_cfg(int N, int K);   // wgrad_split.hip
+int launch_wgrad_split_jobs(int n, const float *const *g, const float *const *x, long long M, const int *N, const int *K, float *const *out,
+                            int msplit, const unsigned *const *g_max, const unsigned *const *x_max, hipStream_t s);
 int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
                        int nslab_n, int nslab_k, int msplit, const unsigned *g_max, const unsigned *x_max, hipStream_t s);
 
@@ -457,6 +459,92 @@ static int linear_wgrad_impl(const float *g, const float *y, const float *x, int
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + per_wg - 1) / per_wg)), dim3(256), 0, s,
                            reinterpret_cast<const float *>(workspace), pl.msplit, pl.pow2, tlog, nk4, dW);
         RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
+    }
+    profile_end(s);
+    return RQHIP_OK;
+}
+
+// ---- several layers' weight gradients in one launch (rqhip_linear_wgrad_f16_batch; csrc/wgrad_split.hip:wgrad_split_jobs_kernel) ----
+// The common number of row ranges of a batch: the CU count over the tiles of all jobs, a multiple of 8 when there are that many (the
+// kernel then keeps the slabs of one range on one XCD), never more than the 32-row granules of the batch.  0: not batchable (a job
+// that is not tiled 256 x 256, fewer than two or more than four jobs, a batch of at most 128 rows, more tiles than CUs).
+static int wgrad_batch_ranges(long long M, const int *N, const int *K, int n) {
+    if (n < 2 || n > 4 || M <= 128 || !N || !K) return 0;
+    long long tiles = 0;
+    for (int j = 0; j < n; ++j) {
+        if (N[j] <= 0 || K[j] <= 0 || N[j] % 256 != 0 || K[j] % 256 != 0) return 0;
+        tiles += (long long)(N[j] / 256) * (K[j] / 256);
+    }
+    long long ms = cu_count() / tiles;
+    if (ms < 1) return 0;
+    if (ms >= 8) ms &= ~7LL;
+    const long long chunks = (M + kWgChunk - 1) / kWgChunk;
+    if (ms > chunks) ms = chunks;
+    return (int)ms;
+}
+
+extern "C" int rqhip_linear_wgrad_f16_batch_plan(int64_t M, const int *N, const int *K, int n) { return wgrad_batch_ranges(M, N, K, n); }
+
+extern "C" size_t rqhip_linear_wgrad_f16_batch_workspace_bytes(int64_t M, const int *N, const int *K, int n) {
+    const int ms = wgrad_batch_ranges(M, N, K, n);
+    if (ms <= 1) return 16;
+    size_t total = 0;
+    for (int j = 0; j < n; ++j) total += (size_t)ms * N[j] * K[j] * sizeof(float);
+    return total;
+}
+
+extern "C" int rqhip_linear_wgrad_f16_batch(const rqhip_wgrad_job *jobs, int n, int64_t M, void *workspace, size_t workspace_bytes,
+                                            rqhip_stream_t stream) {
+    if (!jobs || n < 2 || n > 4) {
+        set_error("linear_wgrad_f16_batch: 2 to 4 jobs (got %d)", n);
+        return RQHIP_EARG;
+    }
+    int N[4], K[4];
+    const float *g[4], *x[4];
+    const unsigned *gm[4], *xm[4];
+    float *out[4];
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    for (int j = 0; j < n; ++j) {
+        const rqhip_wgrad_job &b = jobs[j];
+        if (!b.g || !b.x || !b.dW || !b.g_col_max || !b.x_col_max || !al16(b.g) || !al16(b.x) || !al16(b.dW)) {
+            set_error("linear_wgrad_f16_batch: job %d: null or misaligned pointer (g, x, dW 16-byte aligned; both column maxima)", j);
+            return RQHIP_EARG;
+        }
+        N[j] = b.N; K[j] = b.K; g[j] = b.g; x[j] = b.x; gm[j] = b.g_col_max; xm[j] = b.x_col_max;
+    }
+    const int ms = wgrad_batch_ranges(M, N, K, n);
+    if (ms < 1) {
+        set_error("linear_wgrad_f16_batch: not batchable (every dW tiled 256 x 256, more than 128 rows, tiles <= CUs: "
+                  "rqhip_linear_wgrad_f16_batch_plan)");
+        return RQHIP_EUNSUPPORTED;
+    }
+    if (ms > 1 && (!workspace || !al16(workspace) || workspace_bytes < rqhip_linear_wgrad_f16_batch_workspace_bytes(M, N, K, n))) {
+        set_error("linear_wgrad_f16_batch: workspace too small (rqhip_linear_wgrad_f16_batch_workspace_bytes)");
+        return RQHIP_EWORKSPACE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float *part = reinterpret_cast<float *>(workspace);
+    double flops = 0.0, bytes = 0.0;
+    for (int j = 0; j < n; ++j) {
+        out[j] = ms > 1 ? part : jobs[j].dW;
+        part += (size_t)ms * N[j] * K[j];
+        flops += 2.0 * (double)M * N[j] * K[j];
+        bytes += 4.0 * (double)M * (N[j] + K[j]);
+    }
+    profile_begin(s, RQHIP_PROF_WGRAD, flops, bytes);
+    int rc = launch_wgrad_split_jobs(n, g, x, M, N, K, out, ms, gm, xm, s);
+    if (rc) { profile_end(s); return rc; }
+    if (ms > 1) {
+        int pow2 = 1;
+        while (pow2 < ms) pow2 <<= 1;
+        for (int j = 0; j < n; ++j) {       // the same balanced tree over a job's partial blocks as rqhip_linear_wgrad_f16's
+            const size_t nk4 = (size_t)N[j] * K[j] / 4;
+            const int tlog = wgrad_reduce_tlog(nk4, pow2);
+            const size_t per_wg = (size_t)256 >> tlog;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + per_wg - 1) / per_wg)), dim3(256), 0, s, out[j], ms, pow2, tlog, nk4,
+                               jobs[j].dW);
+            RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
+        }
     }
     profile_end(s);
     return RQHIP_OK;

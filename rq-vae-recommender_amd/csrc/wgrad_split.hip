@@ -100,8 +100,9 @@ __device__ __forceinline__ void ws_await(ws_f32x4 (&r)[4]) {
 }
 
 // TA x TB tiles per wave, WA x WB waves per workgroup; MASK: y given; NP: pieces per operand (3 bf16 / 2 fp16 under column scales)
+// (the body of a workgroup: `block` is its number inside ITS launch or, in the job-table launch below, inside its job)
 template <int TA, int TB, int WA, int WB, bool MASK, int NP>
-__global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSplitParams p) {
+__device__ __forceinline__ void wgrad_split_body(const WgradSplitParams &p, const int block) {
     constexpr int Nt = 32 * TA * WA, Kt = 32 * TB * WB, NT = 64 * WA * WB;
     constexpr int UNITS = Nt + Kt;                 // staging units of 4 rows x 4 columns per stage: Nt for g, Kt for x
     constexpr int UQ = (UNITS + NT - 1) / NT;      // per thread
@@ -121,12 +122,12 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     const int nslabs = p.nslab_n * p.nslab_k;
     int slab, split;
     if ((p.msplit & 7) == 0) {   // slabs of one row range back to back on one XCD (they share its strips in that L2)
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = block & 7, j = block >> 3;
         slab = j % nslabs;
         split = (j / nslabs) * 8 + xcd;
     } else {
-        slab = blockIdx.x % nslabs;
-        split = blockIdx.x / nslabs;
+        slab = block % nslabs;
+        split = block / nslabs;
     }
     const int slab_n = slab / p.nslab_k, slab_k = slab % p.nslab_k;
     const int n0 = slab_n * Nt, k0 = slab_k * Kt;
@@ -471,6 +472,37 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSp
     }
 }
 
+template <int TA, int TB, int WA, int WB, bool MASK, int NP>
+__global__ __launch_bounds__(64 * WA * WB) void wgrad_split_kernel(const WgradSplitParams p) {
+    wgrad_split_body<TA, TB, WA, WB, MASK, NP>(p, (int)blockIdx.x);
+}
+
+// ---- several layers in ONE launch (round 6): the weight gradients of up to four layers whose dW is tiled 256 x 256, all cut into the SAME
+// number of row ranges.  What a launch costs beyond its rows is its partial blocks -- one 256 KB block per workgroup, written at the end of the
+// kernel and read again by the reduction: 67 MB + 67 MB whatever the layer -- and a launch fills the chip only by cutting its rows until
+// tiles x ranges reaches the CU count (dW [512, 768]: 6 x 40; dW [256, 512]: 2 x 128).  Two layers in one launch fill it with HALF the ranges
+// each (8 tiles x 32 ranges), i.e. half the partial-block bytes of the two launches, ranges four times as long for the small layer, one
+// prologue / flush phase instead of two.  Same kernel body, same bits for a given number of ranges.
+constexpr int kWsMaxJobs = 4;
+struct WgradSplitJobs {
+    WgradSplitParams p[kWsMaxJobs];
+    int first[kWsMaxJobs];     // first workgroup of job j (a multiple of 8 whenever the range count is)
+    int n;
+};
+template <int TA, int TB, int WA, int WB, int NP>
+__global__ __launch_bounds__(64 * WA * WB) void wgrad_split_jobs_kernel(const WgradSplitJobs jobs) {
+    // (uniform selects of scalar kernel arguments: indexing the array with a run-time value would move it to scratch)
+    WgradSplitParams p = jobs.p[0];
+    int first = 0;
+#pragma unroll
+    for (int j = 1; j < kWsMaxJobs; ++j)
+        if (j < jobs.n && (int)blockIdx.x >= jobs.first[j]) {
+            p = jobs.p[j];
+            first = jobs.first[j];
+        }
+    wgrad_split_body<TA, TB, WA, WB, false, NP>(p, (int)blockIdx.x - first);
+}
+
 // shapes the split kernel tiles: both dimensions multiples of 128 (every large layer of the 768-512-256-128 MLPs)
 int wgrad_split_cfg(int N, int K) {
     if (N % 256 == 0 && K % 256 == 0) return 0;
@@ -516,6 +548,33 @@ int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, 
         case 1: return wgrad_split_go<2, 2, 2, 4, 3>(p, mask, s);
         default: return wgrad_split_go<2, 2, 4, 2, 3>(p, mask, s);
     }
+}
+
+// The job-table launch: every job 256 x 256 tiles, f16x2 arithmetic, no mask, `msplit` row ranges each; out_j = job j's partial blocks
+// [msplit][N_j][K_j] (or dW itself when msplit == 1).
+int launch_wgrad_split_jobs(int n, const float *const *g, const float *const *x, long long M, const int *N, const int *K, float *const *out,
+                            int msplit, const unsigned *const *g_max, const unsigned *const *x_max, hipStream_t s) {
+    WgradSplitJobs jobs;
+    jobs.n = n;
+    int blocks = 0;
+    for (int j = 0; j < kWsMaxJobs; ++j) {
+        const int i = j < n ? j : 0;
+        WgradSplitParams &p = jobs.p[j];
+        p.g = g[i]; p.y = nullptr; p.x = x[i]; p.gm = nullptr; p.out = out[i];
+        p.M = M; p.N = N[i]; p.K = K[i]; p.nslab_n = N[i] / 256; p.nslab_k = K[i] / 256; p.msplit = msplit;
+        p.n_chunks = (M + 31) / 32;
+        p.g_max = g_max[i]; p.x_max = x_max[i];
+        jobs.first[j] = blocks;
+        if (j < n) blocks += p.nslab_n * p.nslab_k * msplit;
+    }
+    constexpr int TA = 4, TB = 2, WA = 2, WB = 4, NP = 2, Nt = 32 * TA * WA, Kt = 32 * TB * WB;
+    const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * NP * 2 * 16;
+    auto kern = wgrad_split_jobs_kernel<TA, TB, WA, WB, NP>;
+    static LdsGrant grant;
+    RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WA * WB), lds, s, jobs);
+    RQ_CHECK_LAUNCH("wgrad_split_jobs_kernel");
+    return 0;
 }
 
 }  // namespace rqhip

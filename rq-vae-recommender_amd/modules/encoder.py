@@ -189,6 +189,9 @@ class _MLPStack(torch.autograd.Function):
         # (csrc/wgrad_jobs.hip; same bits as the per-layer path, which runs the same kernel with one job)
         deferred = g.is_cuda and _lin.wgrad_jobs_ok(g.shape[0], [tuple(w.shape) for i, w in enumerate(weights) if need_w[i]])
         pending = []
+        # split-kernel batches: the weight gradients of the layers tiled 256 x 256 whose gradient arrives masked wait for ONE launch at the
+        # end of the stack (rqhip_linear_wgrad_f16_batch: one workgroup's partial block per CU for all of them instead of per layer)
+        batched = []
         for i in range(n - 1, -1, -1):
             w, a = weights[i], acts[i]
             y = acts[i + 1] if (relus[i] and not premasked) else None
@@ -200,6 +203,9 @@ class _MLPStack(torch.autograd.Function):
                 if y is not None:
                     g, gsc = torch.ops.aten.threshold_backward(g, y, 0.0), _lin.Scales()
                 pending.append((i, g, a, _grad_sink(w)))
+            elif need_w[i] and y is None and g.is_cuda and wg_f16[i] and _lin.wgrad_batch_shape_ok(w.shape[0], w.shape[1], g.shape[0]):
+                gsc = _lin.ensure_scales(g, gsc, False, True)
+                batched.append((i, g, a, gsc.cols, _lin.ensure_scales(a, scs[i], False, True).cols, _grad_sink(w)))
             elif need_w[i]:
                 sink = _grad_sink(w)
                 gw, g, gsc = _lin.weight_grad(g, y, a, w, out=sink, want_masked=need_in[i] and not mask_on_load, g_scales=gsc,
@@ -241,6 +247,17 @@ class _MLPStack(torch.autograd.Function):
             else:
                 g, gsc = g.mm(w), _lin.Scales()
                 premasked = not lower_relu
+        if batched:
+            M = batched[0][1].shape[0]
+            if len(batched) >= 2 and ops.linear_wgrad_f16_batch_ranges(M, [tuple(weights[i].shape) for i, *_ in batched]) >= 1:
+                dws = ops.linear_wgrad_f16_batch([(gm, a, gc, xc) for _, gm, a, gc, xc, _ in batched], outs=[sk for *_, sk in batched])
+                for (i, *_, sk), gw in zip(batched, dws):
+                    gws[i] = _adopt(gw, sk)
+            else:
+                for i, gm, a, gc, xc, sk in batched:
+                    gw, _, _ = _lin.weight_grad(gm, None, a, weights[i], out=sk, want_masked=False, g_scales=_lin.Scales(None, gc),
+                                                x_scales=_lin.Scales(None, xc), premasked=True)
+                    gws[i] = _adopt(gw, sk)
         if pending:
             outs = [sk if sk is not None else torch.empty_like(weights[i]) for (i, _, _, sk) in pending]
             for (i, _, _, sk), gw in zip(pending, ops.linear_wgrad_jobs([(gm, a) for _, gm, a, _ in pending], outs=outs)):

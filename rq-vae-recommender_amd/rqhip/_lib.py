@@ -48,6 +48,11 @@ class GemmArgs(C.Structure):          # rqhip_gemm_args
                 ("c_row_max", C.c_void_p), ("c_col_max", C.c_void_p)]
 
 
+class WgradJob(C.Structure):          # rqhip_wgrad_job
+    _fields_ = [("g", C.c_void_p), ("x", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("g_col_max", C.c_void_p),
+                ("x_col_max", C.c_void_p), ("dW", C.c_void_p)]
+
+
 class ProfileRecord(C.Structure):     # rqhip_profile_record
     _fields_ = [("tag", C.c_int), ("ms", C.c_float), ("flops", C.c_double), ("bytes", C.c_double)]
 
@@ -104,6 +109,9 @@ SIGNATURES = {
     "rqhip_linear_wgrad": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "rqhip_linear_wgrad_ex": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, C.c_uint, _vp]),
     "rqhip_linear_wgrad_f16": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rqhip_linear_wgrad_f16_batch_plan": (_int, [_i64, C.POINTER(_int), C.POINTER(_int), _int]),
+    "rqhip_linear_wgrad_f16_batch_workspace_bytes": (_sz, [_i64, C.POINTER(_int), C.POINTER(_int), _int]),
+    "rqhip_linear_wgrad_f16_batch": (_int, [C.POINTER(WgradJob), _int, _i64, _vp, _sz, _vp]),
     "rqhip_linear_wgrad_jobs_supported": (_int, [_int, _int]),
     "rqhip_linear_wgrad_jobs": (_int, [_vp, _vp, _vp, C.POINTER(_int), C.POINTER(_int), _int, _i64, _vp]),
     "rqhip_gemm_split_supported": (_int, [_int, _int]),

@@ -211,6 +211,23 @@ def wgrad_f16_ok(n_out: int, n_in: int, rows: int = _SPLIT_MIN_ROWS) -> bool:
     return bool(f16() and rows >= _SPLIT_MIN_ROWS and n_out % 128 == 0 and n_in % 128 == 0 and (n_out % 256 == 0 or n_in % 256 == 0))
 
 
+_WGRAD_BATCH = True
+
+
+def use_wgrad_batch(on: bool = True) -> bool:
+    """A/B (round 6): at split-kernel batch sizes the weight gradients of an MLP stack's 256 x 256-tiled layers in ONE launch
+    (rqhip_linear_wgrad_f16_batch: half the partial-block traffic of two launches; default) or one launch per layer.  Returns the
+    previous setting."""
+    global _WGRAD_BATCH
+    before, _WGRAD_BATCH = _WGRAD_BATCH, bool(on)
+    return before
+
+
+def wgrad_batch_shape_ok(n_out: int, n_in: int, rows: int) -> bool:
+    """May this layer's weight gradient wait for the stack's batched launch?"""
+    return bool(_WGRAD_BATCH and wgrad_f16_ok(n_out, n_in, rows) and n_out % 256 == 0 and n_in % 256 == 0)
+
+
 _WGRAD_JOBS = True
 
 

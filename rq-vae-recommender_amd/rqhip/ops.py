@@ -726,6 +726,52 @@ def linear_wgrad(g: Tensor, y: Optional[Tensor], x: Tensor, *, want_masked: bool
     return dw, (g if y is None else gm)
 
 
+def linear_wgrad_f16_batch_ranges(M: int, shapes) -> int:
+    """The common number of row ranges rqhip_linear_wgrad_f16_batch would cut `shapes` = [(N, K), ...] into over M rows; 0 = not batchable
+    (2..4 layers, every dW tiled 256 x 256, more than 128 rows)."""
+    n = len(shapes)
+    if n < 2 or n > 4:
+        return 0
+    ci = C.c_int * n
+    return int(_lib.lib().rqhip_linear_wgrad_f16_batch_plan(int(M), ci(*[int(a) for a, _ in shapes]), ci(*[int(b) for _, b in shapes]), n))
+
+
+def linear_wgrad_f16_batch(jobs, outs=None):
+    """The weight gradients of 2..4 layers in ONE launch (rqhip_linear_wgrad_f16_batch): `jobs` = [(g [M, N_j] already masked by the layer's
+    ReLU, x [M, K_j], g_col_max int32 [N_j], x_col_max int32 [K_j]), ...], every dW tiled 256 x 256; `outs[j]`: a contiguous fp32
+    [N_j, K_j] tensor to receive dW_j (or None).  Returns [dW_j]."""
+    n = len(jobs)
+    gs = [_f32c(j[0], "g") for j in jobs]
+    xs = [_f32c(j[1], "x") for j in jobs]
+    _need_gpu(*gs, *xs, *[j[2] for j in jobs], *[j[3] for j in jobs])
+    M, dev = gs[0].shape[0], gs[0].device
+    shapes = [(g.shape[1], x.shape[1]) for g, x in zip(gs, xs)]
+    for i, (g, x, gm, xm) in enumerate(zip(gs, xs, [j[2] for j in jobs], [j[3] for j in jobs])):
+        if (g.dim() != 2 or x.dim() != 2 or g.shape[0] != M or x.shape[0] != M or gm.dtype != torch.int32 or xm.dtype != torch.int32
+                or gm.numel() != g.shape[1] or xm.numel() != x.shape[1] or not gm.is_contiguous() or not xm.is_contiguous()):
+            raise RqHipError(f"linear_wgrad_f16_batch: job {i}: g {tuple(g.shape)}, x {tuple(x.shape)}, maxima int32 [N] / [K]; one M")
+    if linear_wgrad_f16_batch_ranges(M, shapes) < 1:
+        raise RqHipError(f"linear_wgrad_f16_batch: {shapes} over {M} rows is not batchable (linear_wgrad_f16_batch_ranges)")
+    with torch.cuda.device(dev):
+        l = _lib.lib()
+        dws = []
+        for i, (N, K) in enumerate(shapes):
+            out = outs[i] if outs is not None else None
+            if out is not None and (tuple(out.shape) != (N, K) or out.dtype != torch.float32 or not out.is_contiguous()):
+                raise RqHipError("linear_wgrad_f16_batch: `outs[j]` must be a contiguous float32 [N, K] tensor")
+            dws.append(out if out is not None else torch.empty((N, K), dtype=torch.float32, device=dev))
+        ci = C.c_int * n
+        Ns, Ks = ci(*[a for a, _ in shapes]), ci(*[b for _, b in shapes])
+        wsb = l.rqhip_linear_wgrad_f16_batch_workspace_bytes(M, Ns, Ks, n)
+        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+        arr = (_lib.WgradJob * n)()
+        for i in range(n):
+            arr[i].g, arr[i].x, arr[i].N, arr[i].K = gs[i].data_ptr(), xs[i].data_ptr(), shapes[i][0], shapes[i][1]
+            arr[i].g_col_max, arr[i].x_col_max, arr[i].dW = jobs[i][2].data_ptr(), jobs[i][3].data_ptr(), dws[i].data_ptr()
+        check(l.rqhip_linear_wgrad_f16_batch(arr, n, M, _ptr(ws), wsb, _stream()), "rqhip_linear_wgrad_f16_batch")
+    return dws
+
+
 def linear_wgrad_jobs_supported(n_out: int, n_in: int) -> bool:
     return bool(_lib.lib().rqhip_linear_wgrad_jobs_supported(int(n_out), int(n_in)))
 

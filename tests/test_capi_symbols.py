@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol_and_binding_covers_them():
 def test_version_and_error_string_without_gpu():
     from rqhip import _lib
     l = _lib.lib()
-    assert l.rqhip_version() == 461
+    assert l.rqhip_version() == 462
     # argument validation happens before any HIP call, so it is testable on a CPU-only box
     rc = l.rqhip_rq_forward(None, 4, 32, None, 3, 256, 1, 0.25, None, None, None, None, None, None, None, None, 0, None)
     assert rc == -1

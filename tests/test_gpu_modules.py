@@ -547,6 +547,9 @@ def test_mlp_stack_node_equals_the_per_layer_functions_bit_for_bit(arith, rows):
     from modules.encoder import MLP
     from rqhip import linear
     before = linear.use_arith(arith)
+    # (the node's batched weight-gradient launch cuts its layers into another number of row ranges than the per-layer launches: same
+    # arithmetic, another balanced tree over the partial blocks -- compared at rounding level below, and off for the bit comparison)
+    batch_before = linear.use_wgrad_batch(False)
     try:
         torch.manual_seed(5)
         mlp = MLP(768, [512, 256, 128], 32).cuda()
@@ -577,8 +580,20 @@ def test_mlp_stack_node_equals_the_per_layer_functions_bit_for_bit(arith, rows):
             outs.append([y.detach().clone()] + [p.grad.clone() for p in dec.parameters()] + [z.grad.clone()])
         for u, v in zip(*outs):
             assert torch.equal(u, v)
+        if rows >= 4096 and arith == "f16x2":
+            linear.use_wgrad_batch(True)
+            for p in dec.parameters():
+                p.grad = None
+            z.grad = None
+            y = dec._run(z, list(dec.mlp))
+            y.backward(g2)
+            batched = [y.detach().clone()] + [p.grad.clone() for p in dec.parameters()] + [z.grad.clone()]
+            for u, v in zip(batched, outs[0]):
+                assert (u - v).abs().max().item() <= 4e-6 * v.abs().max().item() + 1e-12
+            assert torch.equal(batched[0], outs[0][0]) and torch.equal(batched[-1], outs[0][-1])     # (outputs and input gradient: untouched)
     finally:
         linear.use_arith(before)
+        linear.use_wgrad_batch(batch_before)
 
 
 def _rqvae_768(seed=0):

@@ -202,6 +202,38 @@ def test_wgrad_f16_operand_families_vs_fp64(N, K):
     assert (dw.double() - ref).abs().max().item() <= max((gp.t().mm(x).double() - ref).abs().max().item(), 2e-7 * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M", [100_000, 4100, 129])
+@pytest.mark.parametrize("shapes", [[(768, 512), (512, 256)], [(512, 768), (256, 512)], [(256, 256), (256, 256), (512, 256), (256, 512)]])
+def test_wgrad_f16_batch_vs_fp64_and_per_layer(M, shapes):
+    """rqhip_linear_wgrad_f16_batch: the weight gradients of 2..4 layers tiled 256 x 256 in one launch, all cut into the plan's common number
+    of row ranges.  Every dW is no further from fp64 than the library's fp32 GEMM of the same product (the gate of the per-layer kernel),
+    agrees with the per-layer call to fp32 rounding of the sum, repeats bit for bit, lands in `outs`; shapes that are not batchable raise."""
+    from rqhip import ops
+    g0 = torch.Generator().manual_seed(M + len(shapes))
+    jobs, refs = [], []
+    for N, K in shapes:
+        g = (torch.randn(M, N, generator=g0) * 0.3 * torch.relu(torch.randn(M, N, generator=g0)).sign()).cuda()   # (already masked: ~half zeros)
+        x = torch.randn(M, K, generator=g0).cuda()
+        jobs.append((g, x, ops.maxima(g, rows=False)[1], ops.maxima(x, rows=False)[1]))
+        refs.append(g.double().t().mm(x.double()))
+    ms = ops.linear_wgrad_f16_batch_ranges(M, shapes)
+    assert ms >= 1
+    outs = [torch.full((N, K), float("nan"), device="cuda") for N, K in shapes]
+    dws = ops.linear_wgrad_f16_batch(jobs, outs=outs)
+    again = ops.linear_wgrad_f16_batch(jobs)
+    for (g, x, gc, xc), dw, dw2, out, ref in zip(jobs, dws, again, outs, refs):
+        assert dw.data_ptr() == out.data_ptr() and torch.equal(dw, dw2)
+        lib = (g.t().mm(x).double() - ref).abs().max().item()
+        err = (dw.double() - ref).abs().max().item()
+        assert err <= max(lib, 2e-7 * ref.abs().max().item()), (err, lib)
+        single = ops.linear_wgrad(g, None, x, g_col_max=gc, x_col_max=xc)[0]
+        assert (dw - single).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert ops.linear_wgrad_f16_batch_ranges(M, [(768, 512)]) == 0 and ops.linear_wgrad_f16_batch_ranges(M, [(768, 512), (256, 128)]) == 0
+    assert ops.linear_wgrad_f16_batch_ranges(64, shapes) == 0
+    with pytest.raises(ops.RqHipError):
+        ops.linear_wgrad_f16_batch(jobs[:1])
+
+
 @pytest.mark.parametrize("rows", [5000, 640, 64])
 def test_mlp_backward_matches_torch_autograd(rows):
     """The module path (modules/encoder.py) with the fused kernels vs the same MLP as plain torch ops: a batch the split kernels
