@@ -112,6 +112,8 @@ def parse_args():
                          "gradients (round 2's step)")
     ap.add_argument("--wide-tiles", action="store_true", help="A/B (round 6, slower): the 512-column layers on 128 x 512 tiles of 8 waves, one workgroup "
                                                               "per CU, instead of 128 x 256 tiles of two workgroups per CU (profiles/r06_gemm_wide_ab.txt)")
+    ap.add_argument("--no-cross-stack", action="store_true", help="A/B: the decoder's batched weight gradients launched with the decoder's backward instead of "
+                    "waiting for the encoder's launch")
     ap.add_argument("--no-wgrad-batch", action="store_true", help="A/B: one weight-gradient launch per layer (rounds 3-5) instead of one per MLP stack for the "
                     "layers tiled 256 x 256")
     ap.add_argument("--dispenser", action="store_true", help="A/B: the product GEMM's tiles from the atomic dispenser of rounds 4-5 instead of the static schedule")
@@ -405,6 +407,7 @@ def main():
     _lin.use_tiny_tiles(args.tiny_tiles)
     _lin.use_static_tiles(not args.dispenser)
     _lin.use_wgrad_batch(not args.no_wgrad_batch)
+    _lin.use_wgrad_cross_stack(not args.no_cross_stack)
     _lin.use_step_trims(not args.no_trims)
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.empty((B, INPUT_DIM), device=device)

@@ -153,6 +153,7 @@ class _MLPStack(torch.autograd.Function):
         ctx.acts_mid, ctx.scs, ctx.relus = (acts[1:] if ctx.has_target else acts[1:-1]), scs, tuple(relus)
         ctx.img_t, ctx.dg_split, ctx.wg_f16, ctx.need_in, ctx.need_w, ctx.chain = img_t, dg_split, wg_f16, need_in, need_w, chain
         ctx.small = small
+        ctx.defer = _lin.take_defer_flag()
         ctx.g_recon, ctx.g_scales, ctx.consumed = g_recon, g_scales, False
         return out
 
@@ -247,17 +248,30 @@ class _MLPStack(torch.autograd.Function):
             else:
                 g, gsc = g.mm(w), _lin.Scales()
                 premasked = not lower_relu
-        if batched:
-            M = batched[0][1].shape[0]
-            if len(batched) >= 2 and ops.linear_wgrad_f16_batch_ranges(M, [tuple(weights[i].shape) for i, *_ in batched]) >= 1:
-                dws = ops.linear_wgrad_f16_batch([(gm, a, gc, xc) for _, gm, a, gc, xc, _ in batched], outs=[sk for *_, sk in batched])
-                for (i, *_, sk), gw in zip(batched, dws):
-                    gws[i] = _adopt(gw, sk)
+        waiting = _lin.xstack_take() if g_out.is_cuda else []      # an earlier stack's weight gradients that waited for this launch
+        if batched or waiting:
+            M = g_out.shape[0]
+            sunk = all(sk is not None for *_, sk in batched)
+            if batched and not waiting and ctx.defer and sunk and _lin.xstack_ok():
+                # (this stack's turn to wait: a later node, or the engine's end-of-backward callback, launches them into the flat buffer)
+                _lin.xstack_push([(weights[i], gm, a, gc, xc, sk) for i, gm, a, gc, xc, sk in batched])
+                for i, *_, sk in batched:
+                    gws[i] = _adopt(sk, sk)
+            elif sunk:
+                _lin._launch_wgrads(waiting + [(weights[i], gm, a, gc, xc, sk) for i, gm, a, gc, xc, sk in batched])
+                for i, *_, sk in batched:
+                    gws[i] = _adopt(sk, sk)
             else:
-                for i, gm, a, gc, xc, sk in batched:
-                    gw, _, _ = _lin.weight_grad(gm, None, a, weights[i], out=sk, want_masked=False, g_scales=_lin.Scales(None, gc),
-                                                x_scales=_lin.Scales(None, xc), premasked=True)
-                    gws[i] = _adopt(gw, sk)
+                _lin._launch_wgrads(waiting)
+                if len(batched) >= 2 and ops.linear_wgrad_f16_batch_ranges(M, [tuple(weights[i].shape) for i, *_ in batched]) >= 1:
+                    dws = ops.linear_wgrad_f16_batch([(gm, a, gc, xc) for _, gm, a, gc, xc, _ in batched], outs=[sk for *_, sk in batched])
+                    for (i, *_, sk), gw in zip(batched, dws):
+                        gws[i] = _adopt(gw, sk)
+                else:
+                    for i, gm, a, gc, xc, sk in batched:
+                        gw, _, _ = _lin.weight_grad(gm, None, a, weights[i], out=sk, want_masked=False, g_scales=_lin.Scales(None, gc),
+                                                    x_scales=_lin.Scales(None, xc), premasked=True)
+                        gws[i] = _adopt(gw, sk)
         if pending:
             outs = [sk if sk is not None else torch.empty_like(weights[i]) for (i, _, _, sk) in pending]
             for (i, _, _, sk), gw in zip(pending, ops.linear_wgrad_jobs([(gm, a) for _, gm, a, _ in pending], outs=outs)):
@@ -310,7 +324,11 @@ class MLP(nn.Module):
             i += 2 if relu else 1
         if weights:
             _lin.handoff_scales(_lin.attached_scales(x))
-            x = _MLPStack.apply(x, target, tuple(relus), self._zero_bias, *weights)
+            _lin.mark_next_stack_defers(getattr(self, "_defer_wgrads", False))
+            try:
+                x = _MLPStack.apply(x, target, tuple(relus), self._zero_bias, *weights)
+            finally:
+                _lin.mark_next_stack_defers(False)
         return self._run_layerwise(x, layers[i:]) if i < len(layers) else x
 
     def _run_layerwise(self, x: Tensor, layers) -> Tensor:

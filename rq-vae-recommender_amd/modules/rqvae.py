@@ -111,6 +111,8 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         self.encoder = MLP(input_dim=input_dim, hidden_dims=hidden_dims, out_dim=embed_dim,
                            normalize=codebook_normalize)
         self.decoder = MLP(input_dim=embed_dim, hidden_dims=hidden_dims[::-1], out_dim=input_dim, normalize=False)
+        # (the decoder's backward runs before the encoder's: its batched weight gradients may wait for the encoder's launch, rqhip/linear.py)
+        self.decoder._defer_wgrads = True
         self.reconstruction_loss = (CategoricalReconstuctionLoss(n_cat_features) if n_cat_features != 0
                                     else ReconstructionLoss())
 
@@ -221,6 +223,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         reducer = getattr(self, "_rq_reducer", None)
         n = self.n_cat_feats
         seam = self._seam_weights(xin)
+        _lin._XSTACK.clear()       # (weight gradients of a backward pass that ended in an exception do not outlive it)
         reconstruction = x_hat = p_unique_ids = side = None
         if seam is not None:
             # the seam: the encoder up to its last hidden activation, then ONE launch for the last encoder Linear, every level and the

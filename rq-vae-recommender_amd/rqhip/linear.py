@@ -223,6 +223,70 @@ def use_wgrad_batch(on: bool = True) -> bool:
     return before
 
 
+# ---- ... and of TWO stacks in one launch: the decoder's wait for the encoder's (single rank, eager, gradients in a flat buffer) ----------
+# The decoder's backward runs first; its 256 x 256-tiled weight gradients (with the encoder's: 16 tiles x 16 row ranges instead of twice
+# 8 x 32) are launched at the end of the encoder stack's backward, or by a callback the autograd engine runs when the backward pass ends
+# (an encoder without gradients, a stack used on its own).  What the decoder's node returns for those weights meanwhile is the parameter's
+# slice of the flat gradient buffer (rqhip/dist.py:claim_grad_sink), which the launch fills before anything on the stream reads it.  NOT
+# with several ranks: the decoder's gradients go on the wire under the encoder's backward there (FlatGradReducer.boundary_hook).
+_XSTACK_ON = True
+_XSTACK: List[tuple] = []            # (w, g, x, g_cols, x_cols, sink) waiting for a later stack of the same backward pass
+_DEFER_NEXT = [False]
+
+
+def use_wgrad_cross_stack(on: bool = True) -> bool:
+    """A/B (round 6): the decoder's batched weight gradients wait for the encoder's launch (default) or are launched per stack."""
+    global _XSTACK_ON
+    before, _XSTACK_ON = _XSTACK_ON, bool(on)
+    return before
+
+
+def mark_next_stack_defers(on: bool = True) -> None:
+    """modules/encoder.py:MLP._run for a module tagged `_defer_wgrads` (RqVae's decoder): the stack node created next may hand its
+    batched weight gradients to a later node's launch."""
+    _DEFER_NEXT[0] = bool(on)
+
+
+def take_defer_flag() -> bool:
+    f, _DEFER_NEXT[0] = _DEFER_NEXT[0], False
+    return f
+
+
+def xstack_ok() -> bool:
+    from . import dist as _dist
+    return bool(_XSTACK_ON and _WGRAD_BATCH and _dist.world_size() == 1 and not torch.cuda.is_current_stream_capturing())
+
+
+def _launch_wgrads(jobs: List[tuple]) -> None:
+    """jobs = [(w, g, x, g_cols, x_cols, sink), ...]: one batched launch where the plan allows (at most 4 per launch), else per layer."""
+    while jobs:
+        take, jobs = jobs[:4], jobs[4:]
+        M = take[0][1].shape[0]
+        if len(take) >= 2 and ops.linear_wgrad_f16_batch_ranges(M, [tuple(w.shape) for w, *_ in take]) >= 1:
+            ops.linear_wgrad_f16_batch([(g, x, gc, xc) for _, g, x, gc, xc, _ in take], outs=[sk for *_, sk in take])
+        else:
+            for w, g, x, gc, xc, sk in take:
+                weight_grad(g, None, x, w, out=sk, want_masked=False, g_scales=Scales(None, gc), x_scales=Scales(None, xc), premasked=True)
+
+
+def xstack_flush() -> None:
+    """Launch whatever still waits (the engine's end-of-backward callback; also the start of every training forward, defensively)."""
+    if _XSTACK:
+        jobs, _XSTACK[:] = list(_XSTACK), []
+        _launch_wgrads(jobs)
+
+
+def xstack_push(jobs: List[tuple]) -> None:
+    if not _XSTACK:
+        torch.autograd.Variable._execution_engine.queue_callback(xstack_flush)
+    _XSTACK.extend(jobs)
+
+
+def xstack_take() -> List[tuple]:
+    jobs, _XSTACK[:] = list(_XSTACK), []
+    return jobs
+
+
 def wgrad_batch_shape_ok(n_out: int, n_in: int, rows: int) -> bool:
     """May this layer's weight gradient wait for the stack's batched launch?"""
     return bool(_WGRAD_BATCH and wgrad_f16_ok(n_out, n_in, rows) and n_out % 256 == 0 and n_in % 256 == 0)

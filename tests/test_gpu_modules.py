@@ -499,6 +499,52 @@ def test_flat_reducer_attach_puts_gradients_in_the_flat_buffer_without_copies():
             assert torch.equal(p.grad, q.grad), name
 
 
+@pytest.mark.parametrize("frozen_encoder", [False, True])
+def test_batched_weight_gradients_across_the_two_stacks(frozen_encoder, monkeypatch):
+    """rqhip/linear.py: at a split-kernel batch the 256 x 256-tiled weight gradients of the decoder wait for the encoder's launch (ONE
+    rqhip_linear_wgrad_f16_batch of four layers, gradients in the flat buffer); with the encoder frozen the autograd engine's end-of-backward
+    callback launches the decoder's two.  Every gradient agrees with the per-layer launches to rounding of the sums, the loss is the same
+    bits, nothing is left waiting."""
+    from data.schemas import SeqBatch
+    from rqhip import linear, ops
+    from rqhip.dist import FlatGradReducer
+    x = torch.nn.functional.normalize(torch.randn(8192, 768, device="cuda"), dim=-1)
+    batch = SeqBatch(None, None, None, x, None, None)
+    calls = []
+    real = ops.linear_wgrad_f16_batch
+
+    def counting(jobs, outs=None):
+        calls.append(len(jobs))
+        return real(jobs, outs=outs)
+    monkeypatch.setattr(ops, "linear_wgrad_f16_batch", counting)
+    res = {}
+    for arm in ("cross", "per_stack", "per_layer"):
+        m = _rqvae_768()
+        if frozen_encoder:
+            for p in m.encoder.parameters():
+                p.requires_grad_(False)
+        red = FlatGradReducer([p for p in m.parameters() if p.requires_grad]).attach(m)
+        b0, b1 = linear.use_wgrad_batch(arm != "per_layer"), linear.use_wgrad_cross_stack(arm == "cross")
+        try:
+            calls.clear()
+            red.zero_()
+            out = m(batch, 0.2)
+            out.loss.backward()
+            torch.cuda.synchronize()
+            assert not linear._XSTACK
+            res[arm] = (out.loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}, list(calls))
+        finally:
+            linear.use_wgrad_batch(b0)
+            linear.use_wgrad_cross_stack(b1)
+    assert res["cross"][2] == ([2] if frozen_encoder else [4]) and res["per_layer"][2] == []
+    assert res["per_stack"][2] == ([2] if frozen_encoder else [2, 2])
+    for arm in ("cross", "per_stack"):
+        assert torch.equal(res[arm][0], res["per_layer"][0])
+        for n, gref in res["per_layer"][1].items():
+            got = res[arm][1][n]
+            assert (got - gref).abs().max().item() <= 4e-6 * gref.abs().max().item() + 1e-12, (arm, n)
+
+
 def test_split_gemms_follow_the_optimizer():
     """The bf16-split GEMMs read the weights through an image that is rebuilt at every use: three optimiser steps with the
     FUSED AdamW (whose in-place update does not bump `Parameter._version` -- a version-keyed cache of the images trained on
