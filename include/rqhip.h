@@ -339,8 +339,9 @@ int rqhip_linear_wgrad_ex(const float *g, const float *y, const float *x, int64_
 int rqhip_linear_wgrad_f16(const float *g, const float *y, const float *x, int64_t M, int N, int K,
                            const unsigned *g_col_max, const unsigned *x_col_max, float *g_masked, float *dW,
                            void *workspace, size_t workspace_bytes, rqhip_stream_t stream);
-/* Several layers' weight gradients in ONE launch (ABI 462): dW_j [N_j, K_j] = g_j^T x_j for 2..4 layers over the same M rows, every dW tiled
- * 256 x 256 (N_j, K_j multiples of 256), g_j ALREADY masked by its layer's ReLU, f16x2 arithmetic under the column maxima (as
+/* Several layers' weight gradients in ONE launch (ABI 462): dW_j [N_j, K_j] = g_j^T x_j for 2..4 layers over the same M rows, EITHER every dW
+ * tiled 256 x 256 (N_j, K_j multiples of 256) OR every dW tiled 128 x 256 / 256 x 128 (one dimension a multiple of 256, the other of 128 but
+ * not 256; the two kinds mix freely), g_j ALREADY masked by its layer's ReLU, f16x2 arithmetic under the column maxima (as
  * rqhip_linear_wgrad_f16).  The jobs share one number of row ranges (rqhip_linear_wgrad_f16_batch_plan: CUs / tiles of all jobs; 0 = not
  * batchable), so the launch writes and reduces one workgroup's worth of partial blocks per CU for ALL its layers instead of per layer --
  * the weight gradients of reference modules/encoder.py:25-38's Linear layers, which autograd forms one by one.  Results are those of

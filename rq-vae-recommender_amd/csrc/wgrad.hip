@@ -336,7 +336,7 @@ static WgradPlan wgrad_plan(long long M, int N, int K) {
 
 int wgrad_split_cfg(int N, int K);   // wgrad_split.hip
 int launch_wgrad_split_jobs(int n, const float *const *g, const float *const *x, long long M, const int *N, const int *K, float *const *out,
-                            int msplit, const unsigned *const *g_max, const unsigned *const *x_max, hipStream_t s);
+                            int msplit, const unsigned *const *g_max, const unsigned *const *x_max, int half, hipStream_t s);
 int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, long long M, int N, int K, float *gm, float *out,
                        int nslab_n, int nslab_k, int msplit, const unsigned *g_max, const unsigned *x_max, hipStream_t s);
 
@@ -468,13 +468,20 @@ static int linear_wgrad_impl(const float *g, const float *y, const float *x, int
 // The common number of row ranges of a batch: the CU count over the tiles of all jobs, a multiple of 8 when there are that many (the
 // kernel then keeps the slabs of one range on one XCD), never more than the 32-row granules of the batch.  0: not batchable (a job
 // that is not tiled 256 x 256, fewer than two or more than four jobs, a batch of at most 128 rows, more tiles than CUs).
-static int wgrad_batch_ranges(long long M, const int *N, const int *K, int n) {
+// A batch is either all 256 x 256-tiled (wgrad_split_cfg 0) or all half-size tiles (cfg 1 / 2, freely mixed): *half says which.
+static int wgrad_batch_ranges(long long M, const int *N, const int *K, int n, int *half = nullptr) {
     if (n < 2 || n > 4 || M <= 128 || !N || !K) return 0;
     long long tiles = 0;
+    int n_full = 0;
     for (int j = 0; j < n; ++j) {
-        if (N[j] <= 0 || K[j] <= 0 || N[j] % 256 != 0 || K[j] % 256 != 0) return 0;
-        tiles += (long long)(N[j] / 256) * (K[j] / 256);
+        if (N[j] <= 0 || K[j] <= 0) return 0;
+        const int cfg = wgrad_split_cfg(N[j], K[j]);
+        if (cfg < 0) return 0;
+        n_full += cfg == 0;
+        tiles += (long long)(N[j] / (cfg == 1 ? 128 : 256)) * (K[j] / (cfg == 2 ? 128 : 256));
     }
+    if (n_full != 0 && n_full != n) return 0;
+    if (half) *half = n_full == 0;
     long long ms = cu_count() / tiles;
     if (ms < 1) return 0;
     if (ms >= 8) ms &= ~7LL;
@@ -512,10 +519,11 @@ extern "C" int rqhip_linear_wgrad_f16_batch(const rqhip_wgrad_job *jobs, int n, 
         }
         N[j] = b.N; K[j] = b.K; g[j] = b.g; x[j] = b.x; gm[j] = b.g_col_max; xm[j] = b.x_col_max;
     }
-    const int ms = wgrad_batch_ranges(M, N, K, n);
+    int half = 0;
+    const int ms = wgrad_batch_ranges(M, N, K, n, &half);
     if (ms < 1) {
-        set_error("linear_wgrad_f16_batch: not batchable (every dW tiled 256 x 256, more than 128 rows, tiles <= CUs: "
-                  "rqhip_linear_wgrad_f16_batch_plan)");
+        set_error("linear_wgrad_f16_batch: not batchable (every dW tiled 256 x 256, or every dW tiled 128 x 256 / 256 x 128; more than 128 rows; "
+                  "tiles <= CUs: rqhip_linear_wgrad_f16_batch_plan)");
         return RQHIP_EUNSUPPORTED;
     }
     if (ms > 1 && (!workspace || !al16(workspace) || workspace_bytes < rqhip_linear_wgrad_f16_batch_workspace_bytes(M, N, K, n))) {
@@ -532,7 +540,7 @@ extern "C" int rqhip_linear_wgrad_f16_batch(const rqhip_wgrad_job *jobs, int n, 
         bytes += 4.0 * (double)M * (N[j] + K[j]);
     }
     profile_begin(s, RQHIP_PROF_WGRAD, flops, bytes);
-    int rc = launch_wgrad_split_jobs(n, g, x, M, N, K, out, ms, gm, xm, s);
+    int rc = launch_wgrad_split_jobs(n, g, x, M, N, K, out, ms, gm, xm, half, s);
     if (rc) { profile_end(s); return rc; }
     if (ms > 1) {
         int pow2 = 1;

@@ -503,6 +503,28 @@ __global__ __launch_bounds__(64 * WA * WB) void wgrad_split_jobs_kernel(const Wg
     wgrad_split_body<TA, TB, WA, WB, false, NP>(p, (int)blockIdx.x - first);
 }
 
+// ... and the half-size tiles (dW tiled 128 x 256 or 256 x 128: the layers next to the 128-wide hidden activation) of two layers in one launch:
+// alone, such a layer is ONE tile cut into 256 row ranges of 390 rows -- 24 stages per workgroup between a prologue and a 128 KB flush.
+// cfg[j]: 1 = 128 x 256 tiles, 2 = 256 x 128 (wgrad_split_cfg); same threads and LDS bytes either way.
+struct WgradSplitJobsMixed {
+    WgradSplitJobs jobs;
+    int cfg[kWsMaxJobs];
+};
+template <int NP>
+__global__ __launch_bounds__(512) void wgrad_split_jobs_mixed_kernel(const WgradSplitJobsMixed m) {
+    WgradSplitParams p = m.jobs.p[0];
+    int first = 0, cfg = m.cfg[0];
+#pragma unroll
+    for (int j = 1; j < kWsMaxJobs; ++j)
+        if (j < m.jobs.n && (int)blockIdx.x >= m.jobs.first[j]) {
+            p = m.jobs.p[j];
+            first = m.jobs.first[j];
+            cfg = m.cfg[j];
+        }
+    if (cfg == 1) wgrad_split_body<2, 2, 2, 4, false, NP>(p, (int)blockIdx.x - first);
+    else wgrad_split_body<2, 2, 4, 2, false, NP>(p, (int)blockIdx.x - first);
+}
+
 // shapes the split kernel tiles: both dimensions multiples of 128 (every large layer of the 768-512-256-128 MLPs)
 int wgrad_split_cfg(int N, int K) {
     if (N % 256 == 0 && K % 256 == 0) return 0;
@@ -552,25 +574,40 @@ int launch_wgrad_split(int cfg, const float *g, const float *y, const float *x, 
 
 // The job-table launch: every job 256 x 256 tiles, f16x2 arithmetic, no mask, `msplit` row ranges each; out_j = job j's partial blocks
 // [msplit][N_j][K_j] (or dW itself when msplit == 1).
+// half == 0: every job 256 x 256 tiles; half == 1: every job 128 x 256 or 256 x 128 tiles (wgrad_split_cfg 1 / 2)
 int launch_wgrad_split_jobs(int n, const float *const *g, const float *const *x, long long M, const int *N, const int *K, float *const *out,
-                            int msplit, const unsigned *const *g_max, const unsigned *const *x_max, hipStream_t s) {
-    WgradSplitJobs jobs;
+                            int msplit, const unsigned *const *g_max, const unsigned *const *x_max, int half, hipStream_t s) {
+    WgradSplitJobsMixed m;
+    WgradSplitJobs &jobs = m.jobs;
     jobs.n = n;
     int blocks = 0;
     for (int j = 0; j < kWsMaxJobs; ++j) {
         const int i = j < n ? j : 0;
+        const int cfg = half ? wgrad_split_cfg(N[i], K[i]) : 0;
+        const int Nt = cfg == 1 ? 128 : 256, Kt = cfg == 2 ? 128 : 256;
         WgradSplitParams &p = jobs.p[j];
         p.g = g[i]; p.y = nullptr; p.x = x[i]; p.gm = nullptr; p.out = out[i];
-        p.M = M; p.N = N[i]; p.K = K[i]; p.nslab_n = N[i] / 256; p.nslab_k = K[i] / 256; p.msplit = msplit;
+        p.M = M; p.N = N[i]; p.K = K[i]; p.nslab_n = N[i] / Nt; p.nslab_k = K[i] / Kt; p.msplit = msplit;
         p.n_chunks = (M + 31) / 32;
         p.g_max = g_max[i]; p.x_max = x_max[i];
+        m.cfg[j] = cfg;
         jobs.first[j] = blocks;
         if (j < n) blocks += p.nslab_n * p.nslab_k * msplit;
     }
-    constexpr int TA = 4, TB = 2, WA = 2, WB = 4, NP = 2, Nt = 32 * TA * WA, Kt = 32 * TB * WB;
+    constexpr int NP = 2;
+    static LdsGrant grant, grant_half;
+    if (half) {
+        constexpr int Nt = 128, Kt = 256;      // (256 x 128: the same sum)
+        const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * NP * 2 * 16;
+        auto kern = wgrad_split_jobs_mixed_kernel<NP>;
+        RQ_RETURN_IF_HIP(grant_half.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, s, m);
+        RQ_CHECK_LAUNCH("wgrad_split_jobs_mixed_kernel");
+        return 0;
+    }
+    constexpr int TA = 4, TB = 2, WA = 2, WB = 4, Nt = 32 * TA * WA, Kt = 32 * TB * WB;
     const size_t lds = (size_t)2 * (4 * (Nt / 4 + 4) + 4 * (Kt / 4 + 4)) * NP * 2 * 16;
     auto kern = wgrad_split_jobs_kernel<TA, TB, WA, WB, NP>;
-    static LdsGrant grant;
     RQ_RETURN_IF_HIP(grant.ensure(reinterpret_cast<const void *>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * WA * WB), lds, s, jobs);
     RQ_CHECK_LAUNCH("wgrad_split_jobs_kernel");

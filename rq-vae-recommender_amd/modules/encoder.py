@@ -261,17 +261,19 @@ class _MLPStack(torch.autograd.Function):
                 _lin._launch_wgrads(waiting + [(weights[i], gm, a, gc, xc, sk) for i, gm, a, gc, xc, sk in batched])
                 for i, *_, sk in batched:
                     gws[i] = _adopt(sk, sk)
-            else:
+            else:       # (some gradient has no slice of a flat buffer to land in: fresh tensors, launched now)
                 _lin._launch_wgrads(waiting)
-                if len(batched) >= 2 and ops.linear_wgrad_f16_batch_ranges(M, [tuple(weights[i].shape) for i, *_ in batched]) >= 1:
-                    dws = ops.linear_wgrad_f16_batch([(gm, a, gc, xc) for _, gm, a, gc, xc, _ in batched], outs=[sk for *_, sk in batched])
-                    for (i, *_, sk), gw in zip(batched, dws):
-                        gws[i] = _adopt(gw, sk)
-                else:
-                    for i, gm, a, gc, xc, sk in batched:
-                        gw, _, _ = _lin.weight_grad(gm, None, a, weights[i], out=sk, want_masked=False, g_scales=_lin.Scales(None, gc),
-                                                    x_scales=_lin.Scales(None, xc), premasked=True)
-                        gws[i] = _adopt(gw, sk)
+                full = [b for b in batched if weights[b[0]].shape[0] % 256 == 0 and weights[b[0]].shape[1] % 256 == 0]
+                for group in (full, [b for b in batched if b not in full]):
+                    if len(group) >= 2 and ops.linear_wgrad_f16_batch_ranges(M, [tuple(weights[i].shape) for i, *_ in group]) >= 1:
+                        dws = ops.linear_wgrad_f16_batch([(gm, a, gc, xc) for _, gm, a, gc, xc, _ in group], outs=[sk for *_, sk in group])
+                        for (i, *_, sk), gw in zip(group, dws):
+                            gws[i] = _adopt(gw, sk)
+                    else:
+                        for i, gm, a, gc, xc, sk in group:
+                            gw, _, _ = _lin.weight_grad(gm, None, a, weights[i], out=sk, want_masked=False, g_scales=_lin.Scales(None, gc),
+                                                        x_scales=_lin.Scales(None, xc), premasked=True)
+                            gws[i] = _adopt(gw, sk)
         if pending:
             outs = [sk if sk is not None else torch.empty_like(weights[i]) for (i, _, _, sk) in pending]
             for (i, _, _, sk), gw in zip(pending, ops.linear_wgrad_jobs([(gm, a) for _, gm, a, _ in pending], outs=outs)):

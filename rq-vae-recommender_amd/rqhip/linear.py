@@ -258,7 +258,15 @@ def xstack_ok() -> bool:
 
 
 def _launch_wgrads(jobs: List[tuple]) -> None:
-    """jobs = [(w, g, x, g_cols, x_cols, sink), ...]: one batched launch where the plan allows (at most 4 per launch), else per layer."""
+    """jobs = [(w, g, x, g_cols, x_cols, sink), ...]: batched launches where the plan allows (layers tiled 256 x 256 together, layers tiled
+    128 x 256 / 256 x 128 together; at most 4 per launch), else per layer."""
+    full = [j for j in jobs if j[0].shape[0] % 256 == 0 and j[0].shape[1] % 256 == 0]
+    half = [j for j in jobs if not (j[0].shape[0] % 256 == 0 and j[0].shape[1] % 256 == 0)]
+    for group in (full, half):
+        _launch_wgrad_group(group)
+
+
+def _launch_wgrad_group(jobs: List[tuple]) -> None:
     while jobs:
         take, jobs = jobs[:4], jobs[4:]
         M = take[0][1].shape[0]
@@ -289,7 +297,7 @@ def xstack_take() -> List[tuple]:
 
 def wgrad_batch_shape_ok(n_out: int, n_in: int, rows: int) -> bool:
     """May this layer's weight gradient wait for the stack's batched launch?"""
-    return bool(_WGRAD_BATCH and wgrad_f16_ok(n_out, n_in, rows) and n_out % 256 == 0 and n_in % 256 == 0)
+    return bool(_WGRAD_BATCH and wgrad_f16_ok(n_out, n_in, rows))      # (tiled 256 x 256, 128 x 256 or 256 x 128: ops.linear_wgrad_f16_batch)
 
 
 _WGRAD_JOBS = True

@@ -536,7 +536,8 @@ def test_batched_weight_gradients_across_the_two_stacks(frozen_encoder, monkeypa
         finally:
             linear.use_wgrad_batch(b0)
             linear.use_wgrad_cross_stack(b1)
-    assert res["cross"][2] == ([2] if frozen_encoder else [4]) and res["per_layer"][2] == []
+    # (cross: the four 256 x 256-tiled layers, then the two half-tiled ones -- dW [256, 128] of the decoder, dW [128, 256] of the encoder)
+    assert res["cross"][2] == ([2] if frozen_encoder else [4, 2]) and res["per_layer"][2] == []
     assert res["per_stack"][2] == ([2] if frozen_encoder else [2, 2])
     for arm in ("cross", "per_stack"):
         assert torch.equal(res[arm][0], res["per_layer"][0])

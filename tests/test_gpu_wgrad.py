@@ -203,7 +203,8 @@ def test_wgrad_f16_operand_families_vs_fp64(N, K):
 
 
 @pytest.mark.parametrize("M", [100_000, 4100, 129])
-@pytest.mark.parametrize("shapes", [[(768, 512), (512, 256)], [(512, 768), (256, 512)], [(256, 256), (256, 256), (512, 256), (256, 512)]])
+@pytest.mark.parametrize("shapes", [[(768, 512), (512, 256)], [(512, 768), (256, 512)], [(256, 256), (256, 256), (512, 256), (256, 512)],
+                                    [(256, 128), (128, 256)], [(128, 256), (128, 512), (256, 128)]])
 def test_wgrad_f16_batch_vs_fp64_and_per_layer(M, shapes):
     """rqhip_linear_wgrad_f16_batch: the weight gradients of 2..4 layers tiled 256 x 256 in one launch, all cut into the plan's common number
     of row ranges.  Every dW is no further from fp64 than the library's fp32 GEMM of the same product (the gate of the per-layer kernel),
@@ -228,7 +229,8 @@ def test_wgrad_f16_batch_vs_fp64_and_per_layer(M, shapes):
         assert err <= max(lib, 2e-7 * ref.abs().max().item()), (err, lib)
         single = ops.linear_wgrad(g, None, x, g_col_max=gc, x_col_max=xc)[0]
         assert (dw - single).abs().max().item() <= 4e-6 * ref.abs().max().item()
-    assert ops.linear_wgrad_f16_batch_ranges(M, [(768, 512)]) == 0 and ops.linear_wgrad_f16_batch_ranges(M, [(768, 512), (256, 128)]) == 0
+    assert ops.linear_wgrad_f16_batch_ranges(M, [(768, 512)]) == 0 and ops.linear_wgrad_f16_batch_ranges(M, [(768, 512), (256, 128)]) == 0   # (one kind per launch)
+    assert ops.linear_wgrad_f16_batch_ranges(M, [(768, 512), (128, 32)]) == 0 and ops.linear_wgrad_f16_batch_ranges(M, [(256, 128), (128, 128)]) == 0
     assert ops.linear_wgrad_f16_batch_ranges(64, shapes) == 0
     with pytest.raises(ops.RqHipError):
         ops.linear_wgrad_f16_batch(jobs[:1])
