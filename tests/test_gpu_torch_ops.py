@@ -54,7 +54,16 @@ def test_registered_ops_equal_the_function_path_and_compile_traces_them():
     from rqhip import torch_ops
     m = _model()
     x = torch.nn.functional.normalize(torch.randn(5000, 768, device="cuda"), dim=-1)
-    ref_out, ref_g = _step(m, x)
+    from rqhip import linear
+    batched_out, batched_g = _step(m, x)        # the function path as shipped: its weight gradients in batched launches (csrc/wgrad_split.hip)
+    before = linear.use_wgrad_batch(False)      # ... and with one launch per layer, the operators' own form: the same arithmetic, bit for bit
+    try:
+        ref_out, ref_g = _step(m, x)
+    finally:
+        linear.use_wgrad_batch(before)
+    assert torch.equal(batched_out.loss, ref_out.loss)
+    for a, b in zip(batched_g, ref_g):          # (another number of row ranges: another balanced tree over the partial blocks)
+        assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item() + 1e-12
     torch_ops.enable(True)
     try:
         out, g = _step(m, x)

@@ -72,7 +72,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         k[f"{counter}_KB_mean"] = sum(vals) / len(vals)
         k["launches_fetch" if counter == "FETCH_SIZE" else "launches_write"] = len(vals)
 # ---- HBM bytes per launch SHAPE: the dispatches between the two marker launches of bench.py --pmc-window, matched in order to the tags ----
-MAIN = ("gemm_f16_kernel", "gemm_split_kernel", "wgrad_split_kernel", "wgrad_kernel<", "wgrad_jobs_kernel")
+MAIN = ("gemm_f16_kernel", "gemm_split_kernel", "wgrad_split_kernel", "wgrad_split_jobs_kernel", "wgrad_split_jobs_mixed_kernel", "wgrad_kernel<",
+        "wgrad_jobs_kernel")
 shape_bytes, shape_note = {}, []
 for counter, weight in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):     # gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)
     tags_file = os.path.join(SRC, f"window_tags_{counter}.json")
