@@ -725,7 +725,7 @@ def main():
         if dom_key is not None:
             dk, dfl, dby = dom_key
             dmean = float(np.mean(fam[dom_key]))
-            dom = {"kernel": {"gemm_split": "gemm_f16_kernel", "wgrad": "wgrad_split_kernel"}.get(dk, dk),
+            dom = {"kernel": {"gemm_split": "gemm_f16_kernel", "wgrad": "wgrad_split_jobs_kernel / wgrad_split_kernel (+ wgrad_reduce_kernel)"}.get(dk, dk),
                    "launches_per_step": round(len(fam[dom_key]) / n_rec, 2), "launch_ms_mean": round(dmean, 5),
                    "algorithmic_gflop_per_launch": round(dfl / 1e9, 3), "algorithmic_mb_per_launch": round(dby / 1e6, 2),
                    "issued_tflops": round(issued_mult * dfl / (dmean * 1e-3) / 1e12, 1),
@@ -753,7 +753,7 @@ def main():
                 fam_traffic_tw = round(tw_num / tw_den, 3)   # per-launch ratios weighted by launch time
         roofline_family = {
             "kernel": ("MLP matrix-kernel family: gemm_f16_kernel / gemm_split_kernel (activation GEMMs with ReLU / mask / reconstruction-"
-                       "loss epilogues) + wgrad_split_kernel (weight gradients), " f"{round(fam_launches / max(n_rec, 1), 1)} launches per step"
+                       "loss epilogues) + wgrad_split_jobs_kernel / wgrad_split_kernel (weight gradients, several layers per launch), " f"{round(fam_launches / max(n_rec, 1), 1)} launches per step"
                        if args.mlp != "library" else "library fp32 GEMMs are not recorded; fp32-MFMA weight gradients only"),
             "bound": "mfma",
             "achieved": round(issued_mult * fam_alg, 2), "peak": issued_peak, "unit": "TFLOP/s",
