@@ -230,12 +230,12 @@ __device__ __forceinline__ wg_f32x4 wg_add4(wg_f32x4 l, const wg_f32x4 r) {
     return l;
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, int pow2, int tlog,
-                                                           size_t nk4, float *__restrict__ dw) {
+__device__ __forceinline__ void wgrad_reduce_body(const float *__restrict__ part, int msplit, int pow2, int tlog, size_t nk4,
+                                                  float *__restrict__ dw, unsigned block) {
     __shared__ wg_f32x4 a[256];   // [q][e]
     const int T = 1 << tlog, E = 256 >> tlog;
     const int e = threadIdx.x & (E - 1), q = threadIdx.x >> (8 - tlog);
-    const size_t elem = (size_t)blockIdx.x * E + e;
+    const size_t elem = (size_t)block * E + e;
     const bool live = elem < nk4;
     const int lpt = pow2 >> tlog;                 // leaves per thread (a power of two >= 1)
     const wg_f32x4 *src = reinterpret_cast<const wg_f32x4 *>(part) + elem;
@@ -284,6 +284,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         __syncthreads();
     }
     if (q == 0 && live) reinterpret_cast<wg_f32x4 *>(dw)[elem] = a[e];
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int msplit, int pow2, int tlog,
+                                                           size_t nk4, float *__restrict__ dw) {
+    wgrad_reduce_body(part, msplit, pow2, tlog, nk4, dw, blockIdx.x);
+}
+
+// the reductions of a batched weight-gradient launch (rqhip_linear_wgrad_f16_batch) as ONE launch: same tree per job
+struct WgradReduceJobs {
+    const float *part[4];
+    float *dw[4];
+    size_t nk4[4];
+    int tlog[4];
+    unsigned first[4];
+    int n, msplit, pow2;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgradReduceJobs jobs) {
+    const float *part = jobs.part[0];
+    float *dw = jobs.dw[0];
+    size_t nk4 = jobs.nk4[0];
+    int tlog = jobs.tlog[0];
+    unsigned first = 0u;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < jobs.n && blockIdx.x >= jobs.first[j]) {
+            part = jobs.part[j]; dw = jobs.dw[j]; nk4 = jobs.nk4[j]; tlog = jobs.tlog[j]; first = jobs.first[j];
+        }
+    wgrad_reduce_body(part, jobs.msplit, jobs.pow2, tlog, nk4, dw, blockIdx.x - first);
 }
 
 // log2 of the subtrees per element: enough threads for a streaming launch, never more subtrees than leaves
@@ -545,14 +573,19 @@ extern "C" int rqhip_linear_wgrad_f16_batch(const rqhip_wgrad_job *jobs, int n, 
     if (ms > 1) {
         int pow2 = 1;
         while (pow2 < ms) pow2 <<= 1;
-        for (int j = 0; j < n; ++j) {       // the same balanced tree over a job's partial blocks as rqhip_linear_wgrad_f16's
-            const size_t nk4 = (size_t)N[j] * K[j] / 4;
-            const int tlog = wgrad_reduce_tlog(nk4, pow2);
-            const size_t per_wg = (size_t)256 >> tlog;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk4 + per_wg - 1) / per_wg)), dim3(256), 0, s, out[j], ms, pow2, tlog, nk4,
-                               jobs[j].dW);
-            RQ_CHECK_LAUNCH("wgrad_reduce_kernel");
+        WgradReduceJobs rj;                 // the same balanced tree over a job's partial blocks as rqhip_linear_wgrad_f16's, all jobs in one launch
+        rj.n = n; rj.msplit = ms; rj.pow2 = pow2;
+        unsigned blocks = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int i = j < n ? j : 0;
+            const size_t nk4 = (size_t)N[i] * K[i] / 4;
+            rj.part[j] = out[i]; rj.dw[j] = jobs[i].dW; rj.nk4[j] = nk4; rj.tlog[j] = wgrad_reduce_tlog(nk4, pow2);
+            rj.first[j] = blocks;
+            const size_t per_wg = (size_t)256 >> rj.tlog[j];
+            if (j < n) blocks += (unsigned)((nk4 + per_wg - 1) / per_wg);
         }
+        hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(blocks), dim3(256), 0, s, rj);
+        RQ_CHECK_LAUNCH("wgrad_reduce_jobs_kernel");
     }
     profile_end(s);
     return RQHIP_OK;

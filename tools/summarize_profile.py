@@ -98,7 +98,7 @@ for counter, weight in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):     # gfx950:
         if any(m in d["name"] for m in MAIN):
             cur = {"kb": d["kb"], "name": d["name"]}
             seq.append(cur)
-        elif "wgrad_reduce_kernel" in d["name"] and cur is not None:
+        elif ("wgrad_reduce_kernel" in d["name"] or "wgrad_reduce_jobs_kernel" in d["name"]) and cur is not None:
             cur["kb"] += d["kb"]               # the partial-block reduction belongs to the weight gradient before it
     if len(seq) != len(tags):
         shape_note.append(f"{counter}: {len(seq)} matrix dispatches in the window vs {len(tags)} tags")
