@@ -277,16 +277,26 @@ def _launch_wgrad_group(jobs: List[tuple]) -> None:
                 weight_grad(g, None, x, w, out=sk, want_masked=False, g_scales=Scales(None, gc), x_scales=Scales(None, xc), premasked=True)
 
 
+_XSTACK_STREAM: List = [None]      # the stream the waiting stack's backward ran on
+
+
 def xstack_flush() -> None:
-    """Launch whatever still waits (the engine's end-of-backward callback; also the start of every training forward, defensively)."""
+    """Launch whatever still waits: the autograd engine's end-of-backward callback.  It runs on the thread that called backward(), whose
+    current stream need not be the one the backward nodes ran on -- the launch goes to THAT stream (recorded by xstack_push)."""
     if _XSTACK:
         jobs, _XSTACK[:] = list(_XSTACK), []
-        _launch_wgrads(jobs)
+        st = _XSTACK_STREAM[0]
+        if st is not None and st != torch.cuda.current_stream(st.device):
+            with torch.cuda.stream(st):
+                _launch_wgrads(jobs)
+        else:
+            _launch_wgrads(jobs)
 
 
 def xstack_push(jobs: List[tuple]) -> None:
     if not _XSTACK:
         torch.autograd.Variable._execution_engine.queue_callback(xstack_flush)
+        _XSTACK_STREAM[0] = torch.cuda.current_stream()
     _XSTACK.extend(jobs)
 
 
