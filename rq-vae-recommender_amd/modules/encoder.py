@@ -274,10 +274,18 @@ class _MLPStack(torch.autograd.Function):
                             gw, _, _ = _lin.weight_grad(gm, None, a, weights[i], out=sk, want_masked=False, g_scales=_lin.Scales(None, gc),
                                                         x_scales=_lin.Scales(None, xc), premasked=True)
                             gws[i] = _adopt(gw, sk)
-        if pending:
-            outs = [sk if sk is not None else torch.empty_like(weights[i]) for (i, _, _, sk) in pending]
-            for (i, _, _, sk), gw in zip(pending, ops.linear_wgrad_jobs([(gm, a) for _, gm, a, _ in pending], outs=outs)):
-                gws[i] = _adopt(gw, sk)
+        waiting_small = _lin.xsmall_take() if g_out.is_cuda else []      # an earlier stack's job-table weight gradients
+        if pending or waiting_small:
+            sunk = all(sk is not None for *_, sk in pending)
+            if pending and not waiting_small and ctx.defer and sunk and _lin.xsmall_ok():
+                _lin.xsmall_push([(gm, a, sk) for _, gm, a, sk in pending])      # (a later stack's launch, or the end-of-backward callback)
+                for i, *_, sk in pending:
+                    gws[i] = _adopt(sk, sk)
+            else:
+                outs = [sk if sk is not None else torch.empty_like(weights[i]) for (i, _, _, sk) in pending]
+                _lin._launch_small(waiting_small + [(gm, a, o) for (_, gm, a, _), o in zip(pending, outs)])
+                for (i, _, _, sk), o in zip(pending, outs):
+                    gws[i] = _adopt(o, sk)
         return (g if ctx.needs_input_grad[0] else None), None, None, None, *gws
 
 

@@ -224,6 +224,7 @@ class RqVae(nn.Module, PyTorchModelHubMixin):
         n = self.n_cat_feats
         seam = self._seam_weights(xin)
         _lin._XSTACK.clear()       # (weight gradients of a backward pass that ended in an exception do not outlive it)
+        _lin._XSMALL.clear()
         reconstruction = x_hat = p_unique_ids = side = None
         if seam is not None:
             # the seam: the encoder up to its last hidden activation, then ONE launch for the last encoder Linear, every level and the

@@ -305,6 +305,45 @@ def xstack_take() -> List[tuple]:
     return jobs
 
 
+# ---- the same for the job-table launch of the reference's batch sizes (< 4096 rows, csrc/wgrad_jobs.hip): one launch for BOTH stacks' layers --------
+# (also inside a hipGraph capture: the engine's end-of-backward callback runs inside the captured region like everything else of the step)
+_XSMALL: List[tuple] = []            # (g, x, sink)
+
+
+def xsmall_ok() -> bool:
+    from . import dist as _dist
+    return bool(_XSTACK_ON and _WGRAD_JOBS and _dist.world_size() == 1)
+
+
+def _launch_small(jobs: List[tuple]) -> None:
+    while jobs:
+        take, jobs = jobs[:ops.WGRAD_JOBS_MAX], jobs[ops.WGRAD_JOBS_MAX:]
+        ops.linear_wgrad_jobs([(g, x) for g, x, _ in take], outs=[sk for *_, sk in take])
+
+
+def xsmall_flush() -> None:
+    if _XSMALL:
+        jobs, _XSMALL[:] = list(_XSMALL), []
+        st = _XSTACK_STREAM[0]
+        if st is not None and st != torch.cuda.current_stream(st.device):
+            with torch.cuda.stream(st):
+                _launch_small(jobs)
+        else:
+            _launch_small(jobs)
+
+
+def xsmall_push(jobs: List[tuple]) -> None:
+    if not _XSMALL:
+        torch.autograd.Variable._execution_engine.queue_callback(xsmall_flush)
+        _XSTACK_STREAM[0] = torch.cuda.current_stream()
+    _XSMALL.extend(jobs)
+
+
+def xsmall_take() -> List[tuple]:
+    jobs, _XSMALL[:] = list(_XSMALL), []
+    return jobs
+
+
 def wgrad_batch_shape_ok(n_out: int, n_in: int, rows: int) -> bool:
     """May this layer's weight gradient wait for the stack's batched launch?"""
     return bool(_WGRAD_BATCH and wgrad_f16_ok(n_out, n_in, rows))      # (tiled 256 x 256, 128 x 256 or 256 x 128: ops.linear_wgrad_f16_batch)

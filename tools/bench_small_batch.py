@@ -33,7 +33,10 @@ if "--no-seam" in sys.argv:      # A/B: round 5's library GEMMs for the 128 <-> 
 if "--no-small" in sys.argv:     # A/B: round 5's library GEMMs + threshold_backward launches instead of csrc/mlp_small.hip
     from rqhip import linear as _linear
     _linear.use_small_kernels(False)
-ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs", "--no-seam", "--no-small")]
+if "--no-cross-stack" in sys.argv:   # A/B: one job-table weight-gradient launch per MLP stack instead of one for both (rqhip/linear.py:xsmall_*)
+    from rqhip import linear as _linear
+    _linear.use_wgrad_cross_stack(False)
+ARGS = [a for a in sys.argv[1:] if a not in ("--json", "--no-jobs", "--no-seam", "--no-small", "--no-cross-stack")]
 
 
 def timeit(fn, n=200):
@@ -60,11 +63,16 @@ def run(c3: bool, B: int, say=print):
     x = torch.nn.functional.normalize(torch.randn(B, 768, device="cuda"), dim=-1)
     batch = SeqBatch(None, None, None, x, None, None)
 
+    # the step as train_rqvae.train runs it (_GraphedStep._step): gradients in one flat buffer (rqhip.dist.FlatGradReducer, zeroed per step), a
+    # cached seed for backward()
+    from rqhip import dist as rqdist
+    red = rqdist.FlatGradReducer(m.parameters()).attach(m)
+    seed = torch.ones((), dtype=torch.float32, device="cuda")
+
     def step():
-        for p in m.parameters():
-            p.grad = None
+        red.zero_()
         out = m(batch, 0.2)
-        out.loss.backward()
+        out.loss.backward(gradient=seed)
         opt.step()
         return out.loss
 
@@ -96,8 +104,6 @@ def run(c3: bool, B: int, say=print):
                 step()
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        for p in m.parameters():
-            p.grad = None
         with torch.cuda.graph(g):
             loss = step()
         ms = timeit(g.replay)
