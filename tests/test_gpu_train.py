@@ -49,6 +49,29 @@ def test_train_amazon_config_short_run_checkpoint_and_resume(tmp_path, monkeypat
     assert res2["loss"] == res2["loss"]
 
 
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_train_loop_at_a_split_kernel_batch(tmp_path, monkeypatch, accumulate):
+    """The gin-driven loop at a batch the split kernels take (8192 rows): the seam launch, the static-schedule GEMMs, and the weight gradients of
+    both MLP stacks in the batched launches (the decoder's waiting for the encoder's when the gradients live in the flat buffer; with gradient
+    accumulation the later micro-batches take the per-stack launches).  The loss falls like the per-layer path's, step for step to rounding."""
+    import numpy as np
+    from rqhip import linear
+    losses = {}
+    for arm in ("batched", "per_layer"):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        before = linear.use_wgrad_batch(arm == "batched")
+        try:
+            res, _ = _run("rqvae_amazon.gin", tmp_path, monkeypatch, batch_size=8192, dataset_folder="synthetic:20000", iterations=8,
+                          eval_every=1000, save_model_every=1000, gradient_accumulate_every=accumulate, use_hip_graph=False)
+        finally:
+            linear.use_wgrad_batch(before)
+        assert not linear._XSTACK and not linear._XSMALL
+        losses[arm] = res["loss"]
+        assert res["loss"] == res["loss"] and res["loss"] < 5.0
+    assert abs(losses["batched"] - losses["per_layer"]) <= 2e-4 * abs(losses["per_layer"])
+
+
 def test_train_ml32m_hyperparameters_rotation_trick(tmp_path, monkeypatch):
     """configs/rqvae_ml32m.gin: D = 64, ROTATION_TRICK, batch 64, k-means init (train() default)."""
     import numpy as np
